@@ -1,0 +1,195 @@
+/*
+ * infur_hip.h -- C ABI of the MI355X-native InFur segmentation hot path.
+ *
+ * This is the drop-in boundary: exactly the calls the reference's three `Processor`
+ * implementations on the per-frame path would bind over FFI (the Rust-side stubs are in
+ * INTEGRATION.md).  Citations are path:line in the reference tree (ahirner/infur v0.2.0).
+ *
+ *   Scale      infur/src/processing.rs:179-282   -> infur_scale_validate / _out_dims / infur_scale
+ *   Model<f32> infur/src/predict_onnx.rs:283-345 -> infur_model_load / _info / infur_model_advance
+ *   ColorCode  infur/src/decode_predict.rs:41-84 -> infur_colorcode
+ *   app graph  infur/src/app.rs:107-153          -> infur_frame_advance (scale->model->decode fused)
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no C++ or torch types.  All functions return an
+ *     int32_t status (0 = ok) and never throw or abort; infur_last_error(ctx) gives the
+ *     detail string for the last failing call on that context.
+ *   - One `infur_ctx` = one GPU + one HIP stream + its device arena.  A context is NOT
+ *     thread-safe: use it from one thread at a time, as the reference's `&mut self`
+ *     processors are (infur/src/main.rs:38-40).
+ *   - The caller owns every buffer it passes; the context owns all device memory it
+ *     allocates.  Functions ending in `_dev` take device pointers (resident data, no PCIe
+ *     copy) and are asynchronous on the context's stream; the host-pointer forms copy in,
+ *     run, copy out and return after the results are in the caller's buffers.
+ *   - There is no CPU fallback: without a usable HIP device infur_ctx_create fails with
+ *     INFUR_E_HIP.
+ */
+#ifndef INFUR_HIP_H
+#define INFUR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INFUR_ABI_VERSION 1
+
+/* status codes */
+enum {
+    INFUR_OK = 0,
+    INFUR_E_INVALID_SCALE = 1,    /* ValidScaleError, processing.rs:161-163 (factor <= 0) */
+    INFUR_E_ZERO_SIZE_IN = 2,     /* ScaleProcError::ZeroSizeIn, processing.rs:203-204 */
+    INFUR_E_ZERO_SIZE_OUT = 3,    /* ScaleProcError::ZeroSizeOut, processing.rs:205-206 */
+    INFUR_E_SHAPE = 4,            /* ModelProcError::ShapeError, predict_onnx.rs:35-36 */
+    INFUR_E_MODEL_NOT_LOADED = 5, /* advance without a model where one is required */
+    INFUR_E_MODEL_FORMAT = 6,     /* ModelCmdError / ModelInputFormatError, predict_onnx.rs:41-54 */
+    INFUR_E_HIP = 7,              /* HIP runtime error (ModelProcError::RuntimeError analogue) */
+    INFUR_E_RCCL = 8,             /* reserved: collective error in the multi-GPU host layer */
+    INFUR_E_INVALID_ARG = 9,
+    INFUR_E_IO = 10,              /* model file could not be read */
+    INFUR_E_CAPACITY = 11         /* caller's output buffer is too small */
+};
+
+/* Scale resampling mode */
+enum {
+    INFUR_SCALE_NEAREST = 0, /* the reference's fr::ResizeAlg::Nearest, processing.rs:189 */
+    INFUR_SCALE_BILINEAR = 1 /* north-star extension (todo at processing.rs:224) */
+};
+
+/* arithmetic type of the conv stack */
+enum {
+    INFUR_DTYPE_F32 = 0 /* exact f32 MFMA (v_mfma_f32_32x32x2_f32) */
+};
+
+typedef struct infur_ctx infur_ctx;
+
+typedef struct infur_options {
+    uint32_t struct_size;  /* = sizeof(infur_options) */
+    int32_t device;        /* HIP device ordinal */
+    uint32_t compute_dtype; /* INFUR_DTYPE_* */
+    uint32_t compute_aux;  /* 1: evaluate the aux head as the ONNX graph does (default 1) */
+    uint32_t profile;      /* 1: bracket every kernel with HIP events (infur_profile_*) */
+    uint32_t keep_activations; /* 1: debug -- every conv output keeps its own buffer */
+    void* stream;          /* optional caller-owned hipStream_t; NULL = context creates one */
+} infur_options;
+
+/* ModelInfo, predict_onnx.rs:56-62 */
+typedef struct infur_model_info {
+    char input_name[32];    /* "input" */
+    char input0_dtype[16];  /* "Float" */
+    char output_names[2][32]; /* "out", "aux" */
+    uint32_t n_outputs;
+    uint32_t num_classes;
+    uint32_t depth;         /* 50 | 101 */
+    uint32_t n_convs;
+    uint64_t weight_bytes;
+} infur_model_info;
+
+/* one profiled kernel launch of the last advance */
+typedef struct infur_kernel_record {
+    char name[48];      /* layer name, e.g. "backbone.layer4.1.conv2" */
+    char kernel[32];    /* kernel family, e.g. "conv_igemm_f32" */
+    float ms;           /* HIP-event duration */
+    double flops;       /* algorithmic FLOPs (2 x MAC); 0 for byte kernels */
+    double bytes;       /* algorithmic (compulsory) HBM bytes */
+} infur_kernel_record;
+
+/* ---- library ---- */
+uint32_t infur_abi_version(void);
+const char* infur_status_string(int32_t status);
+/* number of visible HIP devices (0 when there is none); never fails */
+int32_t infur_device_count(void);
+
+/* ---- context ---- */
+void infur_options_default(infur_options* opts);
+int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out);
+void infur_ctx_destroy(infur_ctx* ctx);
+const char* infur_last_error(const infur_ctx* ctx);
+int32_t infur_ctx_synchronize(infur_ctx* ctx);
+void* infur_ctx_stream(infur_ctx* ctx); /* the hipStream_t all work is enqueued on */
+
+/* ---- Scale (processing.rs:142-282); host-only helpers need no context ---- */
+/* ValidScale::try_from (processing.rs:158-168): INFUR_E_INVALID_SCALE iff factor <= 0 */
+int32_t infur_scale_validate(float factor);
+/* output dims and the ZeroSizeIn / ZeroSizeOut checks (processing.rs:238-256) */
+int32_t infur_scale_out_dims(uint32_t w, uint32_t h, float factor, uint32_t* ow, uint32_t* oh);
+/* replaces self.resizer.resize (processing.rs:278) and the unit-scale clone (:238-242).
+ * bgr: packed B,G,R u8, h*w*3 bytes (image-ext/src/image_bgr.rs:7-11).  out: capacity bytes. */
+int32_t infur_scale(infur_ctx* ctx, const uint8_t* bgr, uint32_t w, uint32_t h, float factor,
+                    uint32_t mode, uint8_t* out, size_t out_capacity, uint32_t* ow, uint32_t* oh);
+int32_t infur_scale_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t h, float factor,
+                        uint32_t mode, void* d_out, size_t out_capacity, uint32_t* ow,
+                        uint32_t* oh);
+
+/* ---- Model (predict_onnx.rs:283-345) ---- */
+/* ModelCmd::Load(path) (predict_onnx.rs:288-312): empty path unloads.  The file is an
+ * INFURW01 weight blob (infur_amd/weights.py). */
+int32_t infur_model_load(infur_ctx* ctx, const char* path);
+int32_t infur_model_load_blob(infur_ctx* ctx, const void* blob, size_t len);
+/* blob already resident on this context's device (e.g. after an RCCL broadcast) */
+int32_t infur_model_load_blob_dev(infur_ctx* ctx, const void* d_blob, size_t len);
+int32_t infur_model_unload(infur_ctx* ctx);
+/* Model::get_info (predict_onnx.rs:341-345): INFUR_E_MODEL_NOT_LOADED when none */
+int32_t infur_model_info_get(const infur_ctx* ctx, infur_model_info* info);
+/* Model::advance (predict_onnx.rs:317-334): pre-proc (:97-140) + forward (:138) + batch
+ * strip (:326-330).  out / aux: [num_classes, h, w] f32 planar, either may be NULL.
+ * With no model loaded this is a no-op returning INFUR_OK (predict_onnx.rs:318,333) and
+ * *n_outputs (optional) is set to 0; otherwise to 2. */
+int32_t infur_model_advance(infur_ctx* ctx, const uint8_t* bgr, uint32_t w, uint32_t h,
+                            float* out, float* aux, uint32_t* n_outputs);
+int32_t infur_model_advance_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t h,
+                                void* d_out, void* d_aux, uint32_t* n_outputs);
+/* output-stride-8 logits of the last advance, [num_classes, lh, lw] f32 planar (host) */
+int32_t infur_model_lowres_dims(uint32_t h, uint32_t w, uint32_t* lh, uint32_t* lw);
+int32_t infur_model_read_lowres(infur_ctx* ctx, float* out_low, float* aux_low, uint32_t* lh,
+                                uint32_t* lw);
+/* debug (needs keep_activations): output of conv #index of the last advance as
+ * [C, H, W] f32 planar; cap_floats = capacity of host_chw */
+int32_t infur_debug_read_activation(infur_ctx* ctx, uint32_t index, float* host_chw,
+                                    size_t cap_floats, uint32_t* c, uint32_t* h, uint32_t* w);
+
+/* pre-proc on its own (predict_onnx.rs:103-137): packed BGR u8 -> [3,h,w] f32, RGB planar,
+ * ((v*1)/255 - mean) * (1/std).  The fused path folds this into the stem convolution; it is
+ * exported so this stage can be parity-checked (and used) in isolation. */
+int32_t infur_pack_normalize(infur_ctx* ctx, const uint8_t* bgr, uint32_t w, uint32_t h,
+                             float* chw);
+int32_t infur_pack_normalize_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t h,
+                                 void* d_chw);
+
+/* ---- ColorCode (decode_predict.rs:32-79) ---- */
+/* khw: [k, h, w] f32 planar confidences; rgba: h*w*4 bytes premultiplied [r,g,b,a] */
+int32_t infur_colorcode(infur_ctx* ctx, const float* khw, uint32_t k, uint32_t h, uint32_t w,
+                        uint8_t* rgba);
+int32_t infur_colorcode_dev(infur_ctx* ctx, const void* d_khw, uint32_t k, uint32_t h,
+                            uint32_t w, void* d_rgba);
+
+/* ---- fused per-frame path (app.rs:107-153): scale -> model -> decode(out[0]) ---- */
+/* rgba: oh*ow*4 bytes.  scaled_bgr (optional): the scaled frame, oh*ow*3 bytes (the GUI
+ * shows it, app.rs:132-144).  With no model loaded returns INFUR_E_MODEL_NOT_LOADED after
+ * producing scaled_bgr (the reference clears the mask, app.rs:127-129). */
+int32_t infur_frame_advance(infur_ctx* ctx, const uint8_t* bgr, uint32_t w, uint32_t h,
+                            float factor, uint32_t scale_mode, uint8_t* rgba,
+                            size_t rgba_capacity, uint8_t* scaled_bgr, uint32_t* ow,
+                            uint32_t* oh);
+int32_t infur_frame_advance_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t h,
+                                float factor, uint32_t scale_mode, void* d_rgba,
+                                size_t rgba_capacity, void* d_scaled_bgr, uint32_t* ow,
+                                uint32_t* oh);
+
+/* ---- profiling (options.profile = 1) ---- */
+/* number of kernel records of the last advance (synchronises the stream) */
+int32_t infur_profile_count(infur_ctx* ctx, uint32_t* n);
+int32_t infur_profile_get(infur_ctx* ctx, uint32_t i, infur_kernel_record* rec);
+
+/* ---- device memory helpers for bindings without a HIP runtime of their own ---- */
+int32_t infur_dev_alloc(infur_ctx* ctx, size_t bytes, void** d_ptr);
+int32_t infur_dev_free(infur_ctx* ctx, void* d_ptr);
+int32_t infur_memcpy_h2d(infur_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int32_t infur_memcpy_d2h(infur_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFUR_HIP_H */

@@ -1,0 +1,138 @@
+"""ctypes binding of ``libinfur_hip.so`` (the C ABI declared in include/infur_hip.h).
+
+There is no fallback: if the shared library is missing or does not load, importing
+the product path fails loudly with instructions to build it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinfur_hip.so")
+
+# status codes (include/infur_hip.h)
+OK = 0
+E_INVALID_SCALE = 1
+E_ZERO_SIZE_IN = 2
+E_ZERO_SIZE_OUT = 3
+E_SHAPE = 4
+E_MODEL_NOT_LOADED = 5
+E_MODEL_FORMAT = 6
+E_HIP = 7
+E_RCCL = 8
+E_INVALID_ARG = 9
+E_IO = 10
+E_CAPACITY = 11
+
+SCALE_NEAREST, SCALE_BILINEAR = 0, 1
+DTYPE_F32 = 0
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("compute_dtype", C.c_uint32),
+        ("compute_aux", C.c_uint32),
+        ("profile", C.c_uint32),
+        ("keep_activations", C.c_uint32),
+        ("stream", C.c_void_p),
+    ]
+
+
+class ModelInfoC(C.Structure):
+    _fields_ = [
+        ("input_name", C.c_char * 32),
+        ("input0_dtype", C.c_char * 16),
+        ("output_names", (C.c_char * 32) * 2),
+        ("n_outputs", C.c_uint32),
+        ("num_classes", C.c_uint32),
+        ("depth", C.c_uint32),
+        ("n_convs", C.c_uint32),
+        ("weight_bytes", C.c_uint64),
+    ]
+
+
+class KernelRecord(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 48),
+        ("kernel", C.c_char * 32),
+        ("ms", C.c_float),
+        ("flops", C.c_double),
+        ("bytes", C.c_double),
+    ]
+
+
+_u32p = C.POINTER(C.c_uint32)
+_vp = C.c_void_p
+_sz = C.c_size_t
+_u32 = C.c_uint32
+_f = C.c_float
+
+# every symbol include/infur_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "infur_abi_version": (C.c_uint32, []),
+    "infur_status_string": (C.c_char_p, [C.c_int32]),
+    "infur_device_count": (C.c_int32, []),
+    "infur_options_default": (None, [C.POINTER(Options)]),
+    "infur_ctx_create": (C.c_int32, [C.POINTER(Options), C.POINTER(_vp)]),
+    "infur_ctx_destroy": (None, [_vp]),
+    "infur_last_error": (C.c_char_p, [_vp]),
+    "infur_ctx_synchronize": (C.c_int32, [_vp]),
+    "infur_ctx_stream": (_vp, [_vp]),
+    "infur_scale_validate": (C.c_int32, [_f]),
+    "infur_scale_out_dims": (C.c_int32, [_u32, _u32, _f, _u32p, _u32p]),
+    "infur_scale": (C.c_int32, [_vp, _vp, _u32, _u32, _f, _u32, _vp, _sz, _u32p, _u32p]),
+    "infur_scale_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _f, _u32, _vp, _sz, _u32p, _u32p]),
+    "infur_model_load": (C.c_int32, [_vp, C.c_char_p]),
+    "infur_model_load_blob": (C.c_int32, [_vp, _vp, _sz]),
+    "infur_model_load_blob_dev": (C.c_int32, [_vp, _vp, _sz]),
+    "infur_model_unload": (C.c_int32, [_vp]),
+    "infur_model_info_get": (C.c_int32, [_vp, C.POINTER(ModelInfoC)]),
+    "infur_model_advance": (C.c_int32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32p]),
+    "infur_model_advance_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32p]),
+    "infur_model_lowres_dims": (C.c_int32, [_u32, _u32, _u32p, _u32p]),
+    "infur_model_read_lowres": (C.c_int32, [_vp, _vp, _vp, _u32p, _u32p]),
+    "infur_debug_read_activation": (C.c_int32, [_vp, _u32, _vp, _sz, _u32p, _u32p, _u32p]),
+    "infur_pack_normalize": (C.c_int32, [_vp, _vp, _u32, _u32, _vp]),
+    "infur_pack_normalize_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _vp]),
+    "infur_colorcode": (C.c_int32, [_vp, _vp, _u32, _u32, _u32, _vp]),
+    "infur_colorcode_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _u32, _vp]),
+    "infur_frame_advance": (C.c_int32, [_vp, _vp, _u32, _u32, _f, _u32, _vp, _sz, _vp, _u32p, _u32p]),
+    "infur_frame_advance_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _f, _u32, _vp, _sz, _vp, _u32p, _u32p]),
+    "infur_profile_count": (C.c_int32, [_vp, _u32p]),
+    "infur_profile_get": (C.c_int32, [_vp, _u32, C.POINTER(KernelRecord)]),
+    "infur_dev_alloc": (C.c_int32, [_vp, _sz, C.POINTER(_vp)]),
+    "infur_dev_free": (C.c_int32, [_vp, _vp]),
+    "infur_memcpy_h2d": (C.c_int32, [_vp, _vp, _vp, _sz]),
+    "infur_memcpy_d2h": (C.c_int32, [_vp, _vp, _vp, _sz]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP extension; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C infur_amd/csrc). "
+            "infur_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.infur_abi_version() != 1:
+        raise ImportError("libinfur_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def status_string(code: int) -> str:
+    return load().infur_status_string(code).decode()

@@ -1,0 +1,988 @@
+// infur_capi.cpp -- host runtime behind the C ABI in include/infur_hip.h.
+//
+// One infur_ctx = one GPU, one HIP stream, a pooled activation arena, the resident weights
+// of one FCN-ResNet and the small lookup tables of the pre/post stages.  Everything is
+// enqueued on the context's stream; the host-pointer entry points copy in, run, copy out
+// and synchronise.  There is deliberately no CPU fallback anywhere in this file.
+//
+// Reference behaviour mirrored here (path:line in ahirner/infur):
+//   Scale       infur/src/processing.rs:142-282
+//   Model       infur/src/predict_onnx.rs:97-142, 283-345
+//   ColorCode   infur/src/decode_predict.rs:9-79
+//   stage order infur/src/app.rs:107-153
+#include "../../include/infur_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace infur;
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool used = false;
+};
+
+struct Tensor {  // NHWC f32 activation living in the pool
+    float* p = nullptr;
+    int h = 0, w = 0, c = 0;
+    int slot = -1;
+    size_t floats() const { return (size_t)h * w * c; }
+};
+
+struct ConvLayer {
+    std::string name;
+    int cout = 0, cin = 0, k = 0, stride = 1, pad = 0, dil = 1;
+    bool relu = false;
+    char role = 0;        // s stem, 1 2 3 block convs, d downsample, h head3x3, c classifier
+    float* d_w = nullptr;  // repacked weights
+    float* d_b = nullptr;
+};
+
+struct ProfRec {
+    std::string name;
+    const char* kernel;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct infur_ctx {
+    infur_options opt{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // lookup tables
+    float* d_pre_lut = nullptr;     // [3][256] f32, RGB order
+    uint32_t* d_color_lut = nullptr;  // [20][256] premultiplied RGBA
+
+    // model
+    bool loaded = false;
+    infur_model_info info{};
+    int depth = 0, num_classes = 0;
+    bool has_aux = false;
+    std::vector<ConvLayer> convs;
+    void* d_weights = nullptr;  // single allocation holding every repacked tensor
+    size_t weight_bytes = 0;
+
+    // activation pool + results of the last forward
+    std::vector<Buf> pool;
+    Tensor out_low, aux_low;  // NHWC [lh][lw][K]
+    int last_h = 0, last_w = 0;
+    std::vector<Tensor> kept;  // keep_activations: output of every conv
+
+    // staging for the host-pointer entry points
+    Buf st_in, st_scaled, st_rgba, st_f32a, st_f32b;
+
+    // profiling
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_free;
+};
+
+namespace {
+
+int32_t fail(infur_ctx* c, int32_t code, const char* fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail((c), INFUR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define RETIF(expr)                 \
+    do {                            \
+        int32_t rc__ = (expr);      \
+        if (rc__ != INFUR_OK) return rc__; \
+    } while (0)
+
+int32_t ensure(infur_ctx* c, Buf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return INFUR_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return INFUR_OK;
+}
+
+// ---- activation pool: stream-ordered reuse on the single context stream ----
+int32_t pool_acquire(infur_ctx* c, size_t bytes, int* slot) {
+    int best = -1;
+    for (size_t i = 0; i < c->pool.size(); i++) {
+        Buf& b = c->pool[i];
+        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < c->pool[best].bytes)) best = (int)i;
+    }
+    if (best < 0) {
+        Buf b;
+        HIPCHK(c, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+        c->pool.push_back(b);
+        best = (int)c->pool.size() - 1;
+    }
+    c->pool[best].used = true;
+    *slot = best;
+    return INFUR_OK;
+}
+
+void pool_release(infur_ctx* c, Tensor& t) {
+    if (c->opt.keep_activations) return;
+    if (t.slot >= 0) c->pool[t.slot].used = false;
+    t.slot = -1;
+}
+
+void pool_release_all(infur_ctx* c) {
+    for (auto& b : c->pool) b.used = false;
+    c->kept.clear();
+    c->out_low = Tensor();
+    c->aux_low = Tensor();
+}
+
+void pool_free(infur_ctx* c) {
+    for (auto& b : c->pool)
+        if (b.p) (void)hipFree(b.p);
+    c->pool.clear();
+}
+
+int32_t talloc(infur_ctx* c, int h, int w, int ch, Tensor* t) {
+    t->h = h;
+    t->w = w;
+    t->c = ch;
+    int slot;
+    RETIF(pool_acquire(c, t->floats() * sizeof(float), &slot));
+    t->slot = slot;
+    t->p = (float*)c->pool[slot].p;
+    return INFUR_OK;
+}
+
+// ---- profiling ----
+struct ProfScope {
+    infur_ctx* c;
+    bool on;
+    ProfRec r;
+    ProfScope(infur_ctx* c_, const std::string& name, const char* kernel, double flops, double bytes)
+        : c(c_), on(c_->opt.profile != 0) {
+        if (!on) return;
+        r.name = name;
+        r.kernel = kernel;
+        r.flops = flops;
+        r.bytes = bytes;
+        for (hipEvent_t* e : {&r.e0, &r.e1}) {
+            if (!c->ev_free.empty()) {
+                *e = c->ev_free.back();
+                c->ev_free.pop_back();
+            } else {
+                (void)hipEventCreate(e);
+            }
+        }
+        (void)hipEventRecord(r.e0, c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, c->stream);
+        c->prof.push_back(r);
+    }
+};
+
+void prof_reset(infur_ctx* c) {
+    for (auto& r : c->prof) {
+        c->ev_free.push_back(r.e0);
+        c->ev_free.push_back(r.e1);
+    }
+    c->prof.clear();
+}
+
+// ---- lookup tables (host side, exact reference operation order) ----
+// predict_onnx.rs:128 `f32::from(v) * 1f32 / 255f32`, :131-136 `(x - mean) * (1/std)`;
+// ColorNorm::new_torchvision_rgb :175-180.  volatile keeps every rounding step.
+void build_pre_lut(float* lut) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int ch = 0; ch < 3; ch++) {
+        volatile float std1 = 1.0f / stdv[ch];
+        for (int v = 0; v < 256; v++) {
+            volatile float x = ((float)v * 1.0f) / 255.0f;
+            volatile float d = x - mean[ch];
+            lut[ch * 256 + v] = d * std1;
+        }
+    }
+}
+
+// COLORS_PALETTE, decode_predict.rs:9-30
+const uint8_t kPalette[20][3] = {
+    {75, 180, 60},   {75, 25, 230},   {25, 225, 255},  {200, 130, 0},   {48, 130, 245},
+    {240, 240, 70},  {230, 50, 240},  {60, 245, 210},  {180, 30, 145},  {190, 190, 250},
+    {128, 128, 0},   {255, 190, 230}, {40, 110, 170},  {200, 250, 255}, {0, 0, 128},
+    {195, 255, 170}, {0, 128, 128},   {180, 215, 255}, {128, 0, 0},     {128, 128, 128},
+};
+
+// epaint 0.19 Color32::from_rgba_unmultiplied (called at decode_predict.rs:35): gamma-aware
+// premultiply.  The device kernels only index the resulting table.
+float lin_from_gamma_u8(uint8_t s) {
+    if (s <= 10) return (float)s / 3294.6f;
+    return powf(((float)s + 14.025f) / 269.025f, 2.4f);
+}
+uint8_t round_u8(float r) {
+    float f = floorf(r + 0.5f);
+    if (!(f == f) || f <= 0.0f) return 0;
+    if (f >= 255.0f) return 255;
+    return (uint8_t)f;
+}
+uint8_t gamma_u8_from_lin(float l) {
+    if (l <= 0.0f) return 0;
+    if (l <= 0.0031308f) return round_u8(3294.6f * l);
+    if (l <= 1.0f) return round_u8(269.025f * powf(l, 1.0f / 2.4f) - 14.025f);
+    return 255;
+}
+void build_color_lut(uint32_t* lut) {
+    for (int k = 0; k < 20; k++)
+        for (int a = 0; a < 256; a++) {
+            uint8_t r = kPalette[k][0], g = kPalette[k][1], b = kPalette[k][2], o[4];
+            if (a == 255) {
+                o[0] = r; o[1] = g; o[2] = b; o[3] = 255;
+            } else if (a == 0) {
+                o[0] = o[1] = o[2] = o[3] = 0;
+            } else {
+                const float al = (float)a / 255.0f;
+                o[0] = gamma_u8_from_lin(lin_from_gamma_u8(r) * al);
+                o[1] = gamma_u8_from_lin(lin_from_gamma_u8(g) * al);
+                o[2] = gamma_u8_from_lin(lin_from_gamma_u8(b) * al);
+                o[3] = (uint8_t)a;
+            }
+            lut[k * 256 + a] = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+        }
+}
+
+// ---- Scale host logic (processing.rs:158-168, 238-256) ----
+uint32_t f32_as_u32(float v) {  // Rust `as u32`: saturating, NaN -> 0
+    if (!(v == v) || v <= 0.0f) return 0;
+    if (v >= 4294967296.0f) return 4294967295u;
+    return (uint32_t)v;
+}
+
+int conv_out(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
+
+// ---- graph description: torchvision fcn_resnet{50,101}, output stride 8 ----
+bool layer_blocks(int depth, int lb[4]) {
+    if (depth == 50) { lb[0] = 3; lb[1] = 4; lb[2] = 6; lb[3] = 3; return true; }
+    if (depth == 101) { lb[0] = 3; lb[1] = 4; lb[2] = 23; lb[3] = 3; return true; }
+    return false;
+}
+
+std::vector<ConvLayer> build_graph(int depth, int ncls, bool aux) {
+    std::vector<ConvLayer> g;
+    int lb[4];
+    layer_blocks(depth, lb);
+    auto add = [&](const std::string& n, int cout, int cin, int k, int s, int p, int d, bool relu, char role) {
+        ConvLayer c;
+        c.name = n; c.cout = cout; c.cin = cin; c.k = k; c.stride = s; c.pad = p; c.dil = d;
+        c.relu = relu; c.role = role;
+        g.push_back(c);
+    };
+    add("backbone.conv1", 64, 3, 7, 2, 3, 1, true, 's');
+    int inplanes = 64, dilation = 1;
+    for (int L = 0; L < 4; L++) {
+        const int planes = 64 << L;
+        int stride = L == 0 ? 1 : 2;
+        const int prev = dilation;
+        if (L >= 2) {  // replace_stride_with_dilation = [False, True, True]
+            dilation *= stride;
+            stride = 1;
+        }
+        for (int b = 0; b < lb[L]; b++) {
+            const int bs = b == 0 ? stride : 1, bd = b == 0 ? prev : dilation;
+            const std::string p = "backbone.layer" + std::to_string(L + 1) + "." + std::to_string(b);
+            add(p + ".conv1", planes, inplanes, 1, 1, 0, 1, true, '1');
+            add(p + ".conv2", planes, planes, 3, bs, bd, bd, true, '2');
+            add(p + ".conv3", planes * 4, planes, 1, 1, 0, 1, true, '3');
+            if (b == 0) add(p + ".downsample.0", planes * 4, inplanes, 1, bs, 0, 1, false, 'd');
+            inplanes = planes * 4;
+        }
+    }
+    add("classifier.0", 512, 2048, 3, 1, 1, 1, true, 'h');
+    add("classifier.4", ncls, 512, 1, 1, 0, 1, false, 'c');
+    if (aux) {
+        add("aux_classifier.0", 256, 1024, 3, 1, 1, 1, true, 'h');
+        add("aux_classifier.4", ncls, 256, 1, 1, 0, 1, false, 'c');
+    }
+    return g;
+}
+
+constexpr size_t kBlobHdr = 32, kBlobEntry = 80;
+
+void model_free(infur_ctx* c) {
+    if (c->d_weights) (void)hipFree(c->d_weights);
+    c->d_weights = nullptr;
+    c->convs.clear();
+    c->loaded = false;
+    c->weight_bytes = 0;
+    pool_release_all(c);
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// d_blob: INFURW01 blob resident on the device.  Parses the directory (copied to the host),
+// checks it against the expected graph and repacks every tensor into kernel layout.
+int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
+    if (len < kBlobHdr) return fail(c, INFUR_E_MODEL_FORMAT, "weight blob too short (%zu bytes)", len);
+    uint8_t hdr[kBlobHdr];
+    HIPCHK(c, hipMemcpyAsync(hdr, d_blob, kBlobHdr, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (memcmp(hdr, "INFURW01", 8) != 0) return fail(c, INFUR_E_MODEL_FORMAT, "bad magic: not an INFURW01 weight blob");
+    uint32_t h32[6];
+    memcpy(h32, hdr + 8, 24);
+    const int depth = (int)h32[0], ncls = (int)h32[1];
+    const bool aux = h32[2] != 0;
+    const uint32_t n = h32[3];
+    int lb[4];
+    if (!layer_blocks(depth, lb)) return fail(c, INFUR_E_MODEL_FORMAT, "unsupported backbone depth %d (50 or 101)", depth);
+    if (ncls <= 0 || ncls > 256) return fail(c, INFUR_E_MODEL_FORMAT, "unsupported class count %d", ncls);
+    std::vector<ConvLayer> g = build_graph(depth, ncls, aux);
+    if (n != g.size()) return fail(c, INFUR_E_MODEL_FORMAT, "blob has %u convs, graph needs %zu", n, g.size());
+    if (kBlobHdr + (size_t)n * kBlobEntry > len) return fail(c, INFUR_E_MODEL_FORMAT, "truncated conv table");
+    std::vector<uint8_t> table((size_t)n * kBlobEntry);
+    HIPCHK(c, hipMemcpyAsync(table.data(), (const uint8_t*)d_blob + kBlobHdr, table.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    struct Ent { uint64_t w_off, b_off; };
+    std::vector<Ent> ents(n);
+    size_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint8_t* e = table.data() + (size_t)i * kBlobEntry;
+        char name[41];
+        memcpy(name, e, 40);
+        name[40] = 0;
+        uint32_t d[4];
+        memcpy(d, e + 40, 16);
+        memcpy(&ents[i].w_off, e + 56, 8);
+        memcpy(&ents[i].b_off, e + 64, 8);
+        const ConvLayer& L = g[i];
+        if (L.name != name) return fail(c, INFUR_E_MODEL_FORMAT, "conv %u is '%s', expected '%s'", i, name, L.name.c_str());
+        if ((int)d[0] != L.cout || (int)d[1] != L.cin || (int)d[2] != L.k || (int)d[3] != L.k)
+            return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' has shape [%u,%u,%u,%u], expected [%d,%d,%d,%d]", name, d[0], d[1], d[2], d[3], L.cout, L.cin, L.k, L.k);
+        const size_t wn = (size_t)L.cout * L.cin * L.k * L.k * 4, bn = (size_t)L.cout * 4;
+        if (ents[i].w_off % 4 || ents[i].b_off % 4 || ents[i].w_off + wn > len || ents[i].b_off + bn > len)
+            return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' data out of range", name);
+        total += align_up(wn, 256) + align_up(bn, 256);
+    }
+
+    model_free(c);
+    HIPCHK(c, hipMalloc(&c->d_weights, total));
+    size_t off = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        ConvLayer& L = g[i];
+        const size_t wn = (size_t)L.cout * L.cin * L.k * L.k * 4, bn = (size_t)L.cout * 4;
+        L.d_w = (float*)((uint8_t*)c->d_weights + off);
+        off += align_up(wn, 256);
+        L.d_b = (float*)((uint8_t*)c->d_weights + off);
+        off += align_up(bn, 256);
+        const float* src_w = (const float*)((const uint8_t*)d_blob + ents[i].w_off);
+        if (L.role == 's')
+            HIPCHK(c, launch_repack_stem(src_w, L.d_w, c->stream));
+        else if (L.k == 1)
+            HIPCHK(c, hipMemcpyAsync(L.d_w, src_w, wn, hipMemcpyDeviceToDevice, c->stream));  // OI11 == O11I
+        else
+            HIPCHK(c, launch_repack_oihw_to_ohwi(src_w, L.d_w, L.cout, L.cin, L.k, L.k, c->stream));
+        HIPCHK(c, hipMemcpyAsync(L.d_b, (const uint8_t*)d_blob + ents[i].b_off, bn, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->convs.swap(g);
+    c->depth = depth;
+    c->num_classes = ncls;
+    c->has_aux = aux;
+    c->weight_bytes = total;
+    c->loaded = true;
+    infur_model_info& mi = c->info;
+    memset(&mi, 0, sizeof mi);
+    // names as the reference prints them: "input -> out,aux" (predict_onnx.rs:378-380)
+    snprintf(mi.input_name, sizeof mi.input_name, "input");
+    snprintf(mi.input0_dtype, sizeof mi.input0_dtype, "Float");
+    snprintf(mi.output_names[0], 32, "out");
+    snprintf(mi.output_names[1], 32, "aux");
+    mi.n_outputs = 2;
+    mi.num_classes = (uint32_t)ncls;
+    mi.depth = (uint32_t)depth;
+    mi.n_convs = n;
+    mi.weight_bytes = total;
+    return INFUR_OK;
+}
+
+// ---- one convolution on the implicit-GEMM kernel ----
+int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, Tensor* out) {
+    const int oh = conv_out(in.h, L.k, L.stride, L.pad, L.dil), ow = conv_out(in.w, L.k, L.stride, L.pad, L.dil);
+    RETIF(talloc(c, oh, ow, L.cout, out));
+    ConvArgs a;
+    a.in = in.p; a.wt = L.d_w; a.bias = L.d_b; a.res = res ? res->p : nullptr; a.out = out->p;
+    a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = L.cout;
+    a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = L.relu ? 1 : 0;
+    const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
+    const double bytes = 4.0 * ((double)in.floats() + (double)out->floats() * (res ? 2 : 1) + (double)L.cout * L.cin * L.k * L.k);
+    {
+        ProfScope ps(c, L.name, L.k == 1 ? "conv_igemm_f32_1x1" : "conv_igemm_f32_3x3", flops, bytes);
+        HIPCHK(c, launch_conv_igemm_f32(a, c->stream));
+    }
+    if (c->opt.keep_activations) c->kept.push_back(*out);
+    return INFUR_OK;
+}
+
+// FCN-ResNet forward from a packed BGR frame resident on the device.
+// Leaves the output-stride-8 logits in c->out_low / c->aux_low (NHWC).
+int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
+    if (w <= 0 || h <= 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %dx%d", w, h);
+    pool_release_all(c);
+    prof_reset(c);
+    size_t ci = 0;
+    const ConvLayer& stem = c->convs[ci++];
+    Tensor s, x;
+    {
+        const int oh = conv_out(h, 7, 2, 3, 1), ow = conv_out(w, 7, 2, 3, 1);
+        RETIF(talloc(c, oh, ow, 64, &s));
+        ProfScope ps(c, stem.name, "stem_conv7x7", 2.0 * oh * ow * 64 * 147, (double)h * w * 3 + 4.0 * s.floats());
+        HIPCHK(c, launch_stem_conv7x7(d_bgr, h, w, stem.d_w, stem.d_b, c->d_pre_lut, s.p, oh, ow, c->stream));
+    }
+    if (c->opt.keep_activations) c->kept.push_back(s);
+    {
+        const int oh = conv_out(s.h, 3, 2, 1, 1), ow = conv_out(s.w, 3, 2, 1, 1);
+        RETIF(talloc(c, oh, ow, 64, &x));
+        ProfScope ps(c, "backbone.maxpool", "maxpool3x3s2", 0, 4.0 * (s.floats() + x.floats()));
+        HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, x.p, oh, ow, c->stream));
+    }
+    pool_release(c, s);
+
+    Tensor l3;
+    while (c->convs[ci].role == '1') {
+        const ConvLayer& c1 = c->convs[ci];
+        const ConvLayer& c2 = c->convs[ci + 1];
+        const ConvLayer& c3 = c->convs[ci + 2];
+        const bool has_ds = c->convs[ci + 3].role == 'd';
+        Tensor t1, t2, idt, y;
+        RETIF(run_conv(c, c1, x, nullptr, &t1));
+        RETIF(run_conv(c, c2, t1, nullptr, &t2));
+        pool_release(c, t1);
+        if (has_ds) {
+            // keep_activations order follows the blob (conv3 before downsample): fix up below
+            RETIF(run_conv(c, c->convs[ci + 3], x, nullptr, &idt));
+        }
+        RETIF(run_conv(c, c3, t2, has_ds ? &idt : &x, &y));
+        if (has_ds && c->opt.keep_activations) std::swap(c->kept[c->kept.size() - 1], c->kept[c->kept.size() - 2]);
+        pool_release(c, t2);
+        if (has_ds) pool_release(c, idt);
+        ci += has_ds ? 4 : 3;
+        const bool end_l3 = c1.name.compare(0, 16, "backbone.layer3.") == 0 &&
+                            c->convs[ci].name.compare(0, 16, "backbone.layer4.") == 0;
+        // the layer3 output feeds the aux head: it stays acquired until that head has run
+        if (!(l3.p && x.p == l3.p)) pool_release(c, x);
+        x = y;
+        if (end_l3 && c->has_aux && c->opt.compute_aux) l3 = y;
+    }
+    {
+        Tensor h1;
+        RETIF(run_conv(c, c->convs[ci], x, nullptr, &h1));
+        // x (layer4 output) may alias l3 only when there is no layer4 -- never for 50/101
+        pool_release(c, x);
+        RETIF(run_conv(c, c->convs[ci + 1], h1, nullptr, &c->out_low));
+        pool_release(c, h1);
+        ci += 2;
+    }
+    if (c->has_aux && c->opt.compute_aux) {
+        Tensor a1;
+        RETIF(run_conv(c, c->convs[ci], l3, nullptr, &a1));
+        pool_release(c, l3);
+        RETIF(run_conv(c, c->convs[ci + 1], a1, nullptr, &c->aux_low));
+        pool_release(c, a1);
+    }
+    c->last_h = h;
+    c->last_w = w;
+    return INFUR_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+uint32_t infur_abi_version(void) { return INFUR_ABI_VERSION; }
+
+const char* infur_status_string(int32_t s) {
+    switch (s) {
+        case INFUR_OK: return "ok";
+        case INFUR_E_INVALID_SCALE: return "Cannot scale by negative number";  // processing.rs:163
+        case INFUR_E_ZERO_SIZE_IN: return "scaling from 0-sized input";        // processing.rs:203
+        case INFUR_E_ZERO_SIZE_OUT: return "scaling to 0-sized output";        // processing.rs:205
+        case INFUR_E_SHAPE: return "couldn't transform image";                 // predict_onnx.rs:35
+        case INFUR_E_MODEL_NOT_LOADED: return "no model loaded";
+        case INFUR_E_MODEL_FORMAT: return "couldn't load model";
+        case INFUR_E_HIP: return "HIP runtime error";
+        case INFUR_E_RCCL: return "RCCL error";
+        case INFUR_E_INVALID_ARG: return "invalid argument";
+        case INFUR_E_IO: return "couldn't read model file";
+        case INFUR_E_CAPACITY: return "output buffer too small";
+        default: return "unknown status";
+    }
+}
+
+int32_t infur_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void infur_options_default(infur_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->struct_size = sizeof *o;
+    o->compute_dtype = INFUR_DTYPE_F32;
+    o->compute_aux = 1;
+}
+
+int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
+    if (!out) return INFUR_E_INVALID_ARG;
+    *out = nullptr;
+    infur_options o;
+    infur_options_default(&o);
+    if (opts) {
+        if (opts->struct_size != sizeof(infur_options)) return INFUR_E_INVALID_ARG;
+        o = *opts;
+    }
+    if (o.compute_dtype != INFUR_DTYPE_F32) return INFUR_E_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || o.device < 0 || o.device >= n) return INFUR_E_HIP;
+    if (hipSetDevice(o.device) != hipSuccess) return INFUR_E_HIP;
+    infur_ctx* c = new infur_ctx();
+    c->opt = o;
+    c->device = o.device;
+    if (o.stream) {
+        c->stream = (hipStream_t)o.stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return INFUR_E_HIP;
+        }
+        c->own_stream = true;
+    }
+    std::vector<float> pre(768);
+    std::vector<uint32_t> col(20 * 256);
+    build_pre_lut(pre.data());
+    build_color_lut(col.data());
+    bool ok = hipMalloc((void**)&c->d_pre_lut, pre.size() * 4) == hipSuccess &&
+              hipMalloc((void**)&c->d_color_lut, col.size() * 4) == hipSuccess &&
+              hipMemcpy(c->d_pre_lut, pre.data(), pre.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(c->d_color_lut, col.data(), col.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        infur_ctx_destroy(c);
+        return INFUR_E_HIP;
+    }
+    *out = c;
+    return INFUR_OK;
+}
+
+void infur_ctx_destroy(infur_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    model_free(c);
+    pool_free(c);
+    for (Buf* b : {&c->st_in, &c->st_scaled, &c->st_rgba, &c->st_f32a, &c->st_f32b})
+        if (b->p) (void)hipFree(b->p);
+    prof_reset(c);
+    for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    if (c->d_pre_lut) (void)hipFree(c->d_pre_lut);
+    if (c->d_color_lut) (void)hipFree(c->d_color_lut);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* infur_last_error(const infur_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int32_t infur_ctx_synchronize(infur_ctx* c) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+
+void* infur_ctx_stream(infur_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- Scale ----
+int32_t infur_scale_validate(float factor) {
+    // ValidScale::try_from (processing.rs:161-163): only `<= 0` is rejected; NaN passes
+    return factor <= 0.0f ? INFUR_E_INVALID_SCALE : INFUR_OK;
+}
+
+int32_t infur_scale_out_dims(uint32_t w, uint32_t h, float factor, uint32_t* ow, uint32_t* oh) {
+    if (!ow || !oh) return INFUR_E_INVALID_ARG;
+    if (factor == 1.0f) {  // unit scale clones before any size check (processing.rs:238-242)
+        *ow = w;
+        *oh = h;
+        return INFUR_OK;
+    }
+    if (w == 0 || h == 0) return INFUR_E_ZERO_SIZE_IN;  // processing.rs:247-248
+    const uint32_t nw = f32_as_u32((float)w * factor), nh = f32_as_u32((float)h * factor);  // :253-254
+    if (nw == 0 || nh == 0) return INFUR_E_ZERO_SIZE_OUT;  // :255-256
+    *ow = nw;
+    *oh = nh;
+    return INFUR_OK;
+}
+
+int32_t infur_scale_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
+                        void* d_out, size_t cap, uint32_t* ow, uint32_t* oh) {
+    if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
+    if (mode > INFUR_SCALE_BILINEAR) return fail(c, INFUR_E_INVALID_ARG, "unknown scale mode %u", mode);
+    int32_t rc = infur_scale_validate(factor);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    rc = infur_scale_out_dims(w, h, factor, ow, oh);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    const size_t need = (size_t)*ow * *oh * 3;
+    if (need == 0) return INFUR_OK;
+    if (!d_bgr || !d_out) return INFUR_E_INVALID_ARG;
+    if (cap < need) return fail(c, INFUR_E_CAPACITY, "scaled frame needs %zu bytes, buffer has %zu", need, cap);
+    if (factor == 1.0f) {
+        HIPCHK(c, hipMemcpyAsync(d_out, d_bgr, need, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        ProfScope ps(c, "scale", mode ? "scale_bilinear" : "scale_nearest", 0, (double)w * h * 3 + (double)need);
+        HIPCHK(c, launch_scale_bgr((const uint8_t*)d_bgr, (int)w, (int)h, (uint8_t*)d_out, (int)*ow, (int)*oh, (int)mode, c->stream));
+    }
+    return INFUR_OK;
+}
+
+int32_t infur_scale(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
+                    uint8_t* out, size_t cap, uint32_t* ow, uint32_t* oh) {
+    if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
+    int32_t rc = infur_scale_validate(factor);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    rc = infur_scale_out_dims(w, h, factor, ow, oh);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    const size_t in_bytes = (size_t)w * h * 3, need = (size_t)*ow * *oh * 3;
+    if (need == 0) return INFUR_OK;
+    if (!bgr || !out) return INFUR_E_INVALID_ARG;
+    if (cap < need) return fail(c, INFUR_E_CAPACITY, "scaled frame needs %zu bytes, buffer has %zu", need, cap);
+    RETIF(ensure(c, c->st_in, in_bytes));
+    RETIF(ensure(c, c->st_scaled, need));
+    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
+    RETIF(infur_scale_dev(c, c->st_in.p, w, h, factor, mode, c->st_scaled.p, c->st_scaled.bytes, ow, oh));
+    HIPCHK(c, hipMemcpyAsync(out, c->st_scaled.p, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+
+// ---- Model ----
+int32_t infur_model_unload(infur_ctx* c) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    model_free(c);
+    return INFUR_OK;
+}
+
+int32_t infur_model_load_blob_dev(infur_ctx* c, const void* d_blob, size_t len) {
+    if (!c || !d_blob) return INFUR_E_INVALID_ARG;
+    return model_load_dev(c, d_blob, len);
+}
+
+int32_t infur_model_load_blob(infur_ctx* c, const void* blob, size_t len) {
+    if (!c || !blob) return INFUR_E_INVALID_ARG;
+    if (len < kBlobHdr || memcmp(blob, "INFURW01", 8) != 0)
+        return fail(c, INFUR_E_MODEL_FORMAT, "bad magic: not an INFURW01 weight blob");
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, len));
+    hipError_t e = hipMemcpyAsync(d, blob, len, hipMemcpyHostToDevice, c->stream);
+    int32_t rc = e == hipSuccess ? model_load_dev(c, d, len) : fail(c, INFUR_E_HIP, "weight upload failed: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+int32_t infur_model_load(infur_ctx* c, const char* path) {
+    if (!c || !path) return INFUR_E_INVALID_ARG;
+    if (path[0] == 0) return infur_model_unload(c);  // ModelCmd::Load("") unloads, predict_onnx.rs:310-312
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(c, INFUR_E_IO, "couldn't open model file '%s'", path);
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> buf(n > 0 ? (size_t)n : 0);
+    const size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    if (got != buf.size()) return fail(c, INFUR_E_IO, "short read on '%s'", path);
+    if (buf.empty()) return fail(c, INFUR_E_MODEL_FORMAT, "model file '%s' is empty", path);
+    return infur_model_load_blob(c, buf.data(), buf.size());
+}
+
+int32_t infur_model_info_get(const infur_ctx* c, infur_model_info* info) {
+    if (!c || !info) return INFUR_E_INVALID_ARG;
+    if (!c->loaded) return INFUR_E_MODEL_NOT_LOADED;
+    *info = c->info;
+    return INFUR_OK;
+}
+
+int32_t infur_model_lowres_dims(uint32_t h, uint32_t w, uint32_t* lh, uint32_t* lw) {
+    if (!lh || !lw || h == 0 || w == 0) return INFUR_E_INVALID_ARG;
+    int a = (int)h, b = (int)w;
+    a = conv_out(a, 7, 2, 3, 1); b = conv_out(b, 7, 2, 3, 1);
+    a = conv_out(a, 3, 2, 1, 1); b = conv_out(b, 3, 2, 1, 1);
+    a = conv_out(a, 3, 2, 1, 1); b = conv_out(b, 3, 2, 1, 1);
+    *lh = (uint32_t)a;
+    *lw = (uint32_t)b;
+    return INFUR_OK;
+}
+
+int32_t infur_model_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, void* d_out, void* d_aux,
+                                uint32_t* n_outputs) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    if (n_outputs) *n_outputs = 0;
+    if (!c->loaded) return INFUR_OK;  // no session: out untouched, Ok(()) (predict_onnx.rs:318,333)
+    if (!d_bgr) return INFUR_E_INVALID_ARG;
+    if (w == 0 || h == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
+    RETIF(forward(c, (const uint8_t*)d_bgr, (int)w, (int)h));
+    const int K = c->num_classes;
+    const double up_bytes = 4.0 * ((double)c->out_low.floats() + (double)K * h * w);
+    if (d_out) {
+        ProfScope ps(c, "out.resize", "upsample_planar", 0, up_bytes);
+        HIPCHK(c, launch_upsample_planar(c->out_low.p, c->out_low.h, c->out_low.w, K, (float*)d_out, (int)h, (int)w, c->stream));
+    }
+    if (d_aux) {
+        if (!c->aux_low.p) return fail(c, INFUR_E_INVALID_ARG, "aux output requested but the aux head is disabled");
+        ProfScope ps(c, "aux.resize", "upsample_planar", 0, up_bytes);
+        HIPCHK(c, launch_upsample_planar(c->aux_low.p, c->aux_low.h, c->aux_low.w, K, (float*)d_aux, (int)h, (int)w, c->stream));
+    }
+    if (n_outputs) *n_outputs = 2;
+    return INFUR_OK;
+}
+
+int32_t infur_model_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float* out, float* aux,
+                            uint32_t* n_outputs) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    if (n_outputs) *n_outputs = 0;
+    if (!c->loaded) return INFUR_OK;
+    if (!bgr) return INFUR_E_INVALID_ARG;
+    if (w == 0 || h == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
+    const size_t in_bytes = (size_t)w * h * 3, lg = (size_t)c->num_classes * w * h * 4;
+    RETIF(ensure(c, c->st_in, in_bytes));
+    if (out) RETIF(ensure(c, c->st_f32a, lg));
+    if (aux) RETIF(ensure(c, c->st_f32b, lg));
+    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
+    RETIF(infur_model_advance_dev(c, c->st_in.p, w, h, out ? c->st_f32a.p : nullptr, aux ? c->st_f32b.p : nullptr, n_outputs));
+    if (out) HIPCHK(c, hipMemcpyAsync(out, c->st_f32a.p, lg, hipMemcpyDeviceToHost, c->stream));
+    if (aux) HIPCHK(c, hipMemcpyAsync(aux, c->st_f32b.p, lg, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+
+int32_t infur_model_read_lowres(infur_ctx* c, float* out_low, float* aux_low, uint32_t* lh, uint32_t* lw) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    if (!c->loaded || !c->out_low.p) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no forward pass has run");
+    const Tensor& t = c->out_low;
+    if (lh) *lh = (uint32_t)t.h;
+    if (lw) *lw = (uint32_t)t.w;
+    const size_t bytes = t.floats() * 4;
+    RETIF(ensure(c, c->st_f32a, bytes));
+    for (int i = 0; i < 2; i++) {
+        float* dst = i == 0 ? out_low : aux_low;
+        const Tensor& src = i == 0 ? c->out_low : c->aux_low;
+        if (!dst) continue;
+        if (!src.p) return fail(c, INFUR_E_INVALID_ARG, "aux output requested but the aux head is disabled");
+        HIPCHK(c, launch_nhwc_to_planar(src.p, src.h, src.w, src.c, (float*)c->st_f32a.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dst, c->st_f32a.p, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return INFUR_OK;
+}
+
+int32_t infur_debug_read_activation(infur_ctx* c, uint32_t index, float* host, size_t cap, uint32_t* ch, uint32_t* h,
+                                    uint32_t* w) {
+    if (!c || !host) return INFUR_E_INVALID_ARG;
+    if (!c->opt.keep_activations) return fail(c, INFUR_E_INVALID_ARG, "context was created without keep_activations");
+    if (index >= c->kept.size()) return fail(c, INFUR_E_INVALID_ARG, "activation %u of %zu", index, c->kept.size());
+    const Tensor& t = c->kept[index];
+    if (ch) *ch = (uint32_t)t.c;
+    if (h) *h = (uint32_t)t.h;
+    if (w) *w = (uint32_t)t.w;
+    if (cap < t.floats()) return fail(c, INFUR_E_CAPACITY, "activation needs %zu floats", t.floats());
+    RETIF(ensure(c, c->st_f32a, t.floats() * 4));
+    HIPCHK(c, launch_nhwc_to_planar(t.p, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(host, c->st_f32a.p, t.floats() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+
+// ---- pre-proc alone ----
+int32_t infur_pack_normalize_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, void* d_chw) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    if ((size_t)w * h == 0) return INFUR_OK;
+    if (!d_bgr || !d_chw) return INFUR_E_INVALID_ARG;
+    ProfScope ps(c, "pre-proc", "pack_normalize", 0, (double)w * h * 15.0);
+    HIPCHK(c, launch_pack_normalize((const uint8_t*)d_bgr, (int)w, (int)h, c->d_pre_lut, (float*)d_chw, c->stream));
+    return INFUR_OK;
+}
+
+int32_t infur_pack_normalize(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float* chw) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    const size_t npix = (size_t)w * h;
+    if (npix == 0) return INFUR_OK;
+    if (!bgr || !chw) return INFUR_E_INVALID_ARG;
+    RETIF(ensure(c, c->st_in, npix * 3));
+    RETIF(ensure(c, c->st_f32a, npix * 12));
+    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
+    RETIF(infur_pack_normalize_dev(c, c->st_in.p, w, h, c->st_f32a.p));
+    HIPCHK(c, hipMemcpyAsync(chw, c->st_f32a.p, npix * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+
+// ---- ColorCode ----
+int32_t infur_colorcode_dev(infur_ctx* c, const void* d_khw, uint32_t k, uint32_t h, uint32_t w, void* d_rgba) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    if ((size_t)h * w == 0) return INFUR_OK;  // empty image: nothing to write (decode_predict.rs:68 zips 0 pixels)
+    if (!d_rgba || (k > 0 && !d_khw)) return INFUR_E_INVALID_ARG;
+    ProfScope ps(c, "colorcode", "colorcode_planar", 0, (double)h * w * (4.0 * k + 4.0));
+    HIPCHK(c, launch_colorcode_planar((const float*)d_khw, (int)k, (int)h, (int)w, c->d_color_lut, (uint32_t*)d_rgba, c->stream));
+    return INFUR_OK;
+}
+
+int32_t infur_colorcode(infur_ctx* c, const float* khw, uint32_t k, uint32_t h, uint32_t w, uint8_t* rgba) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    const size_t hw = (size_t)h * w;
+    if (hw == 0) return INFUR_OK;
+    if (!rgba || (k > 0 && !khw)) return INFUR_E_INVALID_ARG;
+    RETIF(ensure(c, c->st_f32a, hw * (k ? k : 1) * 4));
+    RETIF(ensure(c, c->st_rgba, hw * 4));
+    if (k) HIPCHK(c, hipMemcpyAsync(c->st_f32a.p, khw, hw * k * 4, hipMemcpyHostToDevice, c->stream));
+    RETIF(infur_colorcode_dev(c, c->st_f32a.p, k, h, w, c->st_rgba.p));
+    HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, hw * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+
+// ---- fused frame path ----
+int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
+                                void* d_rgba, size_t cap, void* d_scaled, uint32_t* ow, uint32_t* oh) {
+    if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
+    if (mode > INFUR_SCALE_BILINEAR) return fail(c, INFUR_E_INVALID_ARG, "unknown scale mode %u", mode);
+    int32_t rc = infur_scale_validate(factor);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    rc = infur_scale_out_dims(w, h, factor, ow, oh);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    if (!d_bgr) return INFUR_E_INVALID_ARG;
+    const size_t sbytes = (size_t)*ow * *oh * 3, need = (size_t)*ow * *oh * 4;
+    if (need == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", *ow, *oh);
+    const void* frame = d_bgr;
+    prof_reset(c);
+    std::vector<ProfRec> pre;
+    if (factor != 1.0f || d_scaled) {
+        void* dst = d_scaled;
+        if (!dst) {
+            RETIF(ensure(c, c->st_scaled, sbytes));
+            dst = c->st_scaled.p;
+        }
+        uint32_t a, b;
+        RETIF(infur_scale_dev(c, d_bgr, w, h, factor, mode, dst, sbytes, &a, &b));
+        frame = dst;
+        pre.swap(c->prof);  // forward() resets the records; keep the scale's
+    }
+    if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");  // app.rs:127-129: mask cleared
+    if (!d_rgba) return INFUR_E_INVALID_ARG;
+    if (cap < need) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", need, cap);
+    RETIF(forward(c, (const uint8_t*)frame, (int)*ow, (int)*oh));
+    c->prof.insert(c->prof.begin(), pre.begin(), pre.end());
+    {
+        const Tensor& t = c->out_low;  // only out[0] is decoded, app.rs:116
+        ProfScope ps(c, "out.resize+colorcode", "upsample_argmax_shade", 0, 4.0 * t.floats() + (double)need);
+        HIPCHK(c, launch_upsample_argmax_shade(t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)*oh, (int)*ow, c->stream));
+    }
+    return INFUR_OK;
+}
+
+int32_t infur_frame_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
+                            uint8_t* rgba, size_t cap, uint8_t* scaled, uint32_t* ow, uint32_t* oh) {
+    if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
+    int32_t rc = infur_scale_validate(factor);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    rc = infur_scale_out_dims(w, h, factor, ow, oh);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    if (!bgr) return INFUR_E_INVALID_ARG;
+    const size_t in_bytes = (size_t)w * h * 3, sbytes = (size_t)*ow * *oh * 3, need = (size_t)*ow * *oh * 4;
+    if (rgba && cap < need) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", need, cap);
+    RETIF(ensure(c, c->st_in, in_bytes ? in_bytes : 1));
+    RETIF(ensure(c, c->st_rgba, need ? need : 1));
+    RETIF(ensure(c, c->st_scaled, sbytes ? sbytes : 1));
+    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = infur_frame_advance_dev(c, c->st_in.p, w, h, factor, mode, c->st_rgba.p, c->st_rgba.bytes,
+                                 (scaled || factor != 1.0f) ? c->st_scaled.p : nullptr, ow, oh);
+    if (rc != INFUR_OK && rc != INFUR_E_MODEL_NOT_LOADED) return rc;
+    if (scaled) HIPCHK(c, hipMemcpyAsync(scaled, c->st_scaled.p, sbytes, hipMemcpyDeviceToHost, c->stream));
+    if (rc == INFUR_OK && rgba) HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return rc;
+}
+
+// ---- profiling ----
+int32_t infur_profile_count(infur_ctx* c, uint32_t* n) {
+    if (!c || !n) return INFUR_E_INVALID_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n = (uint32_t)c->prof.size();
+    return INFUR_OK;
+}
+
+int32_t infur_profile_get(infur_ctx* c, uint32_t i, infur_kernel_record* rec) {
+    if (!c || !rec || i >= c->prof.size()) return INFUR_E_INVALID_ARG;
+    const ProfRec& r = c->prof[i];
+    memset(rec, 0, sizeof *rec);
+    snprintf(rec->name, sizeof rec->name, "%s", r.name.c_str());
+    snprintf(rec->kernel, sizeof rec->kernel, "%s", r.kernel);
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+    rec->ms = ms;
+    rec->flops = r.flops;
+    rec->bytes = r.bytes;
+    return INFUR_OK;
+}
+
+// ---- device memory helpers ----
+int32_t infur_dev_alloc(infur_ctx* c, size_t bytes, void** d) {
+    if (!c || !d) return INFUR_E_INVALID_ARG;
+    HIPCHK(c, hipMalloc(d, bytes ? bytes : 1));
+    return INFUR_OK;
+}
+int32_t infur_dev_free(infur_ctx* c, void* d) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d));
+    return INFUR_OK;
+}
+int32_t infur_memcpy_h2d(infur_ctx* c, void* d, const void* s, size_t n) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+int32_t infur_memcpy_d2h(infur_ctx* c, void* d, const void* s, size_t n) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// prepost.hip -- the HBM-bound, bit-exact stages either side of the conv stack.
+// Compiled with -ffp-contract=off: every f32 expression here must round exactly like the
+// CPU oracle's (oracle/infur_oracle.c), which in turn follows the reference's scalar Rust.
+//
+//   scale_bgr            Scale::advance resize           infur/src/processing.rs:246-278
+//   pack_normalize       ImageSession::forward pre-proc  infur/src/predict_onnx.rs:103-137
+//   upsample_planar      the model's final Resize(linear) node (inside session.run, :138)
+//   colorcode_planar     ColorCode::advance              infur/src/decode_predict.rs:53-79
+//   upsample_argmax_shade  fusion of the last two: reads the 2.7 MB output-stride-8 logits
+//                        instead of writing + re-reading 174 MB of full-resolution logits.
+#include "kernels.h"
+
+namespace infur {
+
+// ---------------------------------------------------------------------------------------
+// Scale.  One thread per output pixel (3 bytes).  Source index rules are the oracle's:
+//   nearest : src = trunc(0.5*s + s*dst) in f64, s = src_len/dst_len, clamp to src_len-1
+//   bilinear: p = (dst+0.5)*s - 0.5 in f32 clamped to [0,src_len-1]; lerp x then y; round half up
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    scale_nearest_kernel(const uint8_t* __restrict__ in, int W, int H, uint8_t* __restrict__ out,
+                         int OW, int OH) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= OW || y >= OH) return;
+    const double sx = (double)W / (double)OW, sy = (double)H / (double)OH;
+    const double px = sx * 0.5 + sx * (double)x;
+    const double py = sy * 0.5 + sy * (double)y;
+    unsigned ix = (unsigned)px, iy = (unsigned)py;
+    if (ix > (unsigned)W - 1) ix = W - 1;
+    if (iy > (unsigned)H - 1) iy = H - 1;
+    const uint8_t* s = in + ((size_t)iy * W + ix) * 3;
+    uint8_t* d = out + ((size_t)y * OW + x) * 3;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+}
+
+__device__ __forceinline__ void bilinear_coord(int i, int src, int dst, int& a, int& b, float& f) {
+    const float scale = (float)src / (float)dst;
+    float p = ((float)i + 0.5f) * scale - 0.5f;
+    if (p < 0.0f) p = 0.0f;
+    const float lim = (float)(src - 1);
+    if (p > lim) p = lim;
+    a = (int)p;
+    b = a + 1 < src ? a + 1 : src - 1;
+    f = p - (float)a;
+}
+
+__global__ void __launch_bounds__(256)
+    scale_bilinear_kernel(const uint8_t* __restrict__ in, int W, int H, uint8_t* __restrict__ out,
+                          int OW, int OH) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= OW || y >= OH) return;
+    int x0, x1, y0, y1;
+    float fx, fy;
+    bilinear_coord(x, W, OW, x0, x1, fx);
+    bilinear_coord(y, H, OH, y0, y1, fy);
+    const uint8_t* r0 = in + (size_t)y0 * W * 3;
+    const uint8_t* r1 = in + (size_t)y1 * W * 3;
+    uint8_t* d = out + ((size_t)y * OW + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float p00 = r0[3 * x0 + c], p01 = r0[3 * x1 + c];
+        const float p10 = r1[3 * x0 + c], p11 = r1[3 * x1 + c];
+        const float top = p00 + (p01 - p00) * fx;
+        const float bot = p10 + (p11 - p10) * fx;
+        const float v = top + (bot - top) * fy;
+        float r = floorf(v + 0.5f);
+        r = fminf(fmaxf(r, 0.0f), 255.0f);
+        d[c] = (uint8_t)r;
+    }
+}
+
+hipError_t launch_scale_bgr(const uint8_t* in, int W, int H, uint8_t* out, int OW, int OH,
+                            int mode, hipStream_t s) {
+    dim3 grid((OW + 63) / 64, (OH + 3) / 4);
+    if (mode == 0)
+        hipLaunchKernelGGL(scale_nearest_kernel, grid, dim3(256), 0, s, in, W, H, out, OW, OH);
+    else
+        hipLaunchKernelGGL(scale_bilinear_kernel, grid, dim3(256), 0, s, in, W, H, out, OW, OH);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// pack_normalize: BGR u8 HWC -> RGB f32 CHW through the 3x256 LUT.  One thread = 4 pixels
+// (12 input bytes as three aligned dwords, three float4 plane stores).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    pack_normalize_kernel(const uint8_t* __restrict__ bgr, size_t npix, const float* __restrict__ lut,
+                          float* __restrict__ chw) {
+    __shared__ float slut[768];
+    for (int i = threadIdx.x; i < 768; i += 256) slut[i] = lut[i];
+    __syncthreads();
+    const size_t nquad = npix >> 2;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(bgr) | reinterpret_cast<uintptr_t>(chw)) & 15) == 0 &&
+                         (npix & 3) == 0;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nquad + (aligned ? 0 : 1);
+         q += (size_t)gridDim.x * 256) {
+        if (aligned) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(bgr + q * 12);
+            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+            // bytes: b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+            float4 R, G, B;
+            B.x = slut[512 + (w0 & 255)];
+            G.x = slut[256 + ((w0 >> 8) & 255)];
+            R.x = slut[(w0 >> 16) & 255];
+            B.y = slut[512 + (w0 >> 24)];
+            G.y = slut[256 + (w1 & 255)];
+            R.y = slut[(w1 >> 8) & 255];
+            B.z = slut[512 + ((w1 >> 16) & 255)];
+            G.z = slut[256 + (w1 >> 24)];
+            R.z = slut[w2 & 255];
+            B.w = slut[512 + ((w2 >> 8) & 255)];
+            G.w = slut[256 + ((w2 >> 16) & 255)];
+            R.w = slut[w2 >> 24];
+            *reinterpret_cast<float4*>(chw + q * 4) = R;
+            *reinterpret_cast<float4*>(chw + npix + q * 4) = G;
+            *reinterpret_cast<float4*>(chw + 2 * npix + q * 4) = B;
+        } else {
+            // ragged / unaligned sizes: same values, scalar accesses
+            const size_t lo = q * 4, hi = lo + 4 < npix ? lo + 4 : npix;
+            for (size_t i = lo; i < hi; i++) {
+                chw[i] = slut[bgr[3 * i + 2]];
+                chw[npix + i] = slut[256 + bgr[3 * i + 1]];
+                chw[2 * npix + i] = slut[512 + bgr[3 * i + 0]];
+            }
+        }
+    }
+}
+
+hipError_t launch_pack_normalize(const uint8_t* bgr, int W, int H, const float* lut, float* chw,
+                                 hipStream_t s) {
+    const size_t npix = (size_t)W * H;
+    size_t blocks = (npix / 4 + 256) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, bgr, npix, lut, chw);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// low-res NHWC -> planar (tiny: 21 x 135 x 240 floats)
+// ---------------------------------------------------------------------------------------
+__global__ void nhwc_to_planar_kernel(const float* __restrict__ in, int HW, int C, float* __restrict__ out) {
+    const size_t total = (size_t)HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i / HW);
+        const size_t p = i - (size_t)c * HW;
+        out[i] = in[p * C + c];
+    }
+}
+
+hipError_t launch_nhwc_to_planar(const float* in, int H, int W, int C, float* out, hipStream_t s) {
+    const size_t total = (size_t)H * W * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(nhwc_to_planar_kernel, dim3(blocks), dim3(256), 0, s, in, H * W, C, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Bilinear up-sample.  Coordinates follow the oracle's upsample_table():
+//   scale = out_len/in_len; src = out_len > 1 ? (dst+0.5)/scale - 0.5 : 0; clamp [0,in_len-1]
+//   i1 = trunc(src), i2 = min(i1+1, in_len-1); d1 = |src-i1|, d2 = |src-i2| (0.5/0.5 if i1==i2)
+//   v = dx2*dy2*X11 + dx1*dy2*X21 + dx2*dy1*X12 + dx1*dy1*X22  (left to right, no FMA)
+// HIP's f32 division is correctly rounded by default (no -ffast-math here), so the
+// coordinates match the host's bit for bit.
+// ---------------------------------------------------------------------------------------
+struct Lerp {
+    int i1, i2;
+    float d1, d2;
+};
+
+__device__ __forceinline__ Lerp lerp_coord(int i, int in_len, int out_len) {
+    const float scale = (float)out_len / (float)in_len;
+    float src = out_len > 1 ? ((float)i + 0.5f) / scale - 0.5f : 0.0f;
+    if (src < 0.0f) src = 0.0f;
+    const float lim = (float)(in_len - 1);
+    if (src > lim) src = lim;
+    Lerp t;
+    t.i1 = (int)src;
+    if (t.i1 > in_len - 1) t.i1 = in_len - 1;
+    t.i2 = t.i1 + 1 < in_len ? t.i1 + 1 : in_len - 1;
+    if (t.i1 == t.i2) {
+        t.d1 = 0.5f;
+        t.d2 = 0.5f;
+    } else {
+        t.d1 = fabsf(src - (float)t.i1);
+        t.d2 = fabsf(src - (float)t.i2);
+    }
+    return t;
+}
+
+__device__ __forceinline__ float bilerp(float X11, float X21, float X12, float X22, float dx1,
+                                        float dx2, float dy1, float dy2) {
+    float v = dx2 * dy2 * X11;
+    v = v + dx1 * dy2 * X21;
+    v = v + dx2 * dy1 * X12;
+    v = v + dx1 * dy1 * X22;
+    return v;
+}
+
+// one thread per output pixel, loops over classes; writes planar [K][OH][OW]
+__global__ void __launch_bounds__(256)
+    upsample_planar_kernel(const float* __restrict__ low, int LH, int LW, int K, float* __restrict__ out,
+                           int OH, int OW) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= OW || y >= OH) return;
+    const Lerp tx = lerp_coord(x, LW, OW), ty = lerp_coord(y, LH, OH);
+    const float* p11 = low + ((size_t)ty.i1 * LW + tx.i1) * K;
+    const float* p21 = low + ((size_t)ty.i1 * LW + tx.i2) * K;
+    const float* p12 = low + ((size_t)ty.i2 * LW + tx.i1) * K;
+    const float* p22 = low + ((size_t)ty.i2 * LW + tx.i2) * K;
+    const size_t plane = (size_t)OH * OW;
+    float* o = out + (size_t)y * OW + x;
+    for (int k = 0; k < K; k++)
+        o[k * plane] = bilerp(p11[k], p21[k], p12[k], p22[k], tx.d1, tx.d2, ty.d1, ty.d2);
+}
+
+hipError_t launch_upsample_planar(const float* low, int LH, int LW, int K, float* out, int OH,
+                                  int OW, hipStream_t s) {
+    dim3 grid((OW + 63) / 64, (OH + 3) / 4);
+    hipLaunchKernelGGL(upsample_planar_kernel, grid, dim3(256), 0, s, low, LH, LW, K, out, OH, OW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// ColorCode.  decode_predict.rs:67-78: k_max = 0, c_max = 0.0, strict '>' in class order;
+// alpha = (c_max * 255.0) as u8 (saturating, truncating); colour = LUT[k_max % 20][alpha]
+// where the LUT holds epaint's premultiplied bytes (built on the host, infur_capi.cpp).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t shade(int k_max, float c_max, const uint32_t* __restrict__ lut) {
+    const float a = c_max * 255.0f;            // c_max >= 0 and never NaN by construction
+    const int ai = a >= 255.0f ? 255 : (int)a;  // Rust `as u8`: saturate, truncate
+    return lut[(k_max % 20) * 256 + ai];
+}
+
+__global__ void __launch_bounds__(256)
+    colorcode_planar_kernel(const float* __restrict__ khw, int K, size_t HW, const uint32_t* __restrict__ lut,
+                            uint32_t* __restrict__ rgba) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
+        int k_max = 0;
+        float c_max = 0.0f;
+        for (int k = 0; k < K; k++) {
+            const float c = khw[(size_t)k * HW + p];
+            if (c > c_max) {
+                k_max = k;
+                c_max = c;
+            }
+        }
+        rgba[p] = shade(k_max, c_max, lut);
+    }
+}
+
+hipError_t launch_colorcode_planar(const float* khw, int K, int H, int W, const uint32_t* lut,
+                                   uint32_t* rgba, hipStream_t s) {
+    const size_t HW = (size_t)H * W;
+    size_t blocks = (HW + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(colorcode_planar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, khw, K, HW, lut, rgba);
+    return hipGetLastError();
+}
+
+// fused up-sample + argmax + shade: same expression tree as upsample_planar -> colorcode
+__global__ void __launch_bounds__(256)
+    upsample_argmax_shade_kernel(const float* __restrict__ low, int LH, int LW, int K,
+                                 const uint32_t* __restrict__ lut, uint32_t* __restrict__ rgba, int OH, int OW) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= OW || y >= OH) return;
+    const Lerp tx = lerp_coord(x, LW, OW), ty = lerp_coord(y, LH, OH);
+    const float* p11 = low + ((size_t)ty.i1 * LW + tx.i1) * K;
+    const float* p21 = low + ((size_t)ty.i1 * LW + tx.i2) * K;
+    const float* p12 = low + ((size_t)ty.i2 * LW + tx.i1) * K;
+    const float* p22 = low + ((size_t)ty.i2 * LW + tx.i2) * K;
+    int k_max = 0;
+    float c_max = 0.0f;
+    for (int k = 0; k < K; k++) {
+        const float c = bilerp(p11[k], p21[k], p12[k], p22[k], tx.d1, tx.d2, ty.d1, ty.d2);
+        if (c > c_max) {
+            k_max = k;
+            c_max = c;
+        }
+    }
+    rgba[(size_t)y * OW + x] = shade(k_max, c_max, lut);
+}
+
+hipError_t launch_upsample_argmax_shade(const float* low, int LH, int LW, int K, const uint32_t* lut,
+                                        uint32_t* rgba, int OH, int OW, hipStream_t s) {
+    dim3 grid((OW + 63) / 64, (OH + 3) / 4);
+    hipLaunchKernelGGL(upsample_argmax_shade_kernel, grid, dim3(256), 0, s, low, LH, LW, K, lut, rgba, OH, OW);
+    return hipGetLastError();
+}
+
+}  // namespace infur

@@ -1,0 +1,177 @@
+// stem_pool.hip -- the network's first two nodes, fed straight from the packed BGR frame.
+//
+//  * stem_conv7x7: fuses the reference's pre-processing (infur/src/predict_onnx.rs:103-137:
+//    BGR->RGB flip, HWC->CHW, /255, mean/std) into the first convolution (7x7 stride 2 pad 3,
+//    3->64, + bias + ReLU).  The normalised value of a byte is looked up in a 3x256 table
+//    computed on the host with the reference's exact f32 operation order, so the f32 input
+//    tensor the reference materialises (24.9 MB at 1080p) never exists here.
+//  * maxpool3x3s2: MaxPool 3x3 stride 2 pad 1 on NHWC f32.
+//  * weight repacks (one-off at model load).
+#include "kernels.h"
+
+namespace infur {
+
+// ---------------------------------------------------------------------------------------
+// stem: one thread = one output pixel x 64 output channels (64 f32 accumulators);
+// weights are wave-uniform -> scalar loads; the normalised input patch lives in LDS.
+// workgroup = 8 rows x 32 cols of output pixels.
+// ---------------------------------------------------------------------------------------
+constexpr int ST_TH = 8, ST_TW = 32;
+constexpr int ST_PH = 2 * ST_TH + 5;  // 21 input rows
+constexpr int ST_PW = 2 * ST_TW + 5;  // 69 input cols
+
+__global__ void __launch_bounds__(256)
+    stem_conv7x7_kernel(const uint8_t* __restrict__ bgr, int H, int W,
+                        const float* __restrict__ wt,    // [7][7][3][64]
+                        const float* __restrict__ bias,  // [64]
+                        const float* __restrict__ lut,   // [3][256] RGB order
+                        float* __restrict__ out, int OH, int OW) {
+    __shared__ float patch[ST_PH * ST_PW * 3];
+    const int tid = threadIdx.x;
+    const int oy0 = blockIdx.y * ST_TH, ox0 = blockIdx.x * ST_TW;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+
+    for (int i = tid; i < ST_PH * ST_PW; i += 256) {
+        const int r = i / ST_PW, q = i - r * ST_PW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;  // zero padding of the NORMALISED tensor
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const uint8_t* p = bgr + ((size_t)iy * W + ix) * 3;
+            v0 = lut[0 * 256 + p[2]];  // R
+            v1 = lut[1 * 256 + p[1]];  // G
+            v2 = lut[2 * 256 + p[0]];  // B
+        }
+        patch[i * 3 + 0] = v0;
+        patch[i * 3 + 1] = v1;
+        patch[i * 3 + 2] = v2;
+    }
+    __syncthreads();
+
+    const int py = tid >> 5, px = tid & 31;
+    float acc[64];
+#pragma unroll
+    for (int c = 0; c < 64; c++) acc[c] = 0.f;
+
+    const float* pbase = patch + ((2 * py) * ST_PW + 2 * px) * 3;
+    for (int ky = 0; ky < 7; ky++) {
+        const float* prow = pbase + ky * ST_PW * 3;
+        const float* wrow = wt + ky * 21 * 64;
+#pragma unroll 3
+        for (int j = 0; j < 21; j++) {  // (kx, c) flattened: contiguous in the patch row
+            const float v = prow[j];
+            const float* w = wrow + j * 64;
+#pragma unroll
+            for (int c = 0; c < 64; c++) acc[c] = fmaf(v, w[c], acc[c]);
+        }
+    }
+
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy < OH && ox < OW) {
+        float4* o = reinterpret_cast<float4*>(out + ((size_t)oy * OW + ox) * 64);
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            float4 v;
+            v.x = fmaxf(acc[4 * c + 0] + bias[4 * c + 0], 0.f);
+            v.y = fmaxf(acc[4 * c + 1] + bias[4 * c + 1], 0.f);
+            v.z = fmaxf(acc[4 * c + 2] + bias[4 * c + 2], 0.f);
+            v.w = fmaxf(acc[4 * c + 3] + bias[4 * c + 3], 0.f);
+            o[c] = v;
+        }
+    }
+}
+
+hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt,
+                               const float* bias, const float* lut, float* out, int OH, int OW,
+                               hipStream_t s) {
+    dim3 grid((OW + ST_TW - 1) / ST_TW, (OH + ST_TH - 1) / ST_TH);
+    hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, out,
+                       OH, OW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// maxpool 3x3 / 2, pad 1, NHWC: one thread = one output pixel x 4 channels
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out,
+                        int OH, int OW) {
+    const int c4n = C >> 2;
+    const size_t total = (size_t)OH * OW * c4n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        const size_t p = i / c4n;
+        const int ox = (int)(p % OW), oy = (int)(p / OW);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const int iy = 2 * oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const int ix = 2 * ox - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)iy * W + ix) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + p * C + c4 * 4) = m;
+    }
+}
+
+hipError_t launch_maxpool3x3s2(const float* in, int H, int W, int C, float* out, int OH, int OW,
+                               hipStream_t s) {
+    const size_t total = (size_t)OH * OW * (C / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, s, in, H, W, C, out, OH, OW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// weight repacks
+// ---------------------------------------------------------------------------------------
+__global__ void repack_oihw_to_ohwi_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                           int O, int I, int KH, int KW) {
+    const size_t total = (size_t)O * I * KH * KW;
+    for (size_t d = (size_t)blockIdx.x * 256 + threadIdx.x; d < total; d += (size_t)gridDim.x * 256) {
+        // d indexes dst [o][ky][kx][i]
+        const int i = (int)(d % I);
+        size_t r = d / I;
+        const int kx = (int)(r % KW);
+        r /= KW;
+        const int ky = (int)(r % KH);
+        const int o = (int)(r / KH);
+        dst[d] = src[(((size_t)o * I + i) * KH + ky) * KW + kx];
+    }
+}
+
+hipError_t launch_repack_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW,
+                                      hipStream_t s) {
+    const size_t total = (size_t)O * I * KH * KW;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(repack_oihw_to_ohwi_kernel, dim3(blocks), dim3(256), 0, s, src, dst, O, I, KH, KW);
+    return hipGetLastError();
+}
+
+__global__ void repack_stem_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+    // dst [ky][kx][c][o]  <-  src [o][c][ky][kx]   (O=64, C=3, 7x7)
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= 7 * 7 * 3 * 64) return;
+    const int o = d & 63;
+    int r = d >> 6;
+    const int c = r % 3;
+    r /= 3;
+    const int kx = r % 7, ky = r / 7;
+    dst[d] = src[((o * 3 + c) * 7 + ky) * 7 + kx];
+}
+
+hipError_t launch_repack_stem(const float* src, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(repack_stem_kernel, dim3((7 * 7 * 3 * 64 + 255) / 256), dim3(256), 0, s, src, dst);
+    return hipGetLastError();
+}
+
+}  // namespace infur

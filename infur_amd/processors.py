@@ -1,0 +1,396 @@
+"""Host-side mirror of the reference's ``Processor`` plugin surface over the C ABI.
+
+The reference defines one trait, ``Processor`` (infur/src/processing.rs:23-60), and the
+per-frame path instantiates it three times: ``Scale`` (processing.rs:179-282),
+``Model<f32>`` (infur/src/predict_onnx.rs:146-345) and ``ColorCode``
+(infur/src/decode_predict.rs:38-84), wired together by ``ProcessingApp::advance``
+(infur/src/app.rs:107-153).  The classes below keep the same names, commands, argument
+meaning and error behaviour; the arithmetic happens in ``libinfur_hip.so`` (hand-written
+gfx950 kernels).  There is no CPU fallback.
+
+Rust ``&mut Output`` parameters become mutable holders: ``Slot`` for ``Option<T>``
+outputs, a plain ``list`` for ``Vec<ArrayD<f32>>``.  Typed ``Result`` errors become
+exceptions carrying the status code of include/infur_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Generic, List, Optional, TypeVar
+
+import numpy as np
+
+from . import _lib
+
+T = TypeVar("T")
+
+
+# --------------------------------------------------------------------------- #
+# errors (thiserror enums of the reference)
+# --------------------------------------------------------------------------- #
+class InfurError(Exception):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        self.detail = detail
+        super().__init__(detail or _lib.status_string(code))
+
+
+class ValidScaleError(InfurError):
+    """processing.rs:145-168 -- "Cannot scale by negative number"."""
+
+
+class ScaleProcError(InfurError):
+    """processing.rs:201-211 -- ZeroSizeIn / ZeroSizeOut."""
+
+    @property
+    def kind(self) -> str:
+        return {_lib.E_ZERO_SIZE_IN: "ZeroSizeIn", _lib.E_ZERO_SIZE_OUT: "ZeroSizeOut"}.get(self.code, "Other")
+
+
+class ModelCmdError(InfurError):
+    """predict_onnx.rs:41-48 -- the model could not be loaded."""
+
+
+class ModelProcError(InfurError):
+    """predict_onnx.rs:33-39 -- ShapeError / RuntimeError while processing."""
+
+
+class Slot(Generic[T]):
+    """A mutable ``Option<T>`` the callee may fill or reuse (Rust ``&mut Option<T>``)."""
+
+    def __init__(self, value: Optional[T] = None):
+        self.value = value
+
+    def is_some(self) -> bool:
+        return self.value is not None
+
+    def take(self) -> Optional[T]:
+        v, self.value = self.value, None
+        return v
+
+
+@dataclass
+class Frame:
+    """processing.rs:9-18: frame id + packed BGR image ([h, w, 3] u8, row-major, no padding)."""
+
+    id: int
+    img: np.ndarray
+
+    def __eq__(self, other):  # PartialEq compares ids only (processing.rs:14-18)
+        return isinstance(other, Frame) and self.id == other.id
+
+
+def bgr_image(w: int, h: int) -> np.ndarray:
+    """``BgrImage::new(w, h)``: zero-filled packed BGR."""
+    return np.zeros((h, w, 3), np.uint8)
+
+
+def _check_bgr(img: np.ndarray) -> np.ndarray:
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+        raise ModelProcError(_lib.E_SHAPE, f"expected packed BGR u8 [h,w,3], got {img.dtype} {img.shape}")
+    return np.ascontiguousarray(img)
+
+
+# --------------------------------------------------------------------------- #
+# context
+# --------------------------------------------------------------------------- #
+class Context:
+    """One GPU + one HIP stream + device arena (``infur_ctx``).  Not thread-safe."""
+
+    def __init__(self, device: int = 0, compute_aux: bool = True, profile: bool = False,
+                 keep_activations: bool = False, stream: Optional[int] = None):
+        L = self.L = _lib.load()
+        o = _lib.Options()
+        L.infur_options_default(C.byref(o))
+        o.device = device
+        o.compute_aux = 1 if compute_aux else 0
+        o.profile = 1 if profile else 0
+        o.keep_activations = 1 if keep_activations else 0
+        o.stream = stream
+        h = C.c_void_p(None)
+        rc = L.infur_ctx_create(C.byref(o), C.byref(h))
+        if rc != _lib.OK:
+            raise InfurError(rc, f"infur_ctx_create(device={device}) failed: {_lib.status_string(rc)} "
+                                 f"({L.infur_device_count()} HIP devices visible; there is no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def last_error(self) -> str:
+        return self.L.infur_last_error(self.h).decode()
+
+    def check(self, rc: int, exc=InfurError):
+        if rc != _lib.OK:
+            raise exc(rc, self.last_error() or _lib.status_string(rc))
+
+    def synchronize(self):
+        self.check(self.L.infur_ctx_synchronize(self.h))
+
+    @property
+    def stream(self) -> int:
+        return self.L.infur_ctx_stream(self.h) or 0
+
+    def profile(self) -> List[dict]:
+        """Kernel records of the last advance (needs ``profile=True``)."""
+        n = C.c_uint32(0)
+        self.check(self.L.infur_profile_count(self.h, C.byref(n)))
+        out = []
+        rec = _lib.KernelRecord()
+        for i in range(n.value):
+            self.check(self.L.infur_profile_get(self.h, i, C.byref(rec)))
+            out.append({"name": rec.name.decode(), "kernel": rec.kernel.decode(), "ms": rec.ms,
+                        "flops": rec.flops, "bytes": rec.bytes})
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.infur_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# --------------------------------------------------------------------------- #
+# the trait
+# --------------------------------------------------------------------------- #
+class Processor:
+    """processing.rs:23-60."""
+
+    def control(self, cmd):
+        raise NotImplementedError
+
+    def advance(self, inp, out):
+        raise NotImplementedError
+
+    def is_dirty(self) -> bool:
+        raise NotImplementedError
+
+
+class Scale(Processor):
+    """Scale frames by a constant factor (processing.rs:179-282).
+
+    Command = f32, Input = Output = Option<Frame>.  ``mode`` selects the resampler:
+    nearest is the reference's (processing.rs:189); bilinear is the north-star extension.
+    """
+
+    def __init__(self, ctx: Context, mode: int = _lib.SCALE_NEAREST):
+        self.ctx = ctx
+        self.mode = mode
+        self.factor = np.float32(1.0)  # Default, processing.rs:185-193
+        self.dirty = True
+
+    def control(self, cmd: float) -> "Scale":
+        factor = np.float32(cmd)
+        rc = self.ctx.L.infur_scale_validate(float(factor))
+        if rc != _lib.OK:
+            raise ValidScaleError(rc)  # state untouched, like `cmd.try_into()?` (processing.rs:221)
+        self.dirty = bool(factor != self.factor)  # processing.rs:222 (NaN != NaN -> dirty)
+        self.factor = factor
+        return self
+
+    def is_dirty(self) -> bool:
+        return self.dirty
+
+    def is_unit_scale(self) -> bool:
+        return bool(self.factor == np.float32(1.0))
+
+    def advance(self, inp: Optional[Frame], out: Slot) -> None:
+        self.dirty = False  # processing.rs:233
+        if inp is None:
+            return
+        if self.is_unit_scale():  # clone, processing.rs:238-242
+            out.value = Frame(inp.id, inp.img.copy())
+            return
+        img = _check_bgr(inp.img)
+        h, w = img.shape[:2]
+        L = self.ctx.L
+        ow, oh = C.c_uint32(0), C.c_uint32(0)
+        rc = L.infur_scale_out_dims(w, h, float(self.factor), C.byref(ow), C.byref(oh))
+        if rc != _lib.OK:
+            raise ScaleProcError(rc)
+        nw, nh = ow.value, oh.value
+        # get or create the output frame; re-allocate only on size change (processing.rs:260-268)
+        fr = out.value
+        if fr is None or fr.img.shape[0] != nh or fr.img.shape[1] != nw or not fr.img.flags["C_CONTIGUOUS"]:
+            fr = Frame(inp.id, bgr_image(nw, nh))
+            out.value = fr
+        fr.id = inp.id
+        rc = L.infur_scale(self.ctx.h, img.ctypes.data, w, h, float(self.factor), self.mode,
+                           fr.img.ctypes.data, fr.img.nbytes, C.byref(ow), C.byref(oh))
+        self.ctx.check(rc, ScaleProcError)
+
+
+@dataclass
+class ModelCmd:
+    """predict_onnx.rs:267-270: ``ModelCmd::Load(path)``; empty path unloads."""
+
+    path: str = ""
+    blob: Optional[bytes] = None  # extension: load an in-memory INFURW01 blob
+
+    @staticmethod
+    def Load(path: str) -> "ModelCmd":
+        return ModelCmd(path=path)
+
+    @staticmethod
+    def LoadBlob(blob: bytes) -> "ModelCmd":
+        return ModelCmd(blob=blob)
+
+
+@dataclass
+class ModelInfo:
+    """predict_onnx.rs:56-62."""
+
+    input_names: List[str]
+    input0_dtype: str
+    output_names: List[str]
+    num_classes: int = 0
+    depth: int = 0
+    weight_bytes: int = 0
+
+
+class Model(Processor):
+    """Segmentation model session (predict_onnx.rs:146-345).
+
+    Command = ModelCmd, Input = BgrImage, Output = Vec<ArrayD<f32>> (a ``list`` here).
+    """
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def control(self, cmd: ModelCmd) -> "Model":
+        L, h = self.ctx.L, self.ctx.h
+        if cmd.blob is not None:
+            rc = L.infur_model_load_blob(h, cmd.blob, len(cmd.blob))
+        else:
+            rc = L.infur_model_load(h, cmd.path.encode())  # "" unloads (predict_onnx.rs:310-312)
+        self.ctx.check(rc, ModelCmdError)
+        return self
+
+    def is_dirty(self) -> bool:
+        return False  # predict_onnx.rs:336-338
+
+    def get_info(self) -> Optional[ModelInfo]:
+        mi = _lib.ModelInfoC()
+        rc = self.ctx.L.infur_model_info_get(self.ctx.h, C.byref(mi))
+        if rc == _lib.E_MODEL_NOT_LOADED:
+            return None
+        self.ctx.check(rc)
+        outs = [bytes(mi.output_names[i]).split(b"\0", 1)[0].decode() for i in range(mi.n_outputs)]
+        return ModelInfo([mi.input_name.decode()], mi.input0_dtype.decode(), outs, mi.num_classes, mi.depth,
+                         mi.weight_bytes)
+
+    def advance(self, img: np.ndarray, out: list) -> None:
+        """Fills ``out`` with [out, aux], each [num_classes, h, w] f32; untouched when no model is loaded."""
+        info = self.get_info()
+        if info is None:
+            return  # Ok(()) with `out` untouched (predict_onnx.rs:318,333)
+        img = _check_bgr(img)
+        h, w = img.shape[:2]
+        k = info.num_classes
+        o = np.empty((k, h, w), np.float32)
+        a = np.empty((k, h, w), np.float32)
+        n = C.c_uint32(0)
+        rc = self.ctx.L.infur_model_advance(self.ctx.h, img.ctypes.data, w, h, o.ctypes.data, a.ctypes.data, C.byref(n))
+        self.ctx.check(rc, ModelProcError)
+        out.clear()  # predict_onnx.rs:326
+        out.extend([o, a])
+
+    def lowres(self):
+        """Output-stride-8 logits of the last advance: (out_low, aux_low) [K, lh, lw] f32."""
+        info = self.get_info()
+        L, h = self.ctx.L, self.ctx.h
+        lh, lw = C.c_uint32(0), C.c_uint32(0)
+        self.ctx.check(L.infur_model_read_lowres(h, None, None, C.byref(lh), C.byref(lw)))
+        o = np.empty((info.num_classes, lh.value, lw.value), np.float32)
+        a = np.empty_like(o)
+        self.ctx.check(L.infur_model_read_lowres(h, o.ctypes.data, a.ctypes.data, C.byref(lh), C.byref(lw)))
+        return o, a
+
+
+class ColorCode(Processor):
+    """Per-pixel argmax + confidence-shaded RGBA (decode_predict.rs:38-84).
+
+    Input = Array3<f32> [K, H, W]; Output = Option<ColorImage> (``Slot`` of [H, W, 4] u8,
+    premultiplied r,g,b,a -- the memory layout of epaint's ``Color32``).
+    """
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def control(self, cmd=None) -> "ColorCode":
+        return self
+
+    def is_dirty(self) -> bool:
+        return False
+
+    def advance(self, inp: np.ndarray, out: Slot) -> None:
+        if inp.ndim != 3:
+            raise InfurError(_lib.E_SHAPE, f"expected [K,H,W], got {inp.shape}")
+        khw = np.ascontiguousarray(inp, np.float32)
+        k, h, w = khw.shape
+        img = out.value
+        if img is None or img.shape[:2] != (h, w):  # re-create only on size change (decode_predict.rs:58-65)
+            img = np.zeros((h, w, 4), np.uint8)
+            img[..., 3] = 255  # Color32::BLACK
+            out.value = img
+        self.ctx.check(self.ctx.L.infur_colorcode(self.ctx.h, khw.ctypes.data, k, h, w, img.ctypes.data))
+
+
+def pack_normalize(ctx: Context, img: np.ndarray) -> np.ndarray:
+    """The pre-proc stage on its own (predict_onnx.rs:103-137): BGR u8 HWC -> RGB f32 CHW."""
+    img = _check_bgr(img)
+    h, w = img.shape[:2]
+    out = np.empty((3, h, w), np.float32)
+    ctx.check(ctx.L.infur_pack_normalize(ctx.h, img.ctypes.data, w, h, out.ctypes.data))
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# the fused per-frame path (what ProcessingApp::advance does per frame, app.rs:107-153)
+# --------------------------------------------------------------------------- #
+class FramePath:
+    """scale -> model -> decode(out[0]) in one call, nothing materialised at full resolution."""
+
+    def __init__(self, ctx: Context, scale_mode: int = _lib.SCALE_NEAREST):
+        self.ctx = ctx
+        self.scale_mode = scale_mode
+
+    def advance(self, img: np.ndarray, factor: float = 1.0, want_scaled: bool = False):
+        """-> (rgba [oh,ow,4] u8 or None when no model is loaded, scaled BGR or None)."""
+        img = _check_bgr(img)
+        h, w = img.shape[:2]
+        L = self.ctx.L
+        rc = L.infur_scale_validate(float(np.float32(factor)))
+        if rc:
+            raise ValidScaleError(rc)
+        ow, oh = C.c_uint32(0), C.c_uint32(0)
+        rc = L.infur_scale_out_dims(w, h, float(np.float32(factor)), C.byref(ow), C.byref(oh))
+        if rc:
+            raise ScaleProcError(rc)
+        rgba = np.empty((oh.value, ow.value, 4), np.uint8)
+        scaled = np.empty((oh.value, ow.value, 3), np.uint8) if want_scaled else None
+        rc = L.infur_frame_advance(self.ctx.h, img.ctypes.data, w, h, float(np.float32(factor)), self.scale_mode,
+                                   rgba.ctypes.data, rgba.nbytes, scaled.ctypes.data if want_scaled else None,
+                                   C.byref(ow), C.byref(oh))
+        if rc == _lib.E_MODEL_NOT_LOADED:
+            return None, scaled  # mask cleared (app.rs:127-129)
+        self.ctx.check(rc)
+        return rgba, scaled
+
+    def advance_dev(self, d_bgr: int, w: int, h: int, factor: float, d_rgba: int, rgba_capacity: int,
+                    d_scaled: int = 0):
+        """Device-resident form: pointers are raw device addresses; asynchronous on ctx.stream."""
+        ow, oh = C.c_uint32(0), C.c_uint32(0)
+        rc = self.ctx.L.infur_frame_advance_dev(self.ctx.h, d_bgr, w, h, float(np.float32(factor)), self.scale_mode,
+                                                d_rgba, rgba_capacity, d_scaled or None, C.byref(ow), C.byref(oh))
+        self.ctx.check(rc)
+        return ow.value, oh.value

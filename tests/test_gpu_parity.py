@@ -1,0 +1,389 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bit-exact for the byte/index stages (Scale, pre-proc, ColorCode, up-sample given the same
+low-res logits, fused vs unfused); the conv stack is checked against the oracle within the
+north-star tolerance of 1e-3 relative (f32), stated in REL_TOL below.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from infur_amd import _lib
+from infur_amd import weights as W
+from infur_amd.processors import (ColorCode, Context, Frame, FramePath, InfurError, Model, ModelCmd,
+                                  ModelCmdError, Scale, ScaleProcError, Slot, ValidScaleError,
+                                  bgr_image, pack_normalize)
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-3  # north_star: "logits within 1e-3 relative fp32"
+
+
+def rel_err(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# --------------------------------------------------------------------------- #
+# Scale (processing.rs:179-282)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("mode", [_lib.SCALE_NEAREST, _lib.SCALE_BILINEAR])
+@pytest.mark.parametrize("wh", [(64, 48), (97, 61), (640, 480), (1280, 720), (1, 1), (3, 2), (1921, 1079)])
+def test_scale_matches_oracle(ctx, oracle, mode, wh):
+    w, h = wh
+    fr = W.synth_frame(h, w, index=w)
+    for fac in (0.5, 0.37, 0.999, 1.7, 2.0, 0.1):
+        rc, ref = oracle.scale(fr, fac, mode)
+        s = Scale(ctx, mode).control(fac)
+        out = Slot()
+        if rc != 0:
+            with pytest.raises(ScaleProcError) as e:
+                s.advance(Frame(1, fr), out)
+            assert e.value.code == rc
+            continue
+        s.advance(Frame(7, fr), out)
+        assert out.value.id == 7 and out.value.img.shape == ref.shape
+        assert (out.value.img == ref).all(), (wh, fac, mode)
+
+
+def test_scale_golden(ctx, golden):
+    for tag in ("64x48", "97x61"):
+        fr = golden[f"bgr_{tag}"]
+        for mn, mode in (("nearest", 0), ("bilinear", 1)):
+            for fac in (0.5, 0.37, 1.7):
+                out = Slot()
+                Scale(ctx, mode).control(fac).advance(Frame(0, fr), out)
+                assert (out.value.img == golden[f"scale_{mn}_{fac}_{tag}"]).all()
+
+
+def test_scale_reference_behaviour(ctx, kats):
+    """processing.rs:289-303 and app.rs:187,199,216 through the HIP-backed Scale."""
+    s = Scale(ctx)
+    assert s.is_dirty()  # Default: dirty = true
+    s.control(0.99)
+    with pytest.raises(ScaleProcError) as e:
+        s.advance(Frame(0, bgr_image(0, 10)), Slot())
+    assert e.value.kind == "ZeroSizeIn"
+    s.control(0.00000001)
+    with pytest.raises(ScaleProcError) as e:
+        s.advance(Frame(0, bgr_image(10, 10)), Slot())
+    assert e.value.kind == "ZeroSizeOut"
+    for f in kats["valid_scale_rejects"]["factors"]:
+        with pytest.raises(ValidScaleError):
+            s.control(f)
+    assert s.factor == np.float32(0.00000001)  # failed control leaves state untouched
+    for d in kats["scale_dims"]:
+        out = Slot()
+        Scale(ctx).control(d["factor"]).advance(Frame(3, W.synth_frame(d["h"], d["w"])), out)
+        assert out.value.img.shape == (d["oh"], d["ow"], 3) and out.value.id == 3
+    # dirty flag transitions (processing.rs:222,233)
+    s = Scale(ctx).control(0.5)
+    assert s.is_dirty()
+    out = Slot()
+    s.advance(Frame(1, bgr_image(8, 8)), out)
+    assert not s.is_dirty()
+    s.control(0.5)
+    assert not s.is_dirty()
+    s.control(0.25)
+    assert s.is_dirty()
+    s.advance(None, out)  # None input: only clears dirty
+    assert not s.is_dirty() and out.value.img.shape == (4, 4, 3)
+    # unit scale clones; buffer reuse on same size
+    s = Scale(ctx)
+    img = W.synth_frame(9, 11)
+    out = Slot()
+    s.advance(Frame(5, img), out)
+    assert (out.value.img == img).all() and out.value.img is not img
+    s.control(0.5)
+    s.advance(Frame(6, img), out)
+    buf = out.value.img
+    s.advance(Frame(7, img), out)
+    assert out.value.img is buf and out.value.id == 7
+
+
+# --------------------------------------------------------------------------- #
+# pre-proc (predict_onnx.rs:103-137)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("wh", [(64, 48), (97, 61), (1, 1), (5, 3), (640, 480), (1920, 1080)])
+def test_pack_normalize_bit_exact(ctx, oracle, wh):
+    w, h = wh
+    fr = W.synth_frame(h, w, index=11)
+    got = pack_normalize(ctx, fr)
+    ref = oracle.pack_normalize(fr)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_pack_normalize_all_bytes(ctx, tables):
+    fr = np.zeros((16, 16, 3), np.uint8)
+    fr[..., 0] = np.arange(256).reshape(16, 16)            # B
+    fr[..., 1] = np.arange(256).reshape(16, 16)[::-1]      # G
+    fr[..., 2] = np.arange(256).reshape(16, 16).T          # R
+    got = pack_normalize(ctx, fr)
+    lut = tables["preproc_lut"]
+    assert (got[0] == lut[0][fr[..., 2]]).all() and (got[1] == lut[1][fr[..., 1]]).all() and (got[2] == lut[2][fr[..., 0]]).all()
+
+
+# --------------------------------------------------------------------------- #
+# ColorCode (decode_predict.rs:32-79)
+# --------------------------------------------------------------------------- #
+def test_colorcode_reference_kats(ctx, oracle, kats):
+    k = kats["decode_0to1"]
+    hm = np.linspace(0.0, 1.0, k["linspace"][2], dtype=np.float32).reshape(k["shape"])
+    out = Slot()
+    ColorCode(ctx).advance(hm, out)
+    img = out.value
+    assert img.shape == (k["height"], k["width"], 4)
+    conf = 0
+    for p in img.reshape(-1, 4):
+        assert (p == oracle.color_code(k["klass"], np.float32(p[3]) / np.float32(255.0))).all()
+        assert conf <= p[3]
+        conf = p[3]
+    assert conf == k["last_alpha"]
+    # color_2: a single pixel whose only positive class is 2 with confidence 0.5
+    one = np.zeros((3, 1, 1), np.float32)
+    one[2] = kats["color_2"]["alpha"]
+    out = Slot()
+    ColorCode(ctx).advance(one, out)
+    r, g, b, a = kats["color_2"]["unmultiplied_rgba"]
+    assert (out.value[0, 0] == oracle.from_rgba_unmultiplied(r, g, b, a)).all()
+
+
+def test_colorcode_edge_cases_and_random(ctx, oracle, golden):
+    out = Slot()
+    cc = ColorCode(ctx)
+    cc.advance(golden["cc_in"], out)
+    assert (out.value == golden["cc_rgba"]).all()
+    rng = np.random.default_rng(5)
+    for k, h, w in ((21, 33, 47), (1, 4, 4), (22, 24, 32), (40, 7, 9), (21, 270, 480)):
+        x = rng.normal(0.4, 0.5, size=(k, h, w)).astype(np.float32)
+        x[rng.random(x.shape) < 0.01] = np.nan
+        x[rng.random(x.shape) < 0.01] = np.inf
+        x[rng.random(x.shape) < 0.01] = -np.inf
+        cc.advance(x, out)
+        assert out.value.shape == (h, w, 4)
+        assert (out.value == oracle.colorcode(x)).all()
+    # empty image and reuse on same size
+    cc.advance(np.zeros((21, 0, 5), np.float32), out)
+    assert out.value.shape == (0, 5, 4)
+
+
+def test_color_lut_every_entry(ctx, tables):
+    """All 20 x 256 (class, alpha) pairs through the kernel == the oracle's epaint table."""
+    lut = tables["color_lut"]
+    x = np.zeros((20, 20, 256), np.float32)
+    for k in range(20):
+        # pixel (k, a): class k has confidence with (c*255) as u8 == a
+        x[k, k, :] = (np.arange(256, dtype=np.float32) + np.float32(0.5)) / np.float32(255.0)
+    x[:, :, 0] = 0.0
+    out = Slot()
+    ColorCode(ctx).advance(x, out)
+    got = out.value
+    exp_a = np.minimum((x.max(0) * np.float32(255.0)).astype(np.int64), 255)
+    for k in range(20):
+        assert (got[k] == lut[k, exp_a[k]]).all(), k
+
+
+# --------------------------------------------------------------------------- #
+# Model (predict_onnx.rs:283-345) -- conv stack within tolerance of the oracle
+# --------------------------------------------------------------------------- #
+def test_model_info_and_load_errors(ctx, model, blob50):
+    info = model.get_info()
+    assert info.input_names == ["input"] and info.output_names == ["out", "aux"] and info.input0_dtype == "Float"
+    assert info.num_classes == 21 and info.depth == 50
+    c2 = Context(device=0)
+    m = Model(c2)
+    assert m.get_info() is None
+    out = ["sentinel"]
+    m.advance(bgr_image(32, 24), out)  # no model: Ok(()) and `out` untouched (predict_onnx.rs:318,333)
+    assert out == ["sentinel"]
+    with pytest.raises(ModelCmdError) as e:
+        m.control(ModelCmd.LoadBlob(b"NOTABLOB" + bytes(100)))
+    assert e.value.code == _lib.E_MODEL_FORMAT
+    with pytest.raises(ModelCmdError):
+        m.control(ModelCmd.LoadBlob(blob50[:1000]))  # truncated
+    bad = bytearray(blob50[: 32 + 57 * 80 + 64])
+    with pytest.raises(ModelCmdError):
+        m.control(ModelCmd.LoadBlob(bytes(bad)))  # table ok, data out of range
+    with pytest.raises(ModelCmdError) as e:
+        m.control(ModelCmd.Load("/nonexistent/model.bin"))
+    assert e.value.code == _lib.E_IO
+    assert m.get_info() is None
+    m.control(ModelCmd.LoadBlob(blob50))
+    assert m.get_info() is not None
+    m.control(ModelCmd.Load(""))  # empty path unloads (predict_onnx.rs:310-312)
+    assert m.get_info() is None
+    rgba, scaled = FramePath(c2).advance(W.synth_frame(24, 32), 0.5, want_scaled=True)
+    assert rgba is None and scaled.shape == (12, 16, 3)  # mask cleared, frame still scaled (app.rs:127-129)
+    c2.close()
+
+
+def test_model_load_from_file(ctx, blob50, tmp_path, oracle_model):
+    p = tmp_path / "fcn.infurw"
+    p.write_bytes(blob50)
+    c2 = Context(device=0)
+    m = Model(c2).control(ModelCmd.Load(str(p)))
+    fr = W.synth_frame(48, 64)
+    out = []
+    m.advance(fr, out)
+    lo, _ = m.lowres()
+    ref = oracle_model.model_forward(oracle_model.pack_normalize(fr), full=False)
+    assert rel_err(lo, ref["out_low"]) < REL_TOL
+    c2.close()
+
+
+@pytest.mark.parametrize("tag", ["64x48", "97x61"])
+def test_model_against_golden(ctx, model, golden, oracle, tag):
+    fr = golden[f"bgr_{tag}"]
+    out = []
+    model.advance(fr, out)
+    assert len(out) == 2
+    lo, la = model.lowres()
+    assert rel_err(lo, golden[f"out_low_{tag}"]) < REL_TOL
+    assert rel_err(la, golden[f"aux_low_{tag}"]) < REL_TOL
+    assert rel_err(out[0], golden[f"out_{tag}"]) < REL_TOL
+    assert rel_err(out[1], golden[f"aux_{tag}"]) < REL_TOL
+    # the up-sample kernel itself is bit-exact given the same low-res logits
+    h, w = fr.shape[:2]
+    assert (out[0].view(np.uint32) == oracle.upsample_bilinear(lo, h, w).view(np.uint32)).all()
+    assert (out[1].view(np.uint32) == oracle.upsample_bilinear(la, h, w).view(np.uint32)).all()
+
+
+def test_model_per_layer_against_torch_oracle(blob50):
+    """Every conv output (keep_activations) against the torch-CPU restatement."""
+    from oracle.infur_oracle import COracle, TorchModel
+
+    co = COracle()
+    tm = TorchModel(blob50)
+    c2 = Context(device=0, keep_activations=True)
+    m = Model(c2).control(ModelCmd.LoadBlob(blob50))
+    fr = W.synth_frame(72, 104, index=2)
+    out = []
+    m.advance(fr, out)
+    taps = {}
+    tm.forward_lowres(co.pack_normalize(fr), taps=taps)
+    worst = 0.0
+    for i, spec in enumerate(W.graph(50)):
+        ref = taps[spec.name].numpy()
+        buf = np.empty(ref.shape, np.float32)
+        c, h, w = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        c2.check(c2.L.infur_debug_read_activation(c2.h, i, buf.ctypes.data, buf.size, C.byref(c), C.byref(h), C.byref(w)))
+        assert (c.value, h.value, w.value) == ref.shape, spec.name
+        e = rel_err(buf, ref)
+        worst = max(worst, e)
+        assert e < REL_TOL, (spec.name, e)
+    print("worst per-layer rel err", worst)
+    c2.close()
+
+
+def test_infer_seg_model_shape(ctx, model, kats):
+    """predict_onnx.rs:371-381: black 320x240 frame -> 2 tensors of shape [21,240,320]."""
+    k = kats["infer_seg_model"]
+    out = []
+    model.advance(bgr_image(k["w"], k["h"]), out)
+    assert len(out) == k["n_outputs"]
+    assert list(out[0].shape) == k["shape"] and list(out[1].shape) == k["shape"]
+    assert np.isfinite(out[0]).all() and np.isfinite(out[1]).all()
+
+
+# --------------------------------------------------------------------------- #
+# fused frame path (app.rs:107-153)
+# --------------------------------------------------------------------------- #
+def argmax_report(oracle, got_rgba, ref_logits, tol_logits):
+    """Mismatching pixels are acceptable only where the oracle's top-2 gap is inside the logit tolerance."""
+    ref_rgba = oracle.colorcode(ref_logits)
+    bad = (got_rgba != ref_rgba).any(-1)
+    if not bad.any():
+        return 0, 0.0
+    srt = np.sort(np.maximum(ref_logits, 0.0), axis=0)
+    gap = srt[-1] - srt[-2]
+    # alpha may also differ by one step where c_max*255 sits on an integer boundary
+    kl, al = oracle.argmax(ref_logits)
+    frac = ref_logits.max(0) * 255.0
+    near_alpha = np.abs(frac - np.round(frac)) < tol_logits * 255.0
+    unexplained = bad & ~((gap < tol_logits) | near_alpha)
+    return int(bad.sum()), float(unexplained.mean())
+
+
+@pytest.mark.parametrize("tag", ["64x48", "97x61"])
+def test_frame_advance_small(ctx, model, golden, oracle, tag):
+    fr = golden[f"bgr_{tag}"]
+    fp = FramePath(ctx)
+    rgba, _ = fp.advance(fr, 1.0)
+    lo, _ = model.lowres()
+    h, w = fr.shape[:2]
+    # fused kernel == oracle up-sample + ColorCode on the same low-res logits, bit for bit
+    assert (rgba == oracle.colorcode(oracle.upsample_bilinear(lo, h, w))).all()
+    # against the whole-path oracle: class map identical except at near-ties
+    nbad, unexplained = argmax_report(oracle, rgba, golden[f"out_{tag}"], REL_TOL * np.abs(golden[f"out_{tag}"]).max())
+    assert unexplained == 0.0, (nbad, unexplained)
+    assert nbad <= 0.01 * h * w
+
+
+def test_frame_advance_scaled_equals_unfused(ctx, model, oracle):
+    """scale -> model -> decode fused == Scale, Model, ColorCode processors chained (app.rs:107-123)."""
+    fr = W.synth_frame(180, 320, index=4)
+    for mode in (0, 1):
+        rgba, scaled = FramePath(ctx, mode).advance(fr, 0.5, want_scaled=True)
+        s_out = Slot()
+        Scale(ctx, mode).control(0.5).advance(Frame(0, fr), s_out)
+        assert (scaled == s_out.value.img).all()
+        m_out = []
+        model.advance(s_out.value.img, m_out)
+        c_out = Slot()
+        ColorCode(ctx).advance(m_out[0], c_out)
+        assert (rgba == c_out.value).all()
+
+
+@pytest.mark.parametrize("wh", [(1920, 1080), (960, 540)])
+def test_full_size_properties(ctx, model, oracle, blob50, wh):
+    """BASELINE configs C2/C3 at full size: determinism, fused == unfused, logits vs torch-CPU oracle."""
+    from oracle.infur_oracle import TorchModel
+
+    w, h = wh
+    fr = W.synth_frame(h, w, index=1)
+    fp = FramePath(ctx)
+    rgba1, _ = fp.advance(fr, 1.0)
+    rgba2, _ = fp.advance(fr, 1.0)
+    assert (rgba1 == rgba2).all()  # deterministic
+    lo, la = model.lowres()
+    assert (rgba1 == oracle.colorcode(oracle.upsample_bilinear(lo, h, w))).all()
+    tl, ta = TorchModel(blob50).forward_lowres(oracle.pack_normalize(fr))
+    e_out, e_aux = rel_err(lo, tl.numpy()), rel_err(la, ta.numpy())
+    print(f"{w}x{h}: low-res logits rel err out={e_out:.2e} aux={e_aux:.2e}")
+    assert e_out < REL_TOL and e_aux < REL_TOL
+    ref_full = oracle.upsample_bilinear(tl.numpy(), h, w)
+    nbad, unexplained = argmax_report(oracle, rgba1, ref_full, REL_TOL * np.abs(ref_full).max())
+    print(f"{w}x{h}: {nbad} of {h*w} mask pixels differ from the CPU path; unexplained fraction {unexplained}")
+    assert unexplained == 0.0 and nbad <= 0.005 * h * w
+    assert (rgba1[..., 3] > 0).any()
+
+
+def test_profile_records(blob50):
+    c2 = Context(device=0, profile=True)
+    Model(c2).control(ModelCmd.LoadBlob(blob50))
+    rgba, _ = FramePath(c2).advance(W.synth_frame(96, 128), 1.0)
+    recs = c2.profile()
+    names = [r["name"] for r in recs]
+    assert names[0] == "backbone.conv1" and names[-1] == "out.resize+colorcode" and len(recs) == 57 + 2
+    flops = sum(r["flops"] for r in recs)
+    assert abs(flops - W.conv_flops(96, 128)["total"]) < 1e-6 * flops
+    assert all(r["ms"] > 0 for r in recs)
+    c2.close()
+
+
+def test_device_resident_entry_points(ctx, model, oracle):
+    """_dev forms with caller-owned device buffers (torch used only as the allocator)."""
+    import torch
+
+    fr = W.synth_frame(120, 160, index=9)
+    d_in = torch.from_numpy(fr).cuda()
+    d_rgba = torch.empty((60, 80, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ow, oh = FramePath(ctx).advance_dev(d_in.data_ptr(), 160, 120, 0.5, d_rgba.data_ptr(), d_rgba.numel())
+    ctx.synchronize()
+    assert (ow, oh) == (80, 60)
+    ref, _ = FramePath(ctx).advance(fr, 0.5)
+    assert (d_rgba.cpu().numpy() == ref).all()
+    with pytest.raises(InfurError) as e:
+        FramePath(ctx).advance_dev(d_in.data_ptr(), 160, 120, 0.5, d_rgba.data_ptr(), 100)
+    assert e.value.code == _lib.E_CAPACITY
