@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- 1080p frames/s of the FCN-ResNet50 segmentation path on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (packed BGR frame -> [scale] -> fused pre-proc + stem ->
+FCN-ResNet50 incl. aux head -> bilinear up-sample + argmax + shade -> RGBA mask) over one batch
+of ``--frames-per-step`` distinct synthetic frames per GPU, inputs and outputs resident in HBM.
+N > 1 is launched by torch.distributed.run, one rank per GPU: the weight blob is broadcast
+once over RCCL (timed separately, outside the region), frames are sharded with no data-path
+collective ("weak" scaling: per-GPU work is fixed).  Rank 0 prints ONE JSON line.
+
+The CPU oracle (oracle/) is used here only for the ``cpu_baseline`` leg and a one-frame
+parity spot check; it is never part of the measured path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--scale-mode", type=int, default=0, help="0 nearest (reference), 1 bilinear")
+    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--no-aux", action="store_true", help="skip the aux head (the ONNX graph always evaluates it)")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget")
+    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(blob, frame, budget_s):
+    """The oracle's whole path on the host cores: pre-proc (C) + FCN-ResNet50 (torch-CPU /
+    oneDNN, all cores) + up-sample + ColorCode (C).  Bounded sample: whole 1080p frames until
+    the budget is spent (at least one)."""
+    import torch
+
+    from oracle.infur_oracle import COracle, TorchModel
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    co = COracle(threads=cores)
+    tm = TorchModel(blob)
+    h, w = frame.shape[:2]
+    n, t0 = 0, time.perf_counter()
+    while True:
+        chw = co.pack_normalize(frame)
+        lo, _ = tm.forward_lowres(chw)
+        full = co.upsample_bilinear(lo.numpy(), h, w)
+        co.colorcode(full)
+        n += 1
+        el = time.perf_counter() - t0
+        if el + el / n > budget_s or n >= 8:
+            break
+    return {
+        "value": n / el, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{n} whole {w}x{h} frame(s) through the oracle path (C pre-proc, torch-CPU oneDNN FCN-ResNet50 "
+                  f"incl. aux head, C up-sample + ColorCode) on {cores} threads, {el:.1f} s",
+        "reference_note": "the reference pins ONNX Runtime to 3 intra-op threads (predict_onnx.rs:292); "
+                          "it cannot run here (no cargo/onnxruntime/model file)",
+    }
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from infur_amd import dist as idist
+    from infur_amd import weights as W
+    from infur_amd.processors import Context, FramePath
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    stream = torch.cuda.Stream()
+    ctx = Context(device=local_rank, compute_aux=not a.no_aux, profile=not a.no_profile, stream=stream.cuda_stream)
+
+    # ---- weights: rank 0 synthesises, RCCL broadcast over xGMI, every rank repacks locally ----
+    blob = W.synth_blob() if rank == 0 else None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nbytes = idist.load_model_everywhere(ctx, blob)
+    torch.cuda.synchronize()
+    load_ms = (time.perf_counter() - t0) * 1e3
+
+    # ---- synthetic frames, resident in HBM ----
+    H, Wd, B = a.height, a.width, a.frames_per_step
+    frames_np = [W.synth_frame(H, Wd, index=rank * B + i) for i in range(B)]
+    d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
+    rc_w, rc_h = idims(ctx, Wd, H, a.scale)
+    d_masks = [torch.empty((rc_h, rc_w, 4), dtype=torch.uint8, device="cuda") for _ in range(B)]
+    fp = FramePath(ctx, a.scale_mode)
+    torch.cuda.synchronize()
+
+    def step():
+        for i in range(B):
+            fp.advance_dev(d_frames[i].data_ptr(), Wd, H, a.scale, d_masks[i].data_ptr(), d_masks[i].numel())
+
+    for _ in range(a.warmup):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_total = world * B * a.steps
+    fps = frames_total / elapsed
+    out = {
+        "metric": "1080p frames/sec FCN-ResNet50-12 @1/2/4/8 MI355X; %MFMA roofline",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{Wd}x{H} packed-BGR frame, FCN-ResNet50 f32 (aux head {'off' if a.no_aux else 'on'}), "
+                        f"scale={a.scale}" + (" [BASELINE configs[1]]" if (Wd, H, a.scale) == (1920, 1080, 1.0) else ""),
+            "frames_per_step_per_gpu": B, "sharding": f"frames x{world}, no data-path collective",
+            "weights": f"synthetic seed {W.DEFAULT_SEED:#x}, {nbytes / 1e6:.1f} MB blob",
+            "weights_load_ms": round(load_ms, 2), "ms_per_frame_per_gpu": elapsed / (a.steps * B) * 1e3,
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family from the HIP events of the last timed frame ----
+        flops = W.conv_flops(rc_h, rc_w, aux=not a.no_aux)
+        if not a.no_profile:
+            recs = ctx.profile()
+            conv = [r for r in recs if r["kernel"].startswith("conv_igemm_f32")]
+            c3 = [r for r in conv if r["kernel"].endswith("3x3")]
+            c1 = [r for r in conv if r["kernel"].endswith("1x1")]
+            tf = lambda rs: sum(r["flops"] for r in rs) / max(sum(r["ms"] for r in rs), 1e-9) / 1e9  # noqa: E731
+            ms_all = sum(r["ms"] for r in recs)
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv_igemm_f32 (all 1x1 + 3x3 convs)", "achieved": tf(conv),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf(conv) / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None, "launches": len(conv), "avg_launch_ms": sum(r["ms"] for r in conv) / max(len(conv), 1),
+                "flops_per_launch": sum(r["flops"] for r in conv) / max(len(conv), 1),
+                "conv3x3": {"achieved": tf(c3), "frac": tf(c3) / PEAK_F32_MFMA_TFLOPS, "ms": sum(r["ms"] for r in c3)},
+                "conv1x1": {"achieved": tf(c1), "frac": tf(c1) / PEAK_F32_MFMA_TFLOPS, "ms": sum(r["ms"] for r in c1)},
+                "frame_kernel_ms": ms_all,
+                "other_kernels": {r["kernel"]: {"ms": r["ms"], "GB/s": r["bytes"] / max(r["ms"], 1e-9) / 1e6,
+                                                "frac_hbm": r["bytes"] / max(r["ms"], 1e-9) / 1e6 / PEAK_HBM_GBS}
+                                  for r in recs if not r["kernel"].startswith("conv_igemm")},
+            }
+            if a.kernels:
+                for r in recs:
+                    sys.stderr.write(f"{r['name']:40s} {r['kernel']:24s} {r['ms']:8.3f} ms "
+                                     f"{r['flops'] / max(r['ms'], 1e-9) / 1e9:8.1f} TF/s {r['bytes'] / max(r['ms'], 1e-9) / 1e6:9.1f} GB/s\n")
+        out["config"]["conv_gflop_per_frame"] = flops["total"] / 1e9
+        out["config"]["effective_conv_tflops"] = flops["total"] * fps / world / 1e12
+
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(blob, frames_np[0], a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def idims(ctx, w, h, factor):
+    import ctypes as C
+
+    ow, oh = C.c_uint32(0), C.c_uint32(0)
+    rc = ctx.L.infur_scale_out_dims(w, h, factor, C.byref(ow), C.byref(oh))
+    if rc:
+        raise SystemExit(f"scale dims error {rc}")
+    return ow.value, oh.value
+
+
+if __name__ == "__main__":
+    main()

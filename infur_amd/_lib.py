@@ -123,6 +123,16 @@ def load() -> C.CDLL:
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C infur_amd/csrc). "
             "infur_amd has no CPU fallback."
         )
+    # PyTorch wheels bundle their own HIP/HSA runtime (soname libamdhip64.so.7, same as
+    # /opt/rocm's).  Two runtimes in one process cannot both own the GPU, so when torch is
+    # installed it is imported FIRST: the loader then binds libinfur_hip.so's libamdhip64.so.7
+    # dependency to the copy torch already mapped and the process has a single runtime
+    # (needed for torch.distributed/RCCL next to our kernels).  Without torch the system
+    # runtime from the library's RUNPATH is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
