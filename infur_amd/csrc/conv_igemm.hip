@@ -11,11 +11,13 @@
 //
 // Tiling: BM x BN x 32 per workgroup, one wave per SIMD, each wave TM x TN tiles of 32x32.
 // Operands are staged global -> VGPR -> LDS (row stride 36 floats: ds_write_b128 and
-// ds_read_b128 both conflict-free) with two LDS buffers and one barrier per K step; the
-// global loads of step k+1 are issued before the MFMAs of step k.
+// ds_read_b128 both conflict-free) with two LDS buffers and one barrier per K step; global
+// loads run two K steps ahead and LDS fragment reads one slice ahead of the MFMAs.
 // A lane reads 4 consecutive k of its row with one ds_read_b128 (lanes 0-31: k 0-3,
 // lanes 32-63: k 4-7 of an 8-wide slice) and feeds them to 4 MFMAs; A and B use the same
 // permutation of k, so the sum is complete.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace infur {
@@ -24,6 +26,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;  // floats
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// voffset that is out of range for every tensor this kernel accepts (< 2 GiB): the buffer
+// load then returns zeros -- branch-free zero padding / tail predication.
+constexpr unsigned OOB = 0x80000000u;
 
 template <int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
@@ -60,27 +68,31 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     const int M = a.OH * a.OW;
     const int Ktot = a.KH * a.KW * a.Cin;
 
+    // Buffer descriptors: hardware bounds checking turns an out-of-range offset into a
+    // zero result, so padding taps and ragged tiles need no branches in the K loop.
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.in), 0, (unsigned)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+    const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wt), 0, (unsigned)((size_t)a.Cout * Ktot * 4), 0x00020000);
+
     // per-thread gather coordinates of the A rows it stages
     int a_iy0[A_IT], a_ix0[A_IT];
-    bool a_ok[A_IT];
     const int c4 = tid & 7;  // which float4 of the 32-channel slice
 #pragma unroll
     for (int i = 0; i < A_IT; i++) {
         const int row = (tid >> 3) + i * (T / 8);
         const int m = m0 + row;
-        a_ok[i] = m < M;
         const int oy = m / a.OW, ox = m - oy * a.OW;
-        a_iy0[i] = oy * a.stride - a.pad;
+        // rows past M get coordinates that fail the bounds test for every tap
+        a_iy0[i] = m < M ? oy * a.stride - a.pad : -0x100000;
         a_ix0[i] = ox * a.stride - a.pad;
     }
-    const float* b_ptr[B_IT];
-    bool b_ok[B_IT];
+    unsigned b_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; i++) {
         const int row = (tid >> 3) + i * (T / 8);
         const int n = n0 + row;
-        b_ok[i] = n < a.Cout;
-        b_ptr[i] = a.wt + (size_t)(b_ok[i] ? n : 0) * Ktot + c4 * 4;
+        b_off[i] = n < a.Cout ? (unsigned)n * (unsigned)Ktot * 4u + c4 * 16u : OOB;
     }
 
     f32x16 acc[TM][TN];
@@ -91,32 +103,33 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    float4 ra[A_IT], rb[B_IT];
+    u32x4 ra[A_IT], rb[B_IT];
     const int cchunks = a.Cin / BK;
     const int ksteps = a.KH * a.KW * cchunks;
     int ky = 0, kx = 0, cc = 0;  // coordinates of the K step being LOADED
 
     auto load_step = [&](int ks) {
         const int dy = ky * a.dil, dx = kx * a.dil;
+        const unsigned coff = (unsigned)(cc * BK + c4 * 4) * 4u;
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const size_t off = ((size_t)(ok ? iy : 0) * a.W + (ok ? ix : 0)) * a.Cin + cc * BK + c4 * 4;
-            ra[i] = ok ? *reinterpret_cast<const float4*>(a.in + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off = (unsigned)(iy * a.W + ix) * (unsigned)(a.Cin * 4) + coff;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
         }
+        const unsigned koff = (unsigned)ks * (BK * 4u);
 #pragma unroll
         for (int i = 0; i < B_IT; i++)
-            rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(b_ptr[i] + (size_t)ks * BK)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        // advance (ky,kx,cc) to the next K step
-        if (++cc == cchunks) {
-            cc = 0;
-            if (++kx == a.KW) {
-                kx = 0;
-                ++ky;
-            }
-        }
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, b_off[i] == OOB ? OOB : b_off[i] + koff, 0, 0);
+        // advance (ky,kx,cc) to the next K step, branch-free (all wave-uniform scalars)
+        cc += 1;
+        const int w1 = cc == cchunks;
+        cc = w1 ? 0 : cc;
+        kx += w1;
+        const int w2 = kx == a.KW;
+        kx = w2 ? 0 : kx;
+        ky += w2;
     };
     auto store_step = [&](int buf) {
         float* Ab = As + buf * BM * LDS_STRIDE;
@@ -124,70 +137,123 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int row = (tid >> 3) + i * (T / 8);
-            *reinterpret_cast<float4*>(Ab + row * LDS_STRIDE + c4 * 4) = ra[i];
+            *reinterpret_cast<u32x4*>(Ab + row * LDS_STRIDE + c4 * 4) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_IT; i++) {
             const int row = (tid >> 3) + i * (T / 8);
-            *reinterpret_cast<float4*>(Bb + row * LDS_STRIDE + c4 * 4) = rb[i];
+            *reinterpret_cast<u32x4*>(Bb + row * LDS_STRIDE + c4 * 4) = rb[i];
         }
     };
 
-    load_step(0);
-    store_step(0);
-    __syncthreads();
-
+    // LDS -> register fragments for one 8-wide k slice of buffer `buf`
     const int a_lds = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
     const int b_lds = (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    auto read_frags = [&](int buf, int kk, float4 (&fa)[TM], float4 (&fb)[TN]) {
+        const float* Ab = As + buf * BM * LDS_STRIDE + a_lds + kk * 8;
+        const float* Bb = Bs + buf * BN * LDS_STRIDE + b_lds + kk * 8;
+#pragma unroll
+        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE);
+#pragma unroll
+        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE);
+    };
 
-    for (int ks = 0; ks < ksteps; ks++) {
+    float4 fa[TM], fb[TN], fa_n[TM], fb_n[TN];
+
+    // One K step = 4 slices of 8 k.  Software pipeline with ONE barrier per K step, placed
+    // mid-step, and no control flow inside a step, so the scheduler can hide the staging
+    // (buffer loads, LDS writes, address arithmetic) in the shadow of the 64-cycle MFMAs:
+    //   every slice : the fragments of the next slice (slice 0 of the OTHER buffer after
+    //                 slice 3) are read while the 16 MFMAs of this slice issue;
+    //   slice 1     : registers holding K step ks+1 -> other LDS buffer; then the global
+    //                 loads of K step ks+2 are issued into the same registers;
+    //   slice 2     : s_barrier.  The other buffer is complete before slice 3 reads it, and
+    //                 every read of the current buffer has completed (lgkmcnt(0)) before it
+    //                 is overwritten one step later.
+    // STORE / LOAD / NEXT are compile-time so the steady-state body is straight-line code.
+    auto k_step = [&](int ks, auto STORE, auto LOAD, auto NEXT) {
         const int buf = ks & 1;
-        if (ks + 1 < ksteps) load_step(ks + 1);
-
-        const float* Ab = As + buf * BM * LDS_STRIDE + a_lds;
-        const float* Bb = Bs + buf * BN * LDS_STRIDE + b_lds;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; kk++) {
-            float4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-                fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE + kk * 8);
+            if (kk < BK / 8 - 1)
+                read_frags(buf, kk + 1, fa_n, fb_n);
+            else if (NEXT)
+                read_frags(buf ^ 1, 0, fa_n, fb_n);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    // D rows = output channels, D cols = pixels (operands swapped on purpose)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
                 }
+            if (kk == 1 && STORE) {
+                store_step(buf ^ 1);
+                if (LOAD) load_step(ks + 2);
+            }
+            if (kk == 2 && STORE) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++) fa[i] = fa_n[i];
+#pragma unroll
+            for (int j = 0; j < TN; j++) fb[j] = fb_n[j];
         }
-        if (ks + 1 < ksteps) store_step(buf ^ 1);
-        __syncthreads();
-    }
+    };
+    constexpr auto Y = std::true_type{};
+    constexpr auto N = std::false_type{};
 
-    // epilogue: + bias, + residual, ReLU.  C/D layout of 32x32: col = lane & 31,
-    // row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+    load_step(0);
+    store_step(0);
+    if (ksteps > 1) load_step(1);
+    __syncthreads();
+    read_frags(0, 0, fa, fb);
+
+    int ks = 0;
+    for (; ks + 2 < ksteps; ks++) k_step(ks, Y, Y, Y);  // steady state
+    if (ks + 1 < ksteps) k_step(ks++, Y, N, Y);          // last but one: nothing left to load
+    k_step(ks, N, N, N);                                 // last: nothing left to stage
+
+    // epilogue: + bias, + residual, ReLU.  The MFMA was issued with the weight fragment as the
+    // row operand, so in the 32x32 C/D layout (col = lane & 31, row = (e & 3) + 8 * (e >> 2) +
+    // 4 * (lane >> 5)) a lane owns ONE pixel (col) and, per group g = e >> 2, FOUR consecutive
+    // output channels: NHWC stores, residual loads and bias loads are all 16 bytes wide.
+    const bool vec_ok = (a.Cout & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (n >= a.Cout) continue;
-        const float bv = a.bias[n];
+    for (int i = 0; i < TM; i++) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (lane & 31);
+        if (m >= M) continue;
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
+        for (int j = 0; j < TN; j++) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int m = m0 + row;
-                if (m < M) {
-                    const size_t o = (size_t)m * a.Cout + n;
-                    float v = acc[i][j][e] + bv;
-                    if (a.res) v += a.res[o];
-                    if (a.relu) v = fmaxf(v, 0.0f);
-                    a.out[o] = v;
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + wn * TN * 32 + j * 32 + 8 * g + 4 * (lane >> 5);
+                if (n >= a.Cout) continue;
+                const size_t o = (size_t)m * a.Cout + n;
+                float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (vec_ok) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    if (a.res) {
+                        const float4 rv = *reinterpret_cast<const float4*>(a.res + o);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    if (a.relu) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    }
+                    *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        if (n + t >= a.Cout) break;
+                        float x = v[t] + a.bias[n + t];
+                        if (a.res) x += a.res[o + t];
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        a.out[o + t] = x;
+                    }
                 }
             }
         }
@@ -214,6 +280,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 
 hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s) {
     if (a.Cin % BK != 0) return hipErrorInvalidValue;
+    // 32-bit buffer offsets with 0x80000000 as the out-of-range marker
+    if ((size_t)a.H * a.W * a.Cin * 4 >= 0x80000000ull || (size_t)a.Cout * a.KH * a.KW * a.Cin * 4 >= 0x80000000ull)
+        return hipErrorInvalidValue;
     if (a.Cout >= 128) return launch_cfg<128, 128, 2, 2>(a, s);
     if (a.Cout > 32) return launch_cfg<128, 64, 2, 2>(a, s);
     return launch_cfg<256, 32, 4, 1>(a, s);
