@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof/...) into the tracked files under profiles/.
+
+    python scripts/profile_summary.py gpurun_out/prof r01
+
+Inputs (any subset):
+  <dir>/trace/**/_kernel_stats.csv        from  rocprofv3 --kernel-trace --stats -- python bench.py
+  <dir>/pmc_FETCH_SIZE/**/counter_collection.csv, <dir>/pmc_WRITE_SIZE/**  (separate --pmc passes)
+  <dir>/pmc_SQ/** , <dir>/pmc_GRBM/**                                        (utilisation passes)
+Outputs: profiles/<tag>_kernel_stats.csv, profiles/<tag>_summary.md, profiles/traffic_latest.json
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def find(d, pat):
+    g = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return g[0] if g else None
+
+
+def short(name):
+    n = name.replace("void infur::", "").replace("infur::", "")
+    return n.split("(")[0]
+
+
+def pmc(d):
+    f = find(d, "*counter_collection.csv")
+    if not f:
+        return {}
+    by = collections.defaultdict(lambda: collections.defaultdict(dict))
+    for r in csv.DictReader(open(f)):
+        k = int(r["Dispatch_Id"])
+        by[short(r["Kernel_Name"])][k][r["Counter_Name"]] = float(r["Counter_Value"])
+        by[short(r["Kernel_Name"])][k]["_dur"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return by
+
+
+def main():
+    d, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "profiles")
+    os.makedirs(out, exist_ok=True)
+    md = [f"# rocprofv3 summary {tag}", ""]
+    ks = find(os.path.join(d, "trace"), "*kernel_stats.csv")
+    if ks:
+        shutil.copy(ks, os.path.join(out, f"{tag}_kernel_stats.csv"))
+        md += ["## kernel trace (`rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline`)", "",
+               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+        for r in csv.DictReader(open(ks)):
+            md.append(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
+                      f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+        md.append("")
+        bj = os.path.join(d, "bench_trace.json")
+        if os.path.exists(bj):
+            shutil.copy(bj, os.path.join(out, f"{tag}_bench_under_rocprof.json"))
+    traffic = {}
+    fe, wr = pmc(os.path.join(d, "pmc_FETCH_SIZE")), pmc(os.path.join(d, "pmc_WRITE_SIZE"))
+    if fe or wr:
+        md += ["## HBM traffic per launch (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
+               "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their",
+               "bytes (MI355X_MICROARCH.md, HBM section), so read bytes = 2 x FETCH_SIZE x 1024.", "",
+               "| kernel | launches | avg read MB (2xFETCH) | avg write MB | avg us |", "|---|---|---|---|---|"]
+        for k in sorted(set(fe) | set(wr)):
+            f = [v.get("FETCH_SIZE", 0.0) for v in fe.get(k, {}).values()]
+            w = [v.get("WRITE_SIZE", 0.0) for v in wr.get(k, {}).values()]
+            du = [v["_dur"] for v in fe.get(k, {}).values()]
+            rd = 2.0 * 1024.0 * sum(f) / max(len(f), 1)
+            wb = 1024.0 * sum(w) / max(len(w), 1)
+            traffic[k] = {"launches": max(len(f), len(w)), "read_bytes_per_launch": rd, "write_bytes_per_launch": wb}
+            md.append(f"| `{k}` | {max(len(f), len(w))} | {rd / 1e6:.1f} | {wb / 1e6:.1f} | {sum(du) / max(len(du), 1) / 1e3:.1f} |")
+        md.append("")
+        with open(os.path.join(out, "traffic_latest.json"), "w") as fjs:
+            json.dump({"tag": tag, "note": "bytes per launch, averaged over all launches of the kernel in one frame pass; "
+                       "read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB", "kernels": traffic}, fjs, indent=1)
+    sq, gr = pmc(os.path.join(d, "pmc_SQ")), pmc(os.path.join(d, "pmc_GRBM"))
+    if gr:
+        md += ["## MFMA utilisation (`--pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES`)", "",
+               "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
+               "clock = GRBM_GUI_ACTIVE / 8 / duration.", "", "| kernel | launches | MfmaUtil % (time-weighted) | clock GHz |", "|---|---|---|---|"]
+        for k, disp in sorted(gr.items()):
+            num = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for v in disp.values())
+            den = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in disp.values()) / 8.0 * 1024.0
+            clk = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in disp.values()) / 8.0 / max(sum(v["_dur"] for v in disp.values()), 1)
+            if den > 0 and num > 0:
+                md.append(f"| `{k}` | {len(disp)} | {100.0 * num / den:.1f} | {clk:.2f} |")
+        md.append("")
+    if sq:
+        md += ["## SQ wave states (`--pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT`)", "",
+               "| kernel | wait_inst % | wait_any % | active % | LDS bank conflict cycles |", "|---|---|---|---|---|"]
+        for k, disp in sorted(sq.items()):
+            wc = sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in disp.values())
+            if wc <= 0:
+                continue
+            g = lambda n: 100.0 * sum(v.get(n, 0.0) for v in disp.values()) / wc  # noqa: E731
+            md.append(f"| `{k}` | {g('SQ_WAIT_INST_ANY'):.1f} | {g('SQ_WAIT_ANY'):.1f} | {g('SQ_ACTIVE_INST_ANY'):.1f} | "
+                      f"{sum(v.get('SQ_LDS_BANK_CONFLICT', 0.0) for v in disp.values()):.0f} |")
+        md.append("")
+    with open(os.path.join(out, f"{tag}_summary.md"), "w") as f:
+        f.write("\n".join(md))
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    main()
