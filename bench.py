@@ -165,16 +165,28 @@ def main():
         flops = W.conv_flops(rc_h, rc_w, aux=not a.no_aux)
         if not a.no_profile:
             recs = ctx.profile()
+            k3 = {c.name for c in W.graph(50) if c.k == 3}
             conv = [r for r in recs if r["kernel"].startswith("conv_igemm_f32")]
-            c3 = [r for r in conv if r["kernel"].endswith("3x3")]
-            c1 = [r for r in conv if r["kernel"].endswith("1x1")]
+            dom = [r for r in conv if r["kernel"] == "conv_igemm_f32<128,128>"]
+            c3 = [r for r in conv if r["name"] in k3]
+            c1 = [r for r in conv if r["name"] not in k3]
             tf = lambda rs: sum(r["flops"] for r in rs) / max(sum(r["ms"] for r in rs), 1e-9) / 1e9  # noqa: E731
             ms_all = sum(r["ms"] for r in recs)
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tj) and (Wd, H, a.scale) == (1920, 1080, 1.0):
+                t = json.load(open(tj))["kernels"].get("conv_igemm_f32_kernel<128, 128, 2, 2>")
+                if t:
+                    traffic = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_f32 (all 1x1 + 3x3 convs)", "achieved": tf(conv),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf(conv) / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "launches": len(conv), "avg_launch_ms": sum(r["ms"] for r in conv) / max(len(conv), 1),
-                "flops_per_launch": sum(r["flops"] for r in conv) / max(len(conv), 1),
+                "bound": "mfma", "kernel": "conv_igemm_f32_kernel<128,128,2,2> (48 of the 56 conv launches of a frame)",
+                "achieved": tf(dom), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf(dom) / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic, "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes "
+                                                    "(profiles/traffic_latest.json); null if not collected for this shape",
+                "launches": len(dom), "avg_launch_ms": sum(r["ms"] for r in dom) / max(len(dom), 1),
+                "flops_per_launch": sum(r["flops"] for r in dom) / max(len(dom), 1),
+                "algorithmic_bytes_per_launch": sum(r["bytes"] for r in dom) / max(len(dom), 1),
+                "all_convs": {"achieved": tf(conv), "frac": tf(conv) / PEAK_F32_MFMA_TFLOPS, "ms": sum(r["ms"] for r in conv)},
                 "conv3x3": {"achieved": tf(c3), "frac": tf(c3) / PEAK_F32_MFMA_TFLOPS, "ms": sum(r["ms"] for r in c3)},
                 "conv1x1": {"achieved": tf(c1), "frac": tf(c1) / PEAK_F32_MFMA_TFLOPS, "ms": sum(r["ms"] for r in c1)},
                 "frame_kernel_ms": ms_all,

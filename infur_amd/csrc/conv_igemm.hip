@@ -331,4 +331,10 @@ hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s) {
     return launch_cfg<256, 32, 4, 1>(a, s);
 }
 
+const char* conv_igemm_f32_config(const ConvArgs& a) {
+    if (a.Cout >= 128) return "conv_igemm_f32<128,128>";
+    if (a.Cout > 32) return "conv_igemm_f32<128,64>";
+    return "conv_igemm_f32<256,32>";
+}
+
 }  // namespace infur

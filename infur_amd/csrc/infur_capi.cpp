@@ -441,7 +441,7 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
     const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
     const double bytes = 4.0 * ((double)in.floats() + (double)out->floats() * (res ? 2 : 1) + (double)L.cout * L.cin * L.k * L.k);
     {
-        ProfScope ps(c, L.name, L.k == 1 ? "conv_igemm_f32_1x1" : "conv_igemm_f32_3x3", flops, bytes);
+        ProfScope ps(c, L.name, conv_igemm_f32_config(a), flops, bytes);
         HIPCHK(c, launch_conv_igemm_f32(a, c->stream));
     }
     if (c->opt.keep_activations) c->kept.push_back(*out);

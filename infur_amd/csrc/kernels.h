@@ -21,6 +21,8 @@ struct ConvArgs {
 
 // conv as implicit GEMM on v_mfma_f32_32x32x2_f32 (Cin % 32 == 0)
 hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);
+// name of the tile configuration launch_conv_igemm_f32 picks for these arguments
+const char* conv_igemm_f32_config(const ConvArgs& a);
 
 // stem: packed BGR u8 -> (LUT normalise, BGR->RGB) -> conv 7x7/2 pad 3 (3->64) + bias + ReLU,
 // NHWC f32 out.  wt: [7][7][3][64] (ky,kx,c,cout), lut: [3][256] in RGB order.
