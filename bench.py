@@ -40,40 +40,51 @@ def parse():
     ap.add_argument("--no-aux", action="store_true", help="skip the aux head (the ONNX graph always evaluates it)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU baseline budget")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     return ap.parse_args()
 
 
 def cpu_baseline(blob, frame, budget_s):
     """The oracle's whole path on the host cores: pre-proc (C) + FCN-ResNet50 (torch-CPU /
-    oneDNN, all cores) + up-sample + ColorCode (C).  Bounded sample: whole 1080p frames until
-    the budget is spent (at least one)."""
+    oneDNN) + up-sample + ColorCode (C).  Bounded sample: one whole 1080p frame per thread
+    count.  oneDNN's best thread count on a many-core host is far below the core count (256
+    threads is ~100x slower than 16 on the GPU box), so a short sweep picks the fastest; the
+    reference's own setting (ONNX Runtime pinned to 3 intra-op threads, predict_onnx.rs:292)
+    is timed too and reported beside it."""
     import torch
 
     from oracle.infur_oracle import COracle, TorchModel
 
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    co = COracle(threads=cores)
+    co = COracle(threads=min(cores, 16))
     tm = TorchModel(blob)
     h, w = frame.shape[:2]
-    n, t0 = 0, time.perf_counter()
-    while True:
+
+    def one_frame():
+        t0 = time.perf_counter()
         chw = co.pack_normalize(frame)
         lo, _ = tm.forward_lowres(chw)
         full = co.upsample_bilinear(lo.numpy(), h, w)
         co.colorcode(full)
-        n += 1
-        el = time.perf_counter() - t0
-        if el + el / n > budget_s or n >= 8:
-            break
+        return time.perf_counter() - t0
+
+    results, spent = {}, 0.0
+    for th in (16, 32, 3):
+        if th > cores or spent > budget_s:
+            continue
+        torch.set_num_threads(th)
+        results[th] = one_frame()
+        spent += results[th]
+    best = min(results, key=results.get)
     return {
-        "value": n / el, "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": f"{n} whole {w}x{h} frame(s) through the oracle path (C pre-proc, torch-CPU oneDNN FCN-ResNet50 "
-                  f"incl. aux head, C up-sample + ColorCode) on {cores} threads, {el:.1f} s",
-        "reference_note": "the reference pins ONNX Runtime to 3 intra-op threads (predict_onnx.rs:292); "
-                          "it cannot run here (no cargo/onnxruntime/model file)",
+        "value": 1.0 / results[best], "unit": "frames/s", "cores": best, "kind": "port",
+        "sample": f"one whole {w}x{h} frame through the oracle path (C pre-proc, torch-CPU oneDNN FCN-ResNet50 incl. aux "
+                  f"head, C up-sample + ColorCode) per thread count {sorted(results)}; {spent:.1f} s of CPU wall time; "
+                  f"host has {cores} logical cores",
+        "frames_per_s_by_threads": {str(k): 1.0 / v for k, v in sorted(results.items())},
+        "reference_note": "the reference pins ONNX Runtime to 3 intra-op threads (predict_onnx.rs:292); the reference "
+                          "itself cannot run here (no cargo / onnxruntime / model file)",
     }
 
 

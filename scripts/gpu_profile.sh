@@ -1,0 +1,17 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for profiles/ on the GPU box (run through gpurun).
+#   bash scripts/gpu_profile.sh        -> gpurun_out/prof/{trace,pmc_*}
+# --pmc passes are separate runs with --kernel-trace only (gpurun refuses other combinations).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
+echo "trace rc=$?"
+SMALL="--no-cpu-baseline --no-profile --steps 1 --warmup 1 --frames-per-step 2"
+for P in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$P -- python $R/bench.py $SMALL > /dev/null 2> $OUT/pmc_$P.err; echo "pmc $P rc=$?"
+done
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_GRBM -- python $R/bench.py $SMALL > /dev/null 2> $OUT/pmc_GRBM.err; echo "pmc GRBM rc=$?"
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python $R/bench.py $SMALL > /dev/null 2> $OUT/pmc_SQ.err; echo "pmc SQ rc=$?"
+du -sh $OUT

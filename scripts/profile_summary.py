@@ -20,7 +20,7 @@ import sys
 
 def find(d, pat):
     g = glob.glob(os.path.join(d, "**", pat), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None  # newest (gpurun merges, never deletes)
 
 
 def short(name):
