@@ -16,6 +16,7 @@
 // A lane reads 4 consecutive k of its row with one ds_read_b128 (lanes 0-31: k 0-3,
 // lanes 32-63: k 4-7 of an 8-wide slice) and feeds them to 4 MFMAs; A and B use the same
 // permutation of k, so the sum is complete.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -308,7 +309,8 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM;
     const int ntiles = (a.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+    size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+    if (const char* e = getenv("INFUR_EXP_LDS_PAD")) lds += (size_t)atoi(e);  // occupancy experiment only
     auto k = conv_igemm_f32_kernel<BM, BN, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) {
