@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU baseline budget")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
+                         "multi-process path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -105,12 +108,18 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank if a.backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
+    coll_dev = f"cuda:{dev}" if a.backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
+        else:
+            dist.init_process_group("gloo")
 
     stream = torch.cuda.Stream()
-    ctx = Context(device=local_rank, compute_aux=not a.no_aux, profile=not a.no_profile, stream=stream.cuda_stream)
+    ctx = Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=stream.cuda_stream)
 
     # ---- weights: rank 0 synthesises, RCCL broadcast over xGMI, every rank repacks locally ----
     blob = W.synth_blob() if rank == 0 else None
@@ -118,7 +127,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nbytes = idist.load_model_everywhere(ctx, blob)
+    nbytes = idist.load_model_everywhere(ctx, blob, coll_device=coll_dev)
     torch.cuda.synchronize()
     load_ms = (time.perf_counter() - t0) * 1e3
 
@@ -151,7 +160,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -165,7 +174,7 @@ def main():
         "config": {
             "workload": f"{Wd}x{H} packed-BGR frame, FCN-ResNet50 f32 (aux head {'off' if a.no_aux else 'on'}), "
                         f"scale={a.scale}" + (" [BASELINE configs[1]]" if (Wd, H, a.scale) == (1920, 1080, 1.0) else ""),
-            "frames_per_step_per_gpu": B, "sharding": f"frames x{world}, no data-path collective",
+            "frames_per_step_per_gpu": B, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if world > 1 else None,
             "weights": f"synthetic seed {W.DEFAULT_SEED:#x}, {nbytes / 1e6:.1f} MB blob",
             "weights_load_ms": round(load_ms, 2), "ms_per_frame_per_gpu": elapsed / (a.steps * B) * 1e3,
         },

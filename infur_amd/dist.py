@@ -59,11 +59,13 @@ def broadcast_blob(blob: Optional[bytes], device=None, src: int = 0):
     return t
 
 
-def load_model_everywhere(ctx, blob: Optional[bytes], src: int = 0):
-    """Broadcast + per-rank load.  ``ctx``: infur_amd.processors.Context on this rank's GPU."""
+def load_model_everywhere(ctx, blob: Optional[bytes], src: int = 0, coll_device: Optional[str] = None):
+    """Broadcast + per-rank load.  ``ctx``: infur_amd.processors.Context on this rank's GPU.
+    ``coll_device``: where the collective runs (default: this rank's GPU, i.e. RCCL)."""
     import torch
 
-    t = broadcast_blob(blob, device=f"cuda:{ctx.device}", src=src)
+    gpu = f"cuda:{ctx.device}"
+    t = broadcast_blob(blob, device=coll_device or gpu, src=src).to(gpu)
     torch.cuda.synchronize()
     ctx.check(ctx.L.infur_model_load_blob_dev(ctx.h, t.data_ptr(), t.numel()))
     return t.numel()
