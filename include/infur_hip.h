@@ -165,6 +165,10 @@ int32_t infur_colorcode(infur_ctx* ctx, const float* khw, uint32_t k, uint32_t h
 int32_t infur_colorcode_dev(infur_ctx* ctx, const void* d_khw, uint32_t k, uint32_t h,
                             uint32_t w, void* d_rgba);
 
+/* ---- display conversion of the scaled frame (app.rs:132-144): packed BGR -> [r,g,b,255] ---- */
+int32_t infur_bgr_to_rgba(infur_ctx* ctx, const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* rgba);
+int32_t infur_bgr_to_rgba_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t h, void* d_rgba);
+
 /* ---- fused per-frame path (app.rs:107-153): scale -> model -> decode(out[0]) ---- */
 /* rgba: oh*ow*4 bytes.  scaled_bgr (optional): the scaled frame, oh*ow*3 bytes (the GUI
  * shows it, app.rs:132-144).  With no model loaded returns INFUR_E_MODEL_NOT_LOADED after
@@ -177,6 +181,29 @@ int32_t infur_frame_advance_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, u
                                 float factor, uint32_t scale_mode, void* d_rgba,
                                 size_t rgba_capacity, void* d_scaled_bgr, uint32_t* ow,
                                 uint32_t* oh);
+
+/* ---- streaming (infur/src/main.rs:27-99,105): bounded queue, copies overlapped with compute ----
+ * The reference back-pressures its producer with sync_channel(2) (main.rs:105); a stream
+ * here is a ring of `depth` pinned + device slots.  submit() copies the caller's frame into a
+ * pinned slot and enqueues H2D -> scale/model/decode -> D2H on three HIP streams (so frame
+ * i+1's upload and frame i-1's download overlap frame i's kernels); it blocks only when all
+ * `depth` slots are in flight.  collect() returns finished masks strictly in submission
+ * order.  Frames are packed bgr24 exactly as `ffmpeg -f image2pipe -pix_fmt bgr24` emits them
+ * (ff-video/src/decoder.rs:53-64,156-165). */
+typedef struct infur_stream infur_stream;
+int32_t infur_stream_create(infur_ctx* ctx, uint32_t depth, infur_stream** out);
+void infur_stream_destroy(infur_stream* st);
+/* INFUR_OK, or an error of infur_frame_advance; frame_id is returned by collect */
+int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor,
+                            uint32_t scale_mode, uint64_t frame_id);
+/* number of submitted-but-not-collected frames */
+uint32_t infur_stream_pending(const infur_stream* st);
+/* mask dimensions and id of the oldest pending frame (no waiting), to size collect()'s buffers */
+int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint32_t* ow, uint32_t* oh);
+/* waits for the oldest pending frame.  rgba: ow*oh*4 bytes; scaled_bgr optional (ow*oh*3).
+ * INFUR_E_INVALID_ARG when nothing is pending. */
+int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t rgba_capacity, uint8_t* scaled_bgr,
+                             uint64_t* frame_id, uint32_t* ow, uint32_t* oh);
 
 /* ---- profiling (options.profile = 1) ---- */
 /* number of kernel records of the last advance (synchronises the stream) */

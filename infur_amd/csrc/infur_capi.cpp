@@ -876,6 +876,30 @@ int32_t infur_colorcode(infur_ctx* c, const float* khw, uint32_t k, uint32_t h, 
     return INFUR_OK;
 }
 
+// ---- display conversion ----
+int32_t infur_bgr_to_rgba_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, void* d_rgba) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    if ((size_t)w * h == 0) return INFUR_OK;
+    if (!d_bgr || !d_rgba) return INFUR_E_INVALID_ARG;
+    ProfScope ps(c, "display", "bgr_to_rgba", 0, (double)w * h * 7.0);
+    HIPCHK(c, launch_bgr_to_rgba((const uint8_t*)d_bgr, (int)w, (int)h, (uint32_t*)d_rgba, c->stream));
+    return INFUR_OK;
+}
+
+int32_t infur_bgr_to_rgba(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* rgba) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    const size_t npix = (size_t)w * h;
+    if (npix == 0) return INFUR_OK;
+    if (!bgr || !rgba) return INFUR_E_INVALID_ARG;
+    RETIF(ensure(c, c->st_in, npix * 3));
+    RETIF(ensure(c, c->st_rgba, npix * 4));
+    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
+    RETIF(infur_bgr_to_rgba_dev(c, c->st_in.p, w, h, c->st_rgba.p));
+    HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return INFUR_OK;
+}
+
 // ---- fused frame path ----
 int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                                 void* d_rgba, size_t cap, void* d_scaled, uint32_t* ow, uint32_t* oh) {
@@ -936,6 +960,158 @@ int32_t infur_frame_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32
     if (rc == INFUR_OK && rgba) HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, need, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return rc;
+}
+
+// ---- streaming ----
+}  // extern "C" (the struct below needs C++ members)
+
+struct infur_stream {
+    struct Slot {
+        uint8_t* h_in = nullptr;   // pinned
+        uint8_t* h_out = nullptr;  // pinned: [rgba | scaled bgr]
+        void* d_in = nullptr;
+        void* d_out = nullptr;  // [rgba | scaled bgr]
+        size_t in_cap = 0, out_cap = 0;
+        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_done = nullptr;
+        uint64_t id = 0;
+        uint32_t ow = 0, oh = 0;
+        int32_t status = INFUR_OK;
+        bool busy = false;
+    };
+    infur_ctx* ctx = nullptr;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    std::vector<Slot> slots;
+    uint64_t head = 0, tail = 0;  // tail = next to collect, head = next to submit
+};
+
+namespace {
+int32_t slot_reserve(infur_ctx* c, infur_stream::Slot& sl, size_t in_bytes, size_t out_bytes) {
+    if (sl.in_cap < in_bytes) {
+        if (sl.h_in) HIPCHK(c, hipHostFree(sl.h_in));
+        if (sl.d_in) HIPCHK(c, hipFree(sl.d_in));
+        sl.h_in = nullptr; sl.d_in = nullptr; sl.in_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_in, in_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc(&sl.d_in, in_bytes));
+        sl.in_cap = in_bytes;
+    }
+    if (sl.out_cap < out_bytes) {
+        if (sl.h_out) HIPCHK(c, hipHostFree(sl.h_out));
+        if (sl.d_out) HIPCHK(c, hipFree(sl.d_out));
+        sl.h_out = nullptr; sl.d_out = nullptr; sl.out_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_out, out_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc(&sl.d_out, out_bytes));
+        sl.out_cap = out_bytes;
+    }
+    return INFUR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t infur_stream_create(infur_ctx* c, uint32_t depth, infur_stream** out) {
+    if (!c || !out || depth == 0 || depth > 64) return INFUR_E_INVALID_ARG;
+    *out = nullptr;
+    infur_stream* st = new infur_stream();
+    st->ctx = c;
+    st->slots.resize(depth);
+    bool ok = hipStreamCreateWithFlags(&st->s_h2d, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st->s_d2h, hipStreamNonBlocking) == hipSuccess;
+    for (auto& sl : st->slots)
+        ok = ok && hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        infur_stream_destroy(st);
+        return fail(c, INFUR_E_HIP, "could not create the streaming ring");
+    }
+    *out = st;
+    return INFUR_OK;
+}
+
+void infur_stream_destroy(infur_stream* st) {
+    if (!st) return;
+    if (st->ctx && st->ctx->stream) (void)hipStreamSynchronize(st->ctx->stream);
+    if (st->s_h2d) (void)hipStreamSynchronize(st->s_h2d);
+    if (st->s_d2h) (void)hipStreamSynchronize(st->s_d2h);
+    for (auto& sl : st->slots) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        for (hipEvent_t e : {sl.ev_h2d, sl.ev_comp, sl.ev_done})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (st->s_h2d) (void)hipStreamDestroy(st->s_h2d);
+    if (st->s_d2h) (void)hipStreamDestroy(st->s_d2h);
+    delete st;
+}
+
+uint32_t infur_stream_pending(const infur_stream* st) { return st ? (uint32_t)(st->head - st->tail) : 0; }
+
+int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
+                            uint64_t frame_id) {
+    if (!st || !bgr) return INFUR_E_INVALID_ARG;
+    infur_ctx* c = st->ctx;
+    int32_t rc = infur_scale_validate(factor);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    uint32_t ow = 0, oh = 0;
+    rc = infur_scale_out_dims(w, h, factor, &ow, &oh);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
+    const size_t depth = st->slots.size();
+    if (st->head - st->tail >= depth)
+        return fail(c, INFUR_E_CAPACITY, "all %zu slots are in flight: collect before submitting more", depth);
+    infur_stream::Slot& sl = st->slots[st->head % depth];
+    const size_t in_bytes = (size_t)w * h * 3, rgba_bytes = (size_t)ow * oh * 4, sc_bytes = (size_t)ow * oh * 3;
+    if (in_bytes == 0 || rgba_bytes == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
+    RETIF(slot_reserve(c, sl, in_bytes, rgba_bytes + sc_bytes));
+    memcpy(sl.h_in, bgr, in_bytes);  // the caller's buffer is free again when submit returns
+    sl.id = frame_id;
+    sl.ow = ow;
+    sl.oh = oh;
+    HIPCHK(c, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
+    HIPCHK(c, hipEventRecord(sl.ev_h2d, st->s_h2d));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_h2d, 0));
+    uint8_t* d_rgba = (uint8_t*)sl.d_out;
+    uint8_t* d_sc = d_rgba + rgba_bytes;
+    uint32_t a = 0, b = 0;
+    sl.status = infur_frame_advance_dev(c, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
+    if (sl.status != INFUR_OK) return sl.status;
+    HIPCHK(c, hipEventRecord(sl.ev_comp, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
+    HIPCHK(c, hipMemcpyAsync(sl.h_out, sl.d_out, rgba_bytes + sc_bytes, hipMemcpyDeviceToHost, st->s_d2h));
+    HIPCHK(c, hipEventRecord(sl.ev_done, st->s_d2h));
+    sl.busy = true;
+    st->head++;
+    return INFUR_OK;
+}
+
+int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint32_t* ow, uint32_t* oh) {
+    if (!st || st->head == st->tail) return INFUR_E_INVALID_ARG;
+    const infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
+    if (frame_id) *frame_id = sl.id;
+    if (ow) *ow = sl.ow;
+    if (oh) *oh = sl.oh;
+    return INFUR_OK;
+}
+
+int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t cap, uint8_t* scaled, uint64_t* frame_id,
+                             uint32_t* ow, uint32_t* oh) {
+    if (!st) return INFUR_E_INVALID_ARG;
+    infur_ctx* c = st->ctx;
+    if (st->head == st->tail) return fail(c, INFUR_E_INVALID_ARG, "no frame is pending");
+    infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
+    const size_t rgba_bytes = (size_t)sl.ow * sl.oh * 4, sc_bytes = (size_t)sl.ow * sl.oh * 3;
+    if (rgba && cap < rgba_bytes) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", rgba_bytes, cap);
+    HIPCHK(c, hipEventSynchronize(sl.ev_done));
+    if (rgba) memcpy(rgba, sl.h_out, rgba_bytes);
+    if (scaled) memcpy(scaled, sl.h_out + rgba_bytes, sc_bytes);
+    if (frame_id) *frame_id = sl.id;
+    if (ow) *ow = sl.ow;
+    if (oh) *oh = sl.oh;
+    sl.busy = false;
+    st->tail++;
+    return INFUR_OK;
 }
 
 // ---- profiling ----

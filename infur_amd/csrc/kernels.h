@@ -48,6 +48,9 @@ hipError_t launch_scale_bgr(const uint8_t* in, int W, int H, uint8_t* out, int O
 hipError_t launch_pack_normalize(const uint8_t* bgr, int W, int H, const float* lut, float* chw,
                                  hipStream_t s);
 
+// display conversion (app.rs:132-144): packed BGR -> [r,g,b,255]
+hipError_t launch_bgr_to_rgba(const uint8_t* bgr, int W, int H, uint32_t* rgba, hipStream_t s);
+
 // low-res NHWC logits [lh][lw][K] -> planar [K][lh][lw]
 hipError_t launch_nhwc_to_planar(const float* in, int H, int W, int C, float* out,
                                  hipStream_t s);

@@ -140,6 +140,40 @@ hipError_t launch_pack_normalize(const uint8_t* bgr, int W, int H, const float* 
 }
 
 // ---------------------------------------------------------------------------------------
+// display conversion of the (scaled) frame, infur/src/app.rs:132-144:
+// Color32::from_rgb(cs[2], cs[1], cs[0]) per pixel -> [r, g, b, 255].  4 pixels per thread.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    bgr_to_rgba_kernel(const uint8_t* __restrict__ bgr, size_t npix, uint32_t* __restrict__ rgba) {
+    const size_t nquad = npix >> 2;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(bgr) & 3) | (reinterpret_cast<uintptr_t>(rgba) & 15)) == 0;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nquad + 1; q += (size_t)gridDim.x * 256) {
+        if (aligned && q < nquad) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(bgr + q * 12);
+            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];  // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+            uint4 o;
+            o.x = 0xff000000u | ((w0 & 0xffu) << 16) | (w0 & 0xff00u) | ((w0 >> 16) & 0xffu);
+            o.y = 0xff000000u | ((w0 >> 24) << 16) | ((w1 & 0xffu) << 8) | ((w1 >> 8) & 0xffu);
+            o.z = 0xff000000u | (((w1 >> 16) & 0xffu) << 16) | ((w1 >> 24) << 8) | (w2 & 0xffu);
+            o.w = 0xff000000u | (((w2 >> 8) & 0xffu) << 16) | (((w2 >> 16) & 0xffu) << 8) | (w2 >> 24);
+            *reinterpret_cast<uint4*>(rgba + q * 4) = o;
+        } else {
+            const size_t lo = q * 4, hi = lo + 4 < npix ? lo + 4 : npix;
+            for (size_t i = lo; i < hi; i++)
+                rgba[i] = 0xff000000u | ((uint32_t)bgr[3 * i] << 16) | ((uint32_t)bgr[3 * i + 1] << 8) | bgr[3 * i + 2];
+        }
+    }
+}
+
+hipError_t launch_bgr_to_rgba(const uint8_t* bgr, int W, int H, uint32_t* rgba, hipStream_t s) {
+    const size_t npix = (size_t)W * H;
+    size_t blocks = (npix / 4 + 256) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bgr_to_rgba_kernel, dim3((unsigned)blocks), dim3(256), 0, s, bgr, npix, rgba);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // low-res NHWC -> planar (tiny: 21 x 135 x 240 floats)
 // ---------------------------------------------------------------------------------------
 __global__ void nhwc_to_planar_kernel(const float* __restrict__ in, int HW, int C, float* __restrict__ out) {

@@ -1,0 +1,169 @@
+"""GPU tests of the app graph and the streaming mode: the reference's own app tests
+(infur/src/app.rs:175-253) re-expressed on synthetic clips of the same dimensions, plus
+fused-vs-unfused and streamed-vs-direct equality."""
+import io
+
+import numpy as np
+import pytest
+
+from infur_amd import weights as W
+from infur_amd.app import (AppCmd, ProcessingApp, RawVideoSource, StreamPath, SyntheticSource, VideoCmd,
+                           VideoProcError)
+from infur_amd.processors import Context, FramePath, InfurError, ModelCmd, ValidScaleError
+from infur_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def short_large_input():  # 1280x720 (the doc comments in app.rs:165,169 are swapped; assertions rule)
+    return SyntheticSource(1280, 720, n_frames=150)
+
+
+def long_small_input():  # 640x480
+    return SyntheticSource(640, 480, n_frames=400)
+
+
+@pytest.fixture()
+def app(ctx):
+    a = ProcessingApp(ctx)
+    a.control(AppCmd.Model(ModelCmd.Load("")))  # the reference's app tests run without a model
+    return a
+
+
+def test_void(app):  # app.rs:175-180
+    assert app.generate() is None
+    assert app.generate() is None
+
+
+def test_scale(app):  # app.rs:182-189
+    app.control(AppCmd.Video(VideoCmd.Play(short_large_input())))
+    app.control(AppCmd.Scale(0.5))
+    f2 = app.generate()
+    assert f2.size == [1280 // 2, 720 // 2] and f2.decoded_buffer is None
+
+
+def test_switch_scale(app):  # app.rs:191-201
+    app.control(AppCmd.Video(VideoCmd.Play(long_small_input())))
+    assert app.generate().size == [640, 480]
+    app.control(AppCmd.Scale(0.5))
+    assert app.generate().size == [640 // 2, 480 // 2]
+
+
+def test_switch_video_then_scale(app):  # app.rs:203-218
+    app.control(AppCmd.Video(VideoCmd.Play(long_small_input())))
+    assert app.generate().size == [640, 480]
+    app.control(AppCmd.Video(VideoCmd.Play(short_large_input())))
+    assert app.generate().size == [1280, 720]
+    app.control(AppCmd.Scale(2.0))
+    assert app.generate().size == [1280 * 2, 720 * 2]
+
+
+def test_scaled_frame_after_stopped_video(app):  # app.rs:220-236
+    app.control(AppCmd.Video(VideoCmd.Play(short_large_input())))
+    f1 = app.generate()
+    assert f1.size == [1280, 720]
+    app.control(AppCmd.Video(VideoCmd.Stop()))
+    f2 = app.generate()
+    assert f1.id == f2.id and not app.is_dirty()
+    app.control(AppCmd.Scale(0.5))
+    assert app.is_dirty()
+    f3 = app.generate()
+    assert f2.id == f3.id and f3.size == [1280 // 2, 720 // 2]
+
+
+def test_pause_video(app):  # app.rs:238-252
+    app.control(AppCmd.Video(VideoCmd.Play(long_small_input())))
+    f1 = app.generate()
+    app.control(AppCmd.Video(VideoCmd.Pause(True)))
+    assert not app.is_dirty()
+    f2 = app.generate()
+    assert f1.id == f2.id and not app.is_dirty()
+    app.control(AppCmd.Video(VideoCmd.Pause(False)))
+    assert app.is_dirty()
+    f3 = app.generate()
+    assert f2.id != f3.id
+
+
+def test_errors_are_relayed_not_fatal(app):  # main.rs:69-71,94-96
+    with pytest.raises(ValidScaleError):
+        app.control(AppCmd.Scale(-1.0))
+    app.control(AppCmd.Video(VideoCmd.Play(SyntheticSource(32, 24, n_frames=1))))
+    assert app.generate().id == 1
+    with pytest.raises(VideoProcError):
+        app.generate()  # FinishedNormally is relayed and the player closes
+    f = app.generate()  # processing continues on the last frame
+    assert f.id == 1 and not app.is_dirty()
+
+
+def test_display_conversion(ctx):  # app.rs:132-144
+    for (w, h) in ((64, 48), (97, 61), (5, 3)):
+        fr = W.synth_frame(h, w, index=2)
+        out = np.empty((h, w, 4), np.uint8)
+        ctx.check(ctx.L.infur_bgr_to_rgba(ctx.h, fr.ctypes.data, w, h, out.ctypes.data))
+        assert (out[..., 0] == fr[..., 2]).all() and (out[..., 1] == fr[..., 1]).all()
+        assert (out[..., 2] == fr[..., 0]).all() and (out[..., 3] == 255).all()
+
+
+def test_app_with_model_fused_equals_unfused(ctx, blob50):
+    """ProcessingApp with a model: the fused route == Scale/Model/ColorCode chained as in app.rs:112-123."""
+    frames = [W.synth_frame(96, 160, index=i) for i in range(3)]
+    clip = b"".join(f.tobytes() for f in frames)
+    masks = {}
+    for fused in (True, False):
+        a = ProcessingApp(ctx, fused=fused)
+        a.control(AppCmd.Model(ModelCmd.LoadBlob(blob50)))
+        assert a.info().model_info.output_names == ["out", "aux"]
+        a.control(AppCmd.Video(VideoCmd.Play(RawVideoSource(io.BytesIO(clip), 160, 96))))
+        a.control(AppCmd.Scale(0.5))
+        out = []
+        for _ in range(3):
+            g = a.generate()
+            assert g.size == [80, 48] and g.decoded_buffer.shape == (48, 80, 4)
+            out.append((g.id, g.buffer.copy(), g.decoded_buffer.copy()))
+        masks[fused] = out
+    for (i0, b0, m0), (i1, b1, m1) in zip(masks[True], masks[False]):
+        assert i0 == i1 and (b0 == b1).all() and (m0 == m1).all()
+    assert [m[0] for m in masks[True]] == [1, 2, 3]
+
+
+def test_streaming_equals_direct(ctx, model):
+    """BASELINE configs[2] in miniature: frames pushed through the depth-2 ring come back in
+    order and identical to the synchronous path; back-pressure when the ring is full."""
+    frames = [(i + 1, W.synth_frame(135, 240, index=i)) for i in range(7)]
+    sp = StreamPath(ctx, depth=2)
+    got = list(sp.run(frames, 0.5))
+    assert [g[0] for g in got] == [f[0] for f in frames]
+    fp = FramePath(ctx)
+    for (fid, rgba), (_, img) in zip(got, frames):
+        ref, _ = fp.advance(img, 0.5)
+        assert rgba.shape == (67, 120, 4) and (rgba == ref).all(), fid
+    # explicit back-pressure: a third submit without collecting is refused
+    sp.submit(frames[0][1], 0.5, 100)
+    sp.submit(frames[1][1], 0.5, 101)
+    assert sp.pending() == 2
+    with pytest.raises(InfurError) as e:
+        sp.submit(frames[2][1], 0.5, 102)
+    assert e.value.code == _lib.E_CAPACITY
+    fid, rgba, scaled = sp.collect(want_scaled=True)
+    assert fid == 100 and scaled.shape == (67, 120, 3)
+    assert sp.collect()[0] == 101 and sp.pending() == 0
+    with pytest.raises(InfurError):
+        sp.collect()
+    sp.close()
+
+
+def test_streaming_full_size_throughput(ctx, model):
+    """configs[2]: 1080p frames, scale 0.5, streamed from host memory; report frames/s incl. PCIe."""
+    import time
+
+    n = 24
+    frames = [(i, W.synth_frame(1080, 1920, index=i % 4)) for i in range(n)]
+    sp = StreamPath(ctx, depth=3)
+    list(sp.run(frames[:4], 0.5))  # warm-up: allocations
+    t0 = time.perf_counter()
+    out = list(sp.run(frames, 0.5))
+    el = time.perf_counter() - t0
+    assert len(out) == n and out[0][1].shape == (540, 960, 4)
+    print(f"streamed 1080p->960x540: {n / el:.1f} frames/s from host buffers (PCIe inclusive)")
+    assert n / el > 30.0  # the 30 fps stream of configs[2] is sustained
+    sp.close()
