@@ -127,6 +127,13 @@ int32_t infur_scale_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t 
 /* ModelCmd::Load(path) (predict_onnx.rs:288-312): empty path unloads.  The file is an
  * INFURW01 weight blob (infur_amd/weights.py). */
 int32_t infur_model_load(infur_ctx* ctx, const char* path);
+/* Host-only converter behind infur_model_load's .onnx support (no context, no GPU): parses an
+ * ONNX ModelProto (float FCN-ResNet50/101 as exported by torchvision, BN folded or not) with the
+ * reference's input checks (predict_onnx.rs:223-265) and returns a malloc'ed INFURW01 blob;
+ * release it with infur_buffer_free.  err (optional, errcap bytes) receives the message. */
+int32_t infur_onnx_to_blob(const void* onnx, size_t len, void** blob, size_t* blob_len, char* err,
+                           size_t errcap);
+void infur_buffer_free(void* p);
 int32_t infur_model_load_blob(infur_ctx* ctx, const void* blob, size_t len);
 /* blob already resident on this context's device (e.g. after an RCCL broadcast) */
 int32_t infur_model_load_blob_dev(infur_ctx* ctx, const void* d_blob, size_t len);

@@ -86,6 +86,8 @@ SIGNATURES = {
     "infur_scale": (C.c_int32, [_vp, _vp, _u32, _u32, _f, _u32, _vp, _sz, _u32p, _u32p]),
     "infur_scale_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _f, _u32, _vp, _sz, _u32p, _u32p]),
     "infur_model_load": (C.c_int32, [_vp, C.c_char_p]),
+    "infur_onnx_to_blob": (C.c_int32, [_vp, _sz, C.POINTER(_vp), C.POINTER(_sz), C.c_char_p, _sz]),
+    "infur_buffer_free": (None, [_vp]),
     "infur_model_load_blob": (C.c_int32, [_vp, _vp, _sz]),
     "infur_model_load_blob_dev": (C.c_int32, [_vp, _vp, _sz]),
     "infur_model_unload": (C.c_int32, [_vp]),

@@ -17,11 +17,13 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "kernels.h"
+#include "onnx_reader.h"
 
 using namespace infur;
 
@@ -728,8 +730,44 @@ int32_t infur_model_load(infur_ctx* c, const char* path) {
     fclose(f);
     if (got != buf.size()) return fail(c, INFUR_E_IO, "short read on '%s'", path);
     if (buf.empty()) return fail(c, INFUR_E_MODEL_FORMAT, "model file '%s' is empty", path);
-    return infur_model_load_blob(c, buf.data(), buf.size());
+    if (buf.size() >= 8 && memcmp(buf.data(), "INFURW01", 8) == 0) return infur_model_load_blob(c, buf.data(), buf.size());
+    if (looks_like_onnx(buf.data(), buf.size())) {
+        std::vector<uint8_t> blob;
+        OnnxInfo oi;
+        std::string err;
+        if (onnx_to_blob(buf.data(), buf.size(), blob, oi, err) != 0)
+            return fail(c, INFUR_E_MODEL_FORMAT, "couldn't infer image input / load '%s': %s", path, err.c_str());
+        int32_t rc = infur_model_load_blob(c, blob.data(), blob.size());
+        if (rc == INFUR_OK) {  // report the file's own tensor names (predict_onnx.rs:89-92)
+            snprintf(c->info.input_name, sizeof c->info.input_name, "%s", oi.input_name.c_str());
+            for (size_t i = 0; i < oi.output_names.size() && i < 2; i++)
+                snprintf(c->info.output_names[i], 32, "%s", oi.output_names[i].c_str());
+        }
+        return rc;
+    }
+    return fail(c, INFUR_E_MODEL_FORMAT, "'%s' is neither an INFURW01 blob nor an ONNX model", path);
 }
+
+int32_t infur_onnx_to_blob(const void* onnx, size_t len, void** blob, size_t* blob_len, char* err, size_t errcap) {
+    if (!onnx || !blob || !blob_len) return INFUR_E_INVALID_ARG;
+    *blob = nullptr;
+    *blob_len = 0;
+    std::vector<uint8_t> out;
+    OnnxInfo oi;
+    std::string e;
+    if (onnx_to_blob((const uint8_t*)onnx, len, out, oi, e) != 0) {
+        if (err && errcap) snprintf(err, errcap, "%s", e.c_str());
+        return INFUR_E_MODEL_FORMAT;
+    }
+    void* p = malloc(out.size());
+    if (!p) return INFUR_E_INVALID_ARG;
+    memcpy(p, out.data(), out.size());
+    *blob = p;
+    *blob_len = out.size();
+    return INFUR_OK;
+}
+
+void infur_buffer_free(void* p) { free(p); }
 
 int32_t infur_model_info_get(const infur_ctx* c, infur_model_info* info) {
     if (!c || !info) return INFUR_E_INVALID_ARG;

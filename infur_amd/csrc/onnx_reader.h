@@ -1,0 +1,22 @@
+// Minimal ONNX (protobuf wire format) reader for FCN-ResNet model files -> INFURW01 blob.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace infur {
+
+struct OnnxInfo {
+    std::string input_name, input_dtype;
+    std::vector<std::string> output_names;
+    int depth = 0, num_classes = 0;
+    bool aux = false;
+};
+
+bool looks_like_onnx(const uint8_t* data, size_t len);
+// 0 = ok; 1 = malformed / unsupported file; 2 = parsed but not a model this path can run
+// (input-layout errors carry the reference's messages, predict_onnx.rs:228-262)
+int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, OnnxInfo& info, std::string& err);
+
+}  // namespace infur

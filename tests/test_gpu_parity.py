@@ -387,3 +387,36 @@ def test_device_resident_entry_points(ctx, model, oracle):
     with pytest.raises(InfurError) as e:
         FramePath(ctx).advance_dev(d_in.data_ptr(), 160, 120, 0.5, d_rgba.data_ptr(), 100)
     assert e.value.code == _lib.E_CAPACITY
+
+
+def test_model_load_from_onnx_file(blob50, tmp_path, oracle_model):
+    """ModelCmd::Load("*.onnx"): logits identical to loading the same weights as a blob, and the
+    file's own tensor names are reported (predict_onnx.rs:89-92, "input -> out,aux")."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import onnx_writer as OW
+
+    _, tensors = W.unpack_blob(blob50)
+    model_bytes, _ = OW.fcn_model(tensors, W.graph(50))
+    p = tmp_path / "fcn-resnet50-12.onnx"
+    p.write_bytes(model_bytes)
+    c2 = Context(device=0)
+    m = Model(c2).control(ModelCmd.Load(str(p)))
+    info = m.get_info()
+    assert info.input_names == ["input"] and info.output_names == ["out", "aux"] and info.depth == 50
+    fr = W.synth_frame(48, 64)
+    out = []
+    m.advance(fr, out)
+    lo, la = m.lowres()
+    m.control(ModelCmd.LoadBlob(blob50))
+    m.advance(fr, out)
+    lo2, la2 = m.lowres()
+    assert (lo.view(np.uint32) == lo2.view(np.uint32)).all() and (la.view(np.uint32) == la2.view(np.uint32)).all()
+    bad = tmp_path / "int8.onnx"
+    bad.write_bytes(OW.fcn_model(tensors, W.graph(50), conv_op="QLinearConv")[0])
+    with pytest.raises(ModelCmdError) as e:
+        m.control(ModelCmd.Load(str(bad)))
+    assert e.value.code == _lib.E_MODEL_FORMAT and "quantised" in str(e.value)
+    c2.close()
