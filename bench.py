@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -42,6 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU baseline budget")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="conv-stack arithmetic: f32 (BASELINE configs[1], the default and the parity mode) or f16 "
+                         "operands with f32 accumulation (configs[4]'s mode)")
+    ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="backbone: FCN-ResNet50 (default) / 101")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
                          "multi-process path on a box with fewer GPUs than ranks)")
@@ -119,10 +124,10 @@ def main():
             dist.init_process_group("gloo")
 
     stream = torch.cuda.Stream()
-    ctx = Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=stream.cuda_stream)
+    ctx = Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=stream.cuda_stream, dtype=a.dtype)
 
     # ---- weights: rank 0 synthesises, RCCL broadcast over xGMI, every rank repacks locally ----
-    blob = W.synth_blob() if rank == 0 else None
+    blob = W.synth_blob(depth=a.depth) if rank == 0 else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -170,10 +175,10 @@ def main():
         "metric": "1080p frames/sec FCN-ResNet50-12 @1/2/4/8 MI355X; %MFMA roofline",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {
-            "workload": f"{Wd}x{H} packed-BGR frame, FCN-ResNet50 f32 (aux head {'off' if a.no_aux else 'on'}), "
-                        f"scale={a.scale}" + (" [BASELINE configs[1]]" if (Wd, H, a.scale) == (1920, 1080, 1.0) else ""),
+            "workload": f"{Wd}x{H} packed-BGR frame, FCN-ResNet{a.depth} {a.dtype} (aux head {'off' if a.no_aux else 'on'}), "
+                        f"scale={a.scale}" + (" [BASELINE configs[1]]" if (Wd, H, a.scale, a.dtype, a.depth) == (1920, 1080, 1.0, "f32", 50) else ""),
             "frames_per_step_per_gpu": B, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if world > 1 else None,
             "weights": f"synthetic seed {W.DEFAULT_SEED:#x}, {nbytes / 1e6:.1f} MB blob",
             "weights_load_ms": round(load_ms, 2), "ms_per_frame_per_gpu": elapsed / (a.steps * B) * 1e3,
@@ -182,12 +187,13 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel family from the HIP events of the last timed frame ----
-        flops = W.conv_flops(rc_h, rc_w, aux=not a.no_aux)
+        flops = W.conv_flops(rc_h, rc_w, depth=a.depth, aux=not a.no_aux)
         if not a.no_profile:
             recs = ctx.profile()
-            k3 = {c.name for c in W.graph(50) if c.k == 3}
-            conv = [r for r in recs if r["kernel"].startswith("conv_igemm_f32")]
-            dom = [r for r in conv if r["kernel"] == "conv_igemm_f32<128,128>"]
+            k3 = {c.name for c in W.graph(a.depth) if c.k == 3}
+            peak = PEAK_F32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_F16_MFMA_TFLOPS
+            conv = [r for r in recs if r["kernel"].startswith("conv_igemm_")]
+            dom = [r for r in conv if r["kernel"] == f"conv_igemm_{a.dtype}<128,128>"]
             c3 = [r for r in conv if r["name"] in k3]
             c1 = [r for r in conv if r["name"] not in k3]
             tf = lambda rs: sum(r["flops"] for r in rs) / max(sum(r["ms"] for r in rs), 1e-9) / 1e9  # noqa: E731
@@ -195,20 +201,20 @@ def main():
             traffic = None
             tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tj) and (Wd, H, a.scale) == (1920, 1080, 1.0):
-                t = json.load(open(tj))["kernels"].get("conv_igemm_f32_kernel<128, 128, 2, 2>")
+                t = json.load(open(tj))["kernels"].get("conv_igemm_kernel<float, float, 128, 128, 2, 2>") if a.dtype == "f32" and a.depth == 50 else None
                 if t:
                     traffic = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_f32_kernel<128,128,2,2> (48 of the 56 conv launches of a frame)",
-                "achieved": tf(dom), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf(dom) / PEAK_F32_MFMA_TFLOPS,
+                "bound": "mfma", "kernel": f"conv_igemm_kernel<{a.dtype}, 128,128,2,2> ({len(dom)} of the {len(conv)} conv launches of a frame)",
+                "achieved": tf(dom), "peak": peak, "unit": "TFLOP/s", "frac": tf(dom) / peak,
                 "traffic": traffic, "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes "
                                                     "(profiles/traffic_latest.json); null if not collected for this shape",
                 "launches": len(dom), "avg_launch_ms": sum(r["ms"] for r in dom) / max(len(dom), 1),
                 "flops_per_launch": sum(r["flops"] for r in dom) / max(len(dom), 1),
                 "algorithmic_bytes_per_launch": sum(r["bytes"] for r in dom) / max(len(dom), 1),
-                "all_convs": {"achieved": tf(conv), "frac": tf(conv) / PEAK_F32_MFMA_TFLOPS, "ms": sum(r["ms"] for r in conv)},
-                "conv3x3": {"achieved": tf(c3), "frac": tf(c3) / PEAK_F32_MFMA_TFLOPS, "ms": sum(r["ms"] for r in c3)},
-                "conv1x1": {"achieved": tf(c1), "frac": tf(c1) / PEAK_F32_MFMA_TFLOPS, "ms": sum(r["ms"] for r in c1)},
+                "all_convs": {"achieved": tf(conv), "frac": tf(conv) / peak, "ms": sum(r["ms"] for r in conv)},
+                "conv3x3": {"achieved": tf(c3), "frac": tf(c3) / peak, "ms": sum(r["ms"] for r in c3)},
+                "conv1x1": {"achieved": tf(c1), "frac": tf(c1) / peak, "ms": sum(r["ms"] for r in c1)},
                 "frame_kernel_ms": ms_all,
                 "other_kernels": {r["kernel"]: {"ms": r["ms"], "GB/s": r["bytes"] / max(r["ms"], 1e-9) / 1e6,
                                                 "frac_hbm": r["bytes"] / max(r["ms"], 1e-9) / 1e6 / PEAK_HBM_GBS}

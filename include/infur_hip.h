@@ -60,7 +60,9 @@ enum {
 
 /* arithmetic type of the conv stack */
 enum {
-    INFUR_DTYPE_F32 = 0 /* exact f32 MFMA (v_mfma_f32_32x32x2_f32) */
+    INFUR_DTYPE_F32 = 0, /* exact f32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode */
+    INFUR_DTYPE_F16 = 1  /* f16 activations/weights on v_mfma_f32_32x32x16_f16, f32 accumulation,
+                            bias/residual/ReLU in f32, logits f32 (BASELINE configs[4]) */
 };
 
 typedef struct infur_ctx infur_ctx;

@@ -27,6 +27,7 @@ E_CAPACITY = 11
 
 SCALE_NEAREST, SCALE_BILINEAR = 0, 1
 DTYPE_F32 = 0
+DTYPE_F16 = 1
 
 
 class Options(C.Structure):

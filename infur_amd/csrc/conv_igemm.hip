@@ -1,5 +1,8 @@
-// conv_igemm.hip -- convolution as an im2col-free implicit GEMM on the gfx950 f32 matrix
-// core (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain).
+// conv_igemm.hip -- convolution as an im2col-free implicit GEMM on the gfx950 matrix cores:
+// f32 operands on v_mfma_f32_32x32x2_f32 (exact f32, bitwise an fmaf chain) or f16 operands
+// on v_mfma_f32_32x32x16_f16 (f32 accumulation).  One kernel source: both instructions take a
+// lane's k-slice as one 16-byte register group (4 f32 / 8 f16), so tiles, staging and LDS
+// image are described in BYTES of k.
 //
 // Replaces the Conv nodes ONNX Runtime executes inside `session.run`
 // (infur/src/predict_onnx.rs:138) for every 1x1 and 3x3 convolution of FCN-ResNet
@@ -9,14 +12,13 @@
 //   A[m][k]  = in[(oy*s - p + ky*d), (ox*s - p + kx*d), c]   NHWC, gathered, zero padded
 //   B[n][k]  = wt[n][ky][kx][c]                               OHWI, k contiguous
 //
-// Tiling: BM x BN x 32 per workgroup, one wave per SIMD, each wave TM x TN tiles of 32x32.
-// Operands are staged global -> VGPR -> LDS (row stride 36 floats: ds_write_b128 and
+// Tiling: BM x BN x 128 bytes of k per workgroup, one wave per SIMD, each wave TM x TN tiles of
+// 32x32.  Operands are staged global -> VGPR -> LDS (row stride 144 bytes: ds_write_b128 and
 // ds_read_b128 both conflict-free) with two LDS buffers and one barrier per K step; global
 // loads run two K steps ahead and LDS fragment reads one slice ahead of the MFMAs.
 // A lane reads 4 consecutive k of its row with one ds_read_b128 (lanes 0-31: k 0-3,
 // lanes 32-63: k 4-7 of an 8-wide slice) and feeds them to 4 MFMAs; A and B use the same
 // permutation of k, so the sum is complete.
-#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -24,29 +26,39 @@
 namespace infur {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = BK + 4;  // floats
-
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// One K step covers ROW_BYTES of every operand row: 32 f32 or 64 f16 channels.  LDS rows are
+// padded to 144 B: ds_write_b128 (8-lane groups) and ds_read_b128 (16-lane groups) are then
+// both conflict-free.
+constexpr int ROW_BYTES = 128;
+constexpr int LDS_ROW = ROW_BYTES + 16;
 
 // voffset that is out of range for every tensor this kernel accepts (< 2 GiB): the buffer
 // load then returns zeros -- branch-free zero padding / tail predication.
 constexpr unsigned OOB = 0x80000000u;
 
-template <int BM, int BN, int WM, int WN>
+// T = operand type (float: v_mfma_f32_32x32x2_f32, exact f32; _Float16: v_mfma_f32_32x32x16_f16
+// with f32 accumulation), OutT = type of the stored activation (f32 for the classifier logits).
+template <typename T, typename OutT, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
-    conv_igemm_f32_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
-    constexpr int T = WM * WN * 64;
+    conv_igemm_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
+    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr int ES = sizeof(T);              // operand element size
+    constexpr int BK = ROW_BYTES / ES;         // channels per K step
+    constexpr int NSL = 4;                     // slices per K step (32 bytes of k each)
+    constexpr int NT = WM * WN * 64;           // threads
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int A_IT = BM * 8 / T;  // float4 per thread per K step
-    constexpr int B_IT = BN * 8 / T;
-    static_assert(BM * 8 % T == 0 && BN * 8 % T == 0, "tile/threads mismatch");
+    constexpr int A_IT = BM * 8 / NT;  // 16-byte chunks per thread per K step
+    constexpr int B_IT = BN * 8 / NT;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                        // [2][BM][LDS_STRIDE]
-    float* Bs = smem + 2 * BM * LDS_STRIDE;  // [2][BN][LDS_STRIDE]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                     // [2][BM][LDS_ROW]
+    char* Bs = smem + 2 * BM * LDS_ROW;  // [2][BN][LDS_ROW]
 
     // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of
     // tiles (n fastest) so the N-tiles that share an activation tile share one L2.
@@ -72,16 +84,16 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // Buffer descriptors: hardware bounds checking turns an out-of-range offset into a
     // zero result, so padding taps and ragged tiles need no branches in the K loop.
     const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.in), 0, (unsigned)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+        const_cast<void*>(a.in), 0, (unsigned)((size_t)a.H * a.W * a.Cin * ES), 0x00020000);
     const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.wt), 0, (unsigned)((size_t)a.Cout * Ktot * 4), 0x00020000);
+        const_cast<void*>(a.wt), 0, (unsigned)((size_t)a.Cout * Ktot * ES), 0x00020000);
 
     // per-thread gather coordinates of the A rows it stages
     int a_iy0[A_IT], a_ix0[A_IT];
-    const int c4 = tid & 7;  // which float4 of the 32-channel slice
+    const int c4 = tid & 7;  // which 16-byte chunk of the 128-byte channel slice
 #pragma unroll
     for (int i = 0; i < A_IT; i++) {
-        const int row = (tid >> 3) + i * (T / 8);
+        const int row = (tid >> 3) + i * (NT / 8);
         const int m = m0 + row;
         const int oy = m / a.OW, ox = m - oy * a.OW;
         // rows past M get coordinates that fail the bounds test for every tap
@@ -91,9 +103,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     unsigned b_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; i++) {
-        const int row = (tid >> 3) + i * (T / 8);
+        const int row = (tid >> 3) + i * (NT / 8);
         const int n = n0 + row;
-        b_off[i] = n < a.Cout ? (unsigned)n * (unsigned)Ktot * 4u + c4 * 16u : OOB;
+        b_off[i] = n < a.Cout ? (unsigned)n * (unsigned)(Ktot * ES) + c4 * 16u : OOB;
     }
 
     f32x16 acc[TM][TN];
@@ -105,18 +117,18 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
     u32x4 ra[A_IT], rb[B_IT];
-    const int cchunks = a.Cin / BK;
+    const int cchunks = a.Cin / BK;  // K steps per filter tap
     const int ksteps = a.KH * a.KW * cchunks;
     int ky = 0, kx = 0, cc = 0;  // coordinates of the K step being LOADED
 
     auto load_a = [&]() {
         const int dy = ky * a.dil, dx = kx * a.dil;
-        const unsigned coff = (unsigned)(cc * BK + c4 * 4) * 4u;
+        const unsigned coff = (unsigned)(cc * ROW_BYTES + c4 * 16);
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
             const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned off = (unsigned)(iy * a.W + ix) * (unsigned)(a.Cin * 4) + coff;
+            const unsigned off = (unsigned)(iy * a.W + ix) * (unsigned)(a.Cin * ES) + coff;
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
         }
         // advance (ky,kx,cc) to the next K step, branch-free (all wave-uniform scalars)
@@ -129,7 +141,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         ky += w2;
     };
     auto load_b = [&](int ks) {
-        const unsigned koff = (unsigned)ks * (BK * 4u);
+        const unsigned koff = (unsigned)ks * (unsigned)ROW_BYTES;
 #pragma unroll
         for (int i = 0; i < B_IT; i++)
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, b_off[i] == OOB ? OOB : b_off[i] + koff, 0, 0);
@@ -139,19 +151,19 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         load_b(ks);
     };
     auto store_a = [&](int buf) {
-        float* Ab = As + buf * BM * LDS_STRIDE;
+        char* Ab = As + buf * BM * LDS_ROW;
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
-            const int row = (tid >> 3) + i * (T / 8);
-            *reinterpret_cast<u32x4*>(Ab + row * LDS_STRIDE + c4 * 4) = ra[i];
+            const int row = (tid >> 3) + i * (NT / 8);
+            *reinterpret_cast<u32x4*>(Ab + row * LDS_ROW + c4 * 16) = ra[i];
         }
     };
     auto store_b = [&](int buf) {
-        float* Bb = Bs + buf * BN * LDS_STRIDE;
+        char* Bb = Bs + buf * BN * LDS_ROW;
 #pragma unroll
         for (int i = 0; i < B_IT; i++) {
-            const int row = (tid >> 3) + i * (T / 8);
-            *reinterpret_cast<u32x4*>(Bb + row * LDS_STRIDE + c4 * 4) = rb[i];
+            const int row = (tid >> 3) + i * (NT / 8);
+            *reinterpret_cast<u32x4*>(Bb + row * LDS_ROW + c4 * 16) = rb[i];
         }
     };
     auto store_step = [&](int buf) {
@@ -159,25 +171,26 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         store_b(buf);
     };
 
-    // LDS -> register fragments for one 8-wide k slice of buffer `buf`
-    const int a_lds = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
-    const int b_lds = (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    // LDS -> register fragments for one 32-byte k slice of buffer `buf`: lanes 0-31 take the
+    // first 16 bytes (4 f32 / 8 f16 consecutive k), lanes 32-63 the second
+    const int a_lds = (wm * TM * 32 + (lane & 31)) * LDS_ROW + (lane >> 5) * 16;
+    const int b_lds = (wn * TN * 32 + (lane & 31)) * LDS_ROW + (lane >> 5) * 16;
     auto read_frags = [&](int buf, int kk, float4 (&fa)[TM], float4 (&fb)[TN]) {
-        const float* Ab = As + buf * BM * LDS_STRIDE + a_lds + kk * 8;
-        const float* Bb = Bs + buf * BN * LDS_STRIDE + b_lds + kk * 8;
+        const char* Ab = As + buf * BM * LDS_ROW + a_lds + kk * 32;
+        const char* Bb = Bs + buf * BN * LDS_ROW + b_lds + kk * 32;
 #pragma unroll
-        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE);
+        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW);
 #pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE);
+        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW);
     };
 
     float4 fa[TM], fb[TN], fa_n[TM], fb_n[TN];
 
-    // One K step = 4 slices of 8 k.  Software pipeline with ONE barrier per K step, placed
+    // One K step = 4 slices of 32 bytes of k.  Software pipeline with ONE barrier per K step, placed
     // mid-step, and no control flow inside a step, so the scheduler can hide the staging
     // (buffer loads, LDS writes, address arithmetic) in the shadow of the 64-cycle MFMAs:
     //   every slice : the fragments of the next slice (slice 0 of the OTHER buffer after
-    //                 slice 3) are read while the 16 MFMAs of this slice issue;
+    //                 slice 3) are read while the MFMAs of this slice (16 f32 / 4 f16) issue;
     //   slice 0 / 1 : registers holding K step ks+1 (activations / weights) -> other LDS
     //                 buffer; then the global loads of K step ks+2 go into the same registers;
     //   slice 2     : s_barrier.  The other buffer is complete before slice 3 reads it, and
@@ -187,8 +200,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     auto k_step = [&](int ks, auto STORE, auto LOAD, auto NEXT) {
         const int buf = ks & 1;
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; kk++) {
-            if (kk < BK / 8 - 1)
+        for (int kk = 0; kk < NSL; kk++) {
+            if (kk < NSL - 1)
                 read_frags(buf, kk + 1, fa_n, fb_n);
             else if (NEXT)
                 read_frags(buf ^ 1, 0, fa_n, fb_n);
@@ -197,10 +210,15 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
                     // D rows = output channels, D cols = pixels (operands swapped on purpose)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
+                    if constexpr (F32) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
+                                                                         __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
+                    }
                 }
             // staging spread over two slices: activations at slice 0, weights at slice 1
             if (kk == 0 && STORE) {
@@ -215,7 +233,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             // work between two MFMAs (a cluster longer than the 64-cycle MFMA shadow is a
             // bubble in this wave's MFMA stream).  Measured +2-3 % on the 3x3 convs.
             // masks: VALU 0x2, MFMA 0x8, VMEM read 0x20, DS read 0x100, DS write 0x200
-            if (kk <= 1 && STORE) {
+            if (!F32) {
+                // f16: 4 MFMAs of 32 cycles per slice -- the staging cannot hide in their shadow;
+                // leave the order to the compiler
+            } else if (kk <= 1 && STORE) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -264,7 +285,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // epilogue: + bias, + residual, ReLU.  The MFMA was issued with the weight fragment as the
     // row operand, so in the 32x32 C/D layout (col = lane & 31, row = (e & 3) + 8 * (e >> 2) +
     // 4 * (lane >> 5)) a lane owns ONE pixel (col) and, per group g = e >> 2, FOUR consecutive
-    // output channels: NHWC stores, residual loads and bias loads are all 16 bytes wide.
+    // output channels: NHWC stores, residual loads and bias loads are 16 (f32) / 8 (f16) bytes wide.
+    const T* res = static_cast<const T*>(a.res);
+    OutT* out = static_cast<OutT*>(a.out);
     const bool vec_ok = (a.Cout & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
@@ -281,22 +304,32 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 if (vec_ok) {
                     const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                    if (a.res) {
-                        const float4 rv = *reinterpret_cast<const float4*>(a.res + o);
-                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    if (res) {
+                        if constexpr (F32) {
+                            const float4 rv = *reinterpret_cast<const float4*>(res + o);
+                            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                        } else {
+                            const f16x4 rv = *reinterpret_cast<const f16x4*>(res + o);
+                            v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
+                        }
                     }
                     if (a.relu) {
                         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                     }
-                    *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (std::is_same<OutT, float>::value) {
+                        *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        *reinterpret_cast<f16x4*>(out + o) = hv;
+                    }
                 } else {
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         if (n + t >= a.Cout) break;
                         float x = v[t] + a.bias[n + t];
-                        if (a.res) x += a.res[o + t];
+                        if (res) x += (float)res[o + t];
                         if (a.relu) x = fmaxf(x, 0.f);
-                        a.out[o + t] = x;
+                        out[o + t] = (OutT)x;
                     }
                 }
             }
@@ -304,14 +337,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM;
     const int ntiles = (a.Cout + BN - 1) / BN;
-    size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-    if (const char* e = getenv("INFUR_EXP_LDS_PAD")) lds += (size_t)atoi(e);  // occupancy experiment only
-    auto k = conv_igemm_f32_kernel<BM, BN, WM, WN>;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_ROW;
+    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -323,20 +355,27 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s) {
-    if (a.Cin % BK != 0) return hipErrorInvalidValue;
+template <typename T, typename OutT>
+static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t ES = sizeof(T);
+    if (a.Cin % (int)(ROW_BYTES / ES) != 0) return hipErrorInvalidValue;
     // 32-bit buffer offsets with 0x80000000 as the out-of-range marker
-    if ((size_t)a.H * a.W * a.Cin * 4 >= 0x80000000ull || (size_t)a.Cout * a.KH * a.KW * a.Cin * 4 >= 0x80000000ull)
+    if ((size_t)a.H * a.W * a.Cin * ES >= 0x80000000ull || (size_t)a.Cout * a.KH * a.KW * a.Cin * ES >= 0x80000000ull)
         return hipErrorInvalidValue;
-    if (a.Cout >= 128) return launch_cfg<128, 128, 2, 2>(a, s);
-    if (a.Cout > 32) return launch_cfg<128, 64, 2, 2>(a, s);
-    return launch_cfg<256, 32, 4, 1>(a, s);
+    if (a.Cout >= 128) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
+    if (a.Cout > 32) return launch_cfg<T, OutT, 128, 64, 2, 2>(a, s);
+    return launch_cfg<T, OutT, 256, 32, 4, 1>(a, s);
 }
 
-const char* conv_igemm_f32_config(const ConvArgs& a) {
-    if (a.Cout >= 128) return "conv_igemm_f32<128,128>";
-    if (a.Cout > 32) return "conv_igemm_f32<128,64>";
-    return "conv_igemm_f32<256,32>";
+hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, hipStream_t s) {
+    if (!f16) return launch_t<float, float>(a, s);
+    return out_f32 ? launch_t<_Float16, float>(a, s) : launch_t<_Float16, _Float16>(a, s);
+}
+
+const char* conv_igemm_config(const ConvArgs& a, int f16) {
+    if (a.Cout >= 128) return f16 ? "conv_igemm_f16<128,128>" : "conv_igemm_f32<128,128>";
+    if (a.Cout > 32) return f16 ? "conv_igemm_f16<128,64>" : "conv_igemm_f32<128,64>";
+    return f16 ? "conv_igemm_f16<256,32>" : "conv_igemm_f32<256,32>";
 }
 
 }  // namespace infur

@@ -35,11 +35,13 @@ struct Buf {
     bool used = false;
 };
 
-struct Tensor {  // NHWC f32 activation living in the pool
-    float* p = nullptr;
+struct Tensor {  // NHWC activation (f32 or f16) living in the pool
+    void* p = nullptr;
     int h = 0, w = 0, c = 0;
     int slot = -1;
-    size_t floats() const { return (size_t)h * w * c; }
+    int es = 4;  // element size: 4 = f32, 2 = f16
+    size_t elems() const { return (size_t)h * w * c; }
+    size_t bytes() const { return elems() * (size_t)es; }
 };
 
 struct ConvLayer {
@@ -47,8 +49,8 @@ struct ConvLayer {
     int cout = 0, cin = 0, k = 0, stride = 1, pad = 0, dil = 1;
     bool relu = false;
     char role = 0;        // s stem, 1 2 3 block convs, d downsample, h head3x3, c classifier
-    float* d_w = nullptr;  // repacked weights
-    float* d_b = nullptr;
+    void* d_w = nullptr;   // repacked weights (context dtype; the stem's stay f32)
+    float* d_b = nullptr;  // bias, always f32
 };
 
 struct ProfRec {
@@ -170,16 +172,20 @@ void pool_free(infur_ctx* c) {
     c->pool.clear();
 }
 
-int32_t talloc(infur_ctx* c, int h, int w, int ch, Tensor* t) {
+int32_t talloc(infur_ctx* c, int h, int w, int ch, int es, Tensor* t) {
     t->h = h;
     t->w = w;
     t->c = ch;
+    t->es = es;
     int slot;
-    RETIF(pool_acquire(c, t->floats() * sizeof(float), &slot));
+    RETIF(pool_acquire(c, t->bytes(), &slot));
     t->slot = slot;
-    t->p = (float*)c->pool[slot].p;
+    t->p = c->pool[slot].p;
     return INFUR_OK;
 }
+
+inline bool ctx_f16(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F16; }
+inline int act_es(const infur_ctx* c) { return ctx_f16(c) ? 2 : 4; }
 
 // ---- profiling ----
 struct ProfScope {
@@ -388,7 +394,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         const size_t wn = (size_t)L.cout * L.cin * L.k * L.k * 4, bn = (size_t)L.cout * 4;
         if (ents[i].w_off % 4 || ents[i].b_off % 4 || ents[i].w_off + wn > len || ents[i].b_off + bn > len)
             return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' data out of range", name);
-        total += align_up(wn, 256) + align_up(bn, 256);
+        total += align_up(wn, 256) + align_up(bn, 256);  // upper bound (f16 weights take half)
     }
 
     model_free(c);
@@ -403,11 +409,11 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         off += align_up(bn, 256);
         const float* src_w = (const float*)((const uint8_t*)d_blob + ents[i].w_off);
         if (L.role == 's')
-            HIPCHK(c, launch_repack_stem(src_w, L.d_w, c->stream));
-        else if (L.k == 1)
+            HIPCHK(c, launch_repack_stem(src_w, (float*)L.d_w, c->stream));
+        else if (L.k == 1 && !ctx_f16(c))
             HIPCHK(c, hipMemcpyAsync(L.d_w, src_w, wn, hipMemcpyDeviceToDevice, c->stream));  // OI11 == O11I
         else
-            HIPCHK(c, launch_repack_oihw_to_ohwi(src_w, L.d_w, L.cout, L.cin, L.k, L.k, c->stream));
+            HIPCHK(c, launch_repack_oihw_to_ohwi(src_w, L.d_w, ctx_f16(c) ? 1 : 0, L.cout, L.cin, L.k, L.k, c->stream));
         HIPCHK(c, hipMemcpyAsync(L.d_b, (const uint8_t*)d_blob + ents[i].b_off, bn, hipMemcpyDeviceToDevice, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -421,7 +427,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     memset(&mi, 0, sizeof mi);
     // names as the reference prints them: "input -> out,aux" (predict_onnx.rs:378-380)
     snprintf(mi.input_name, sizeof mi.input_name, "input");
-    snprintf(mi.input0_dtype, sizeof mi.input0_dtype, "Float");
+    snprintf(mi.input0_dtype, sizeof mi.input0_dtype, "Float");  // the model's declared input type (predict_onnx.rs:90)
     snprintf(mi.output_names[0], 32, "out");
     snprintf(mi.output_names[1], 32, "aux");
     mi.n_outputs = 2;
@@ -435,16 +441,19 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
 // ---- one convolution on the implicit-GEMM kernel ----
 int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, Tensor* out) {
     const int oh = conv_out(in.h, L.k, L.stride, L.pad, L.dil), ow = conv_out(in.w, L.k, L.stride, L.pad, L.dil);
-    RETIF(talloc(c, oh, ow, L.cout, out));
+    const int f16 = ctx_f16(c) ? 1 : 0;
+    const int out_f32 = (!f16 || L.role == 'c') ? 1 : 0;  // the logits leave the conv stack in f32
+    RETIF(talloc(c, oh, ow, L.cout, out_f32 ? 4 : 2, out));
     ConvArgs a;
     a.in = in.p; a.wt = L.d_w; a.bias = L.d_b; a.res = res ? res->p : nullptr; a.out = out->p;
     a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = L.cout;
     a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = L.relu ? 1 : 0;
     const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
-    const double bytes = 4.0 * ((double)in.floats() + (double)out->floats() * (res ? 2 : 1) + (double)L.cout * L.cin * L.k * L.k);
+    const double bytes = (double)in.bytes() + (double)out->bytes() + (res ? (double)res->bytes() : 0.0) +
+                         (double)L.cout * L.cin * L.k * L.k * in.es;
     {
-        ProfScope ps(c, L.name, conv_igemm_f32_config(a), flops, bytes);
-        HIPCHK(c, launch_conv_igemm_f32(a, c->stream));
+        ProfScope ps(c, L.name, conv_igemm_config(a, f16), flops, bytes);
+        HIPCHK(c, launch_conv_igemm(a, f16, out_f32, c->stream));
     }
     if (c->opt.keep_activations) c->kept.push_back(*out);
     return INFUR_OK;
@@ -461,16 +470,16 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     Tensor s, x;
     {
         const int oh = conv_out(h, 7, 2, 3, 1), ow = conv_out(w, 7, 2, 3, 1);
-        RETIF(talloc(c, oh, ow, 64, &s));
-        ProfScope ps(c, stem.name, "stem_conv7x7", 2.0 * oh * ow * 64 * 147, (double)h * w * 3 + 4.0 * s.floats());
-        HIPCHK(c, launch_stem_conv7x7(d_bgr, h, w, stem.d_w, stem.d_b, c->d_pre_lut, s.p, oh, ow, c->stream));
+        RETIF(talloc(c, oh, ow, 64, act_es(c), &s));
+        ProfScope ps(c, stem.name, "stem_conv7x7", 2.0 * oh * ow * 64 * 147, (double)h * w * 3 + (double)s.bytes());
+        HIPCHK(c, launch_stem_conv7x7(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, c->d_pre_lut, s.p, ctx_f16(c) ? 1 : 0, oh, ow, c->stream));
     }
     if (c->opt.keep_activations) c->kept.push_back(s);
     {
         const int oh = conv_out(s.h, 3, 2, 1, 1), ow = conv_out(s.w, 3, 2, 1, 1);
-        RETIF(talloc(c, oh, ow, 64, &x));
-        ProfScope ps(c, "backbone.maxpool", "maxpool3x3s2", 0, 4.0 * (s.floats() + x.floats()));
-        HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, x.p, oh, ow, c->stream));
+        RETIF(talloc(c, oh, ow, 64, act_es(c), &x));
+        ProfScope ps(c, "backbone.maxpool", "maxpool3x3s2", 0, (double)s.bytes() + (double)x.bytes());
+        HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, x.p, ctx_f16(c) ? 1 : 0, oh, ow, c->stream));
     }
     pool_release(c, s);
 
@@ -571,7 +580,7 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
         if (opts->struct_size != sizeof(infur_options)) return INFUR_E_INVALID_ARG;
         o = *opts;
     }
-    if (o.compute_dtype != INFUR_DTYPE_F32) return INFUR_E_INVALID_ARG;
+    if (o.compute_dtype != INFUR_DTYPE_F32 && o.compute_dtype != INFUR_DTYPE_F16) return INFUR_E_INVALID_ARG;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || o.device < 0 || o.device >= n) return INFUR_E_HIP;
     if (hipSetDevice(o.device) != hipSuccess) return INFUR_E_HIP;
@@ -796,15 +805,15 @@ int32_t infur_model_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uin
     if (w == 0 || h == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
     RETIF(forward(c, (const uint8_t*)d_bgr, (int)w, (int)h));
     const int K = c->num_classes;
-    const double up_bytes = 4.0 * ((double)c->out_low.floats() + (double)K * h * w);
+    const double up_bytes = (double)c->out_low.bytes() + 4.0 * (double)K * h * w;
     if (d_out) {
         ProfScope ps(c, "out.resize", "upsample_planar", 0, up_bytes);
-        HIPCHK(c, launch_upsample_planar(c->out_low.p, c->out_low.h, c->out_low.w, K, (float*)d_out, (int)h, (int)w, c->stream));
+        HIPCHK(c, launch_upsample_planar((const float*)c->out_low.p, c->out_low.h, c->out_low.w, K, (float*)d_out, (int)h, (int)w, c->stream));
     }
     if (d_aux) {
         if (!c->aux_low.p) return fail(c, INFUR_E_INVALID_ARG, "aux output requested but the aux head is disabled");
         ProfScope ps(c, "aux.resize", "upsample_planar", 0, up_bytes);
-        HIPCHK(c, launch_upsample_planar(c->aux_low.p, c->aux_low.h, c->aux_low.w, K, (float*)d_aux, (int)h, (int)w, c->stream));
+        HIPCHK(c, launch_upsample_planar((const float*)c->aux_low.p, c->aux_low.h, c->aux_low.w, K, (float*)d_aux, (int)h, (int)w, c->stream));
     }
     if (n_outputs) *n_outputs = 2;
     return INFUR_OK;
@@ -835,14 +844,14 @@ int32_t infur_model_read_lowres(infur_ctx* c, float* out_low, float* aux_low, ui
     const Tensor& t = c->out_low;
     if (lh) *lh = (uint32_t)t.h;
     if (lw) *lw = (uint32_t)t.w;
-    const size_t bytes = t.floats() * 4;
+    const size_t bytes = t.elems() * 4;
     RETIF(ensure(c, c->st_f32a, bytes));
     for (int i = 0; i < 2; i++) {
         float* dst = i == 0 ? out_low : aux_low;
         const Tensor& src = i == 0 ? c->out_low : c->aux_low;
         if (!dst) continue;
         if (!src.p) return fail(c, INFUR_E_INVALID_ARG, "aux output requested but the aux head is disabled");
-        HIPCHK(c, launch_nhwc_to_planar(src.p, src.h, src.w, src.c, (float*)c->st_f32a.p, c->stream));
+        HIPCHK(c, launch_nhwc_to_planar(src.p, src.es == 2, src.h, src.w, src.c, (float*)c->st_f32a.p, c->stream));
         HIPCHK(c, hipMemcpyAsync(dst, c->st_f32a.p, bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -858,10 +867,10 @@ int32_t infur_debug_read_activation(infur_ctx* c, uint32_t index, float* host, s
     if (ch) *ch = (uint32_t)t.c;
     if (h) *h = (uint32_t)t.h;
     if (w) *w = (uint32_t)t.w;
-    if (cap < t.floats()) return fail(c, INFUR_E_CAPACITY, "activation needs %zu floats", t.floats());
-    RETIF(ensure(c, c->st_f32a, t.floats() * 4));
-    HIPCHK(c, launch_nhwc_to_planar(t.p, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
-    HIPCHK(c, hipMemcpyAsync(host, c->st_f32a.p, t.floats() * 4, hipMemcpyDeviceToHost, c->stream));
+    if (cap < t.elems()) return fail(c, INFUR_E_CAPACITY, "activation needs %zu floats", t.elems());
+    RETIF(ensure(c, c->st_f32a, t.elems() * 4));
+    HIPCHK(c, launch_nhwc_to_planar(t.p, t.es == 2, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(host, c->st_f32a.p, t.elems() * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return INFUR_OK;
 }
@@ -971,8 +980,8 @@ int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uin
     c->prof.insert(c->prof.begin(), pre.begin(), pre.end());
     {
         const Tensor& t = c->out_low;  // only out[0] is decoded, app.rs:116
-        ProfScope ps(c, "out.resize+colorcode", "upsample_argmax_shade", 0, 4.0 * t.floats() + (double)need);
-        HIPCHK(c, launch_upsample_argmax_shade(t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)*oh, (int)*ow, c->stream));
+        ProfScope ps(c, "out.resize+colorcode", "upsample_argmax_shade", 0, (double)t.bytes() + (double)need);
+        HIPCHK(c, launch_upsample_argmax_shade((const float*)t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)*oh, (int)*ow, c->stream));
     }
     return INFUR_OK;
 }

@@ -6,36 +6,39 @@
 
 namespace infur {
 
-// NHWC f32 activations; weights OHWI ([Cout][KH][KW][Cin], K contiguous per output channel).
+// NHWC activations (f32 or f16); weights OHWI ([Cout][KH][KW][Cin], K contiguous per output
+// channel) in the same element type; bias always f32.
 struct ConvArgs {
-    const float* in;    // [H][W][Cin]
-    const float* wt;    // [Cout][KH*KW*Cin]
+    const void* in;     // [H][W][Cin]
+    const void* wt;     // [Cout][KH*KW*Cin]
     const float* bias;  // [Cout]
-    const float* res;   // optional residual, same shape as out
-    float* out;         // [OH][OW][Cout]
+    const void* res;    // optional residual, same shape and type as the input activations
+    void* out;          // [OH][OW][Cout]
     int H, W, Cin;
     int OH, OW, Cout;
     int KH, KW, stride, pad, dil;
     int relu;
 };
 
-// conv as implicit GEMM on v_mfma_f32_32x32x2_f32 (Cin % 32 == 0)
-hipError_t launch_conv_igemm_f32(const ConvArgs& a, hipStream_t s);
-// name of the tile configuration launch_conv_igemm_f32 picks for these arguments
-const char* conv_igemm_f32_config(const ConvArgs& a);
+// conv as implicit GEMM on the matrix cores.  f16 = 0: f32 operands (Cin % 32 == 0);
+// f16 = 1: f16 operands, f32 accumulation (Cin % 64 == 0), output f16 or (out_f32) f32.
+hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, hipStream_t s);
+// name of the tile configuration launch_conv_igemm picks for these arguments
+const char* conv_igemm_config(const ConvArgs& a, int f16);
 
 // stem: packed BGR u8 -> (LUT normalise, BGR->RGB) -> conv 7x7/2 pad 3 (3->64) + bias + ReLU,
-// NHWC f32 out.  wt: [7][7][3][64] (ky,kx,c,cout), lut: [3][256] in RGB order.
+// NHWC out (f32, or f16 when f16 != 0; the arithmetic is f32 either way).
+// wt: [7][7][3][64] (ky,kx,c,cout) f32, lut: [3][256] in RGB order.
 hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt,
-                               const float* bias, const float* lut, float* out, int OH, int OW,
+                               const float* bias, const float* lut, void* out, int f16, int OH, int OW,
                                hipStream_t s);
 
-// maxpool 3x3 stride 2 pad 1, NHWC f32 (C % 4 == 0)
-hipError_t launch_maxpool3x3s2(const float* in, int H, int W, int C, float* out, int OH, int OW,
+// maxpool 3x3 stride 2 pad 1, NHWC f32 / f16 (C % 4 == 0)
+hipError_t launch_maxpool3x3s2(const void* in, int H, int W, int C, void* out, int f16, int OH, int OW,
                                hipStream_t s);
 
-// OIHW -> OHWI weight repack (one-off at model load)
-hipError_t launch_repack_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW,
+// OIHW f32 -> OHWI f32 / f16 weight repack (one-off at model load)
+hipError_t launch_repack_oihw_to_ohwi(const float* src, void* dst, int f16, int O, int I, int KH, int KW,
                                       hipStream_t s);
 // OIHW (O=64,I=3,7x7) -> [ky][kx][c][o] for the stem kernel
 hipError_t launch_repack_stem(const float* src, float* dst, hipStream_t s);
@@ -51,8 +54,8 @@ hipError_t launch_pack_normalize(const uint8_t* bgr, int W, int H, const float* 
 // display conversion (app.rs:132-144): packed BGR -> [r,g,b,255]
 hipError_t launch_bgr_to_rgba(const uint8_t* bgr, int W, int H, uint32_t* rgba, hipStream_t s);
 
-// low-res NHWC logits [lh][lw][K] -> planar [K][lh][lw]
-hipError_t launch_nhwc_to_planar(const float* in, int H, int W, int C, float* out,
+// NHWC (f32 or f16) -> planar f32 [C][H][W] (low-res logits, debug activation read-back)
+hipError_t launch_nhwc_to_planar(const void* in, int f16, int H, int W, int C, float* out,
                                  hipStream_t s);
 
 // bilinear up-sample (ONNX Resize linear / pytorch_half_pixel) of NHWC low-res logits to

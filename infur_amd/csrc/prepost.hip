@@ -174,22 +174,26 @@ hipError_t launch_bgr_to_rgba(const uint8_t* bgr, int W, int H, uint32_t* rgba, 
 }
 
 // ---------------------------------------------------------------------------------------
-// low-res NHWC -> planar (tiny: 21 x 135 x 240 floats)
+// NHWC -> planar f32 (low-res logits: 21 x 135 x 240 floats; debug read-back of activations)
 // ---------------------------------------------------------------------------------------
-__global__ void nhwc_to_planar_kernel(const float* __restrict__ in, int HW, int C, float* __restrict__ out) {
+template <typename T>
+__global__ void nhwc_to_planar_kernel(const T* __restrict__ in, int HW, int C, float* __restrict__ out) {
     const size_t total = (size_t)HW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i / HW);
         const size_t p = i - (size_t)c * HW;
-        out[i] = in[p * C + c];
+        out[i] = (float)in[p * C + c];
     }
 }
 
-hipError_t launch_nhwc_to_planar(const float* in, int H, int W, int C, float* out, hipStream_t s) {
+hipError_t launch_nhwc_to_planar(const void* in, int f16, int H, int W, int C, float* out, hipStream_t s) {
     const size_t total = (size_t)H * W * C;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(nhwc_to_planar_kernel, dim3(blocks), dim3(256), 0, s, in, H * W, C, out);
+    if (f16)
+        hipLaunchKernelGGL(nhwc_to_planar_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)in, H * W, C, out);
+    else
+        hipLaunchKernelGGL(nhwc_to_planar_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)in, H * W, C, out);
     return hipGetLastError();
 }
 

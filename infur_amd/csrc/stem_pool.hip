@@ -11,6 +11,9 @@
 
 namespace infur {
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------------------
 // stem: one thread = one output pixel x 64 output channels (64 f32 accumulators);
 // weights are wave-uniform -> scalar loads; the normalised input patch lives in LDS.
@@ -20,12 +23,13 @@ constexpr int ST_TH = 8, ST_TW = 32;
 constexpr int ST_PH = 2 * ST_TH + 5;  // 21 input rows
 constexpr int ST_PW = 2 * ST_TW + 5;  // 69 input cols
 
+template <typename OutT>
 __global__ void __launch_bounds__(256)
     stem_conv7x7_kernel(const uint8_t* __restrict__ bgr, int H, int W,
                         const float* __restrict__ wt,    // [7][7][3][64]
                         const float* __restrict__ bias,  // [64]
                         const float* __restrict__ lut,   // [3][256] RGB order
-                        float* __restrict__ out, int OH, int OW) {
+                        OutT* __restrict__ out, int OH, int OW) {
     __shared__ float patch[ST_PH * ST_PW * 3];
     const int tid = threadIdx.x;
     const int oy0 = blockIdx.y * ST_TH, ox0 = blockIdx.x * ST_TW;
@@ -67,41 +71,56 @@ __global__ void __launch_bounds__(256)
 
     const int oy = oy0 + py, ox = ox0 + px;
     if (oy < OH && ox < OW) {
-        float4* o = reinterpret_cast<float4*>(out + ((size_t)oy * OW + ox) * 64);
+        if constexpr (sizeof(OutT) == 4) {
+            float4* o = reinterpret_cast<float4*>(out + ((size_t)oy * OW + ox) * 64);
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            float4 v;
-            v.x = fmaxf(acc[4 * c + 0] + bias[4 * c + 0], 0.f);
-            v.y = fmaxf(acc[4 * c + 1] + bias[4 * c + 1], 0.f);
-            v.z = fmaxf(acc[4 * c + 2] + bias[4 * c + 2], 0.f);
-            v.w = fmaxf(acc[4 * c + 3] + bias[4 * c + 3], 0.f);
-            o[c] = v;
+            for (int c = 0; c < 16; c++) {
+                float4 v;
+                v.x = fmaxf(acc[4 * c + 0] + bias[4 * c + 0], 0.f);
+                v.y = fmaxf(acc[4 * c + 1] + bias[4 * c + 1], 0.f);
+                v.z = fmaxf(acc[4 * c + 2] + bias[4 * c + 2], 0.f);
+                v.w = fmaxf(acc[4 * c + 3] + bias[4 * c + 3], 0.f);
+                o[c] = v;
+            }
+        } else {
+            f16x8* o = reinterpret_cast<f16x8*>(out + ((size_t)oy * OW + ox) * 64);
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                f16x8 v;
+#pragma unroll
+                for (int t = 0; t < 8; t++) v[t] = (_Float16)fmaxf(acc[8 * c + t] + bias[8 * c + t], 0.f);
+                o[c] = v;
+            }
         }
     }
 }
 
 hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt,
-                               const float* bias, const float* lut, float* out, int OH, int OW,
+                               const float* bias, const float* lut, void* out, int f16, int OH, int OW,
                                hipStream_t s) {
     dim3 grid((OW + ST_TW - 1) / ST_TW, (OH + ST_TH - 1) / ST_TH);
-    hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, out,
-                       OH, OW);
+    if (f16)
+        hipLaunchKernelGGL(stem_conv7x7_kernel<_Float16>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut,
+                           (_Float16*)out, OH, OW);
+    else
+        hipLaunchKernelGGL(stem_conv7x7_kernel<float>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut,
+                           (float*)out, OH, OW);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
 // maxpool 3x3 / 2, pad 1, NHWC: one thread = one output pixel x 4 channels
 // ---------------------------------------------------------------------------------------
+template <typename T, typename V4>
 __global__ void __launch_bounds__(256)
-    maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out,
-                        int OH, int OW) {
+    maxpool3x3s2_kernel(const T* __restrict__ in, int H, int W, int C, T* __restrict__ out, int OH, int OW) {
     const int c4n = C >> 2;
     const size_t total = (size_t)OH * OW * c4n;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c4 = (int)(i % c4n);
         const size_t p = i / c4n;
         const int ox = (int)(p % OW), oy = (int)(p / OW);
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
             const int iy = 2 * oy - 1 + ky;
@@ -110,31 +129,40 @@ __global__ void __launch_bounds__(256)
             for (int kx = 0; kx < 3; kx++) {
                 const int ix = 2 * ox - 1 + kx;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)iy * W + ix) * C + c4 * 4);
-                m.x = fmaxf(m.x, v.x);
-                m.y = fmaxf(m.y, v.y);
-                m.z = fmaxf(m.z, v.z);
-                m.w = fmaxf(m.w, v.w);
+                const V4 v = *reinterpret_cast<const V4*>(in + ((size_t)iy * W + ix) * C + c4 * 4);
+                m0 = fmaxf(m0, (float)v[0]);
+                m1 = fmaxf(m1, (float)v[1]);
+                m2 = fmaxf(m2, (float)v[2]);
+                m3 = fmaxf(m3, (float)v[3]);
             }
         }
-        *reinterpret_cast<float4*>(out + p * C + c4 * 4) = m;
+        V4 r = {(T)m0, (T)m1, (T)m2, (T)m3};
+        *reinterpret_cast<V4*>(out + p * C + c4 * 4) = r;
     }
 }
 
-hipError_t launch_maxpool3x3s2(const float* in, int H, int W, int C, float* out, int OH, int OW,
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+hipError_t launch_maxpool3x3s2(const void* in, int H, int W, int C, void* out, int f16, int OH, int OW,
                                hipStream_t s) {
     const size_t total = (size_t)OH * OW * (C / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, s, in, H, W, C, out, OH, OW);
+    if (f16)
+        hipLaunchKernelGGL((maxpool3x3s2_kernel<_Float16, f16x4>), dim3(blocks), dim3(256), 0, s, (const _Float16*)in, H, W, C,
+                           (_Float16*)out, OH, OW);
+    else
+        hipLaunchKernelGGL((maxpool3x3s2_kernel<float, f32x4v>), dim3(blocks), dim3(256), 0, s, (const float*)in, H, W, C,
+                           (float*)out, OH, OW);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
 // weight repacks
 // ---------------------------------------------------------------------------------------
-__global__ void repack_oihw_to_ohwi_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                           int O, int I, int KH, int KW) {
+template <typename T>
+__global__ void repack_oihw_to_ohwi_kernel(const float* __restrict__ src, T* __restrict__ dst, int O, int I, int KH,
+                                           int KW) {
     const size_t total = (size_t)O * I * KH * KW;
     for (size_t d = (size_t)blockIdx.x * 256 + threadIdx.x; d < total; d += (size_t)gridDim.x * 256) {
         // d indexes dst [o][ky][kx][i]
@@ -144,16 +172,19 @@ __global__ void repack_oihw_to_ohwi_kernel(const float* __restrict__ src, float*
         r /= KW;
         const int ky = (int)(r % KH);
         const int o = (int)(r / KH);
-        dst[d] = src[(((size_t)o * I + i) * KH + ky) * KW + kx];
+        dst[d] = (T)src[(((size_t)o * I + i) * KH + ky) * KW + kx];  // f16: round to nearest even
     }
 }
 
-hipError_t launch_repack_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW,
+hipError_t launch_repack_oihw_to_ohwi(const float* src, void* dst, int f16, int O, int I, int KH, int KW,
                                       hipStream_t s) {
     const size_t total = (size_t)O * I * KH * KW;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(repack_oihw_to_ohwi_kernel, dim3(blocks), dim3(256), 0, s, src, dst, O, I, KH, KW);
+    if (f16)
+        hipLaunchKernelGGL(repack_oihw_to_ohwi_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, src, (_Float16*)dst, O, I, KH, KW);
+    else
+        hipLaunchKernelGGL(repack_oihw_to_ohwi_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, O, I, KH, KW);
     return hipGetLastError();
 }
 

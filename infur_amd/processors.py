@@ -98,11 +98,13 @@ class Context:
     """One GPU + one HIP stream + device arena (``infur_ctx``).  Not thread-safe."""
 
     def __init__(self, device: int = 0, compute_aux: bool = True, profile: bool = False,
-                 keep_activations: bool = False, stream: Optional[int] = None):
+                 keep_activations: bool = False, stream: Optional[int] = None, dtype: str = "f32"):
         L = self.L = _lib.load()
         o = _lib.Options()
         L.infur_options_default(C.byref(o))
         o.device = device
+        o.compute_dtype = {"f32": _lib.DTYPE_F32, "f16": _lib.DTYPE_F16}[dtype]
+        self.dtype = dtype
         o.compute_aux = 1 if compute_aux else 0
         o.profile = 1 if profile else 0
         o.keep_activations = 1 if keep_activations else 0
