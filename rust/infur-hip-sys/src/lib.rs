@@ -1,0 +1,87 @@
+//! Raw bindings of `include/infur_hip.h`.  UNTESTED: never compiled (no Rust toolchain here).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+#[repr(C)]
+pub struct infur_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct infur_stream {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct infur_options {
+    pub struct_size: u32,
+    pub device: i32,
+    pub compute_dtype: u32,
+    pub compute_aux: u32,
+    pub profile: u32,
+    pub keep_activations: u32,
+    pub stream: *mut c_void,
+}
+
+#[repr(C)]
+pub struct infur_model_info {
+    pub input_name: [c_char; 32],
+    pub input0_dtype: [c_char; 16],
+    pub output_names: [[c_char; 32]; 2],
+    pub n_outputs: u32,
+    pub num_classes: u32,
+    pub depth: u32,
+    pub n_convs: u32,
+    pub weight_bytes: u64,
+}
+
+pub const INFUR_OK: i32 = 0;
+pub const INFUR_E_INVALID_SCALE: i32 = 1;
+pub const INFUR_E_ZERO_SIZE_IN: i32 = 2;
+pub const INFUR_E_ZERO_SIZE_OUT: i32 = 3;
+pub const INFUR_E_SHAPE: i32 = 4;
+pub const INFUR_E_MODEL_NOT_LOADED: i32 = 5;
+pub const INFUR_E_MODEL_FORMAT: i32 = 6;
+pub const INFUR_E_HIP: i32 = 7;
+pub const INFUR_E_CAPACITY: i32 = 11;
+pub const INFUR_SCALE_NEAREST: u32 = 0;
+pub const INFUR_SCALE_BILINEAR: u32 = 1;
+pub const INFUR_DTYPE_F32: u32 = 0;
+pub const INFUR_DTYPE_F16: u32 = 1;
+
+extern "C" {
+    pub fn infur_abi_version() -> u32;
+    pub fn infur_status_string(status: i32) -> *const c_char;
+    pub fn infur_device_count() -> i32;
+    pub fn infur_options_default(o: *mut infur_options);
+    pub fn infur_ctx_create(o: *const infur_options, out: *mut *mut infur_ctx) -> i32;
+    pub fn infur_ctx_destroy(c: *mut infur_ctx);
+    pub fn infur_last_error(c: *const infur_ctx) -> *const c_char;
+    pub fn infur_ctx_synchronize(c: *mut infur_ctx) -> i32;
+
+    pub fn infur_scale_validate(factor: f32) -> i32;
+    pub fn infur_scale_out_dims(w: u32, h: u32, factor: f32, ow: *mut u32, oh: *mut u32) -> i32;
+    pub fn infur_scale(c: *mut infur_ctx, bgr: *const u8, w: u32, h: u32, factor: f32, mode: u32,
+                       out: *mut u8, out_capacity: usize, ow: *mut u32, oh: *mut u32) -> i32;
+
+    pub fn infur_model_load(c: *mut infur_ctx, path: *const c_char) -> i32;
+    pub fn infur_model_load_blob(c: *mut infur_ctx, blob: *const c_void, len: usize) -> i32;
+    pub fn infur_model_unload(c: *mut infur_ctx) -> i32;
+    pub fn infur_model_info_get(c: *const infur_ctx, info: *mut infur_model_info) -> i32;
+    pub fn infur_model_advance(c: *mut infur_ctx, bgr: *const u8, w: u32, h: u32, out: *mut f32,
+                               aux: *mut f32, n_outputs: *mut u32) -> i32;
+
+    pub fn infur_colorcode(c: *mut infur_ctx, khw: *const f32, k: u32, h: u32, w: u32, rgba: *mut u8) -> i32;
+    pub fn infur_bgr_to_rgba(c: *mut infur_ctx, bgr: *const u8, w: u32, h: u32, rgba: *mut u8) -> i32;
+    pub fn infur_frame_advance(c: *mut infur_ctx, bgr: *const u8, w: u32, h: u32, factor: f32, mode: u32,
+                               rgba: *mut u8, rgba_capacity: usize, scaled_bgr: *mut u8,
+                               ow: *mut u32, oh: *mut u32) -> i32;
+
+    pub fn infur_stream_create(c: *mut infur_ctx, depth: u32, out: *mut *mut infur_stream) -> i32;
+    pub fn infur_stream_destroy(s: *mut infur_stream);
+    pub fn infur_stream_submit(s: *mut infur_stream, bgr: *const u8, w: u32, h: u32, factor: f32,
+                               mode: u32, frame_id: u64) -> i32;
+    pub fn infur_stream_pending(s: *const infur_stream) -> u32;
+    pub fn infur_stream_next_dims(s: *const infur_stream, frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
+    pub fn infur_stream_collect(s: *mut infur_stream, rgba: *mut u8, cap: usize, scaled_bgr: *mut u8,
+                                frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
+}
