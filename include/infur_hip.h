@@ -74,6 +74,8 @@ typedef struct infur_options {
     uint32_t compute_aux;  /* 1: evaluate the aux head as the ONNX graph does (default 1) */
     uint32_t profile;      /* 1: bracket every kernel with HIP events (infur_profile_*) */
     uint32_t keep_activations; /* 1: debug -- every conv output keeps its own buffer */
+    uint32_t winograd_min_cin; /* f32 stride-1 3x3 convs with Cin >= this use Winograd F(2x2,3x3);
+                                  0 = default (512), 0xFFFFFFFF = never */
     void* stream;          /* optional caller-owned hipStream_t; NULL = context creates one */
 } infur_options;
 
@@ -94,8 +96,10 @@ typedef struct infur_kernel_record {
     char name[48];      /* layer name, e.g. "backbone.layer4.1.conv2" */
     char kernel[32];    /* kernel family, e.g. "conv_igemm_f32" */
     float ms;           /* HIP-event duration */
-    double flops;       /* algorithmic FLOPs (2 x MAC); 0 for byte kernels */
-    double bytes;       /* algorithmic (compulsory) HBM bytes */
+    double flops;       /* FLOPs this launch executes (2 x MAC); 0 for byte kernels */
+    double bytes;       /* compulsory HBM bytes of this launch */
+    double algo_flops;  /* direct-convolution FLOPs of the layer this launch completes (== flops except
+                           for Winograd-domain GEMMs, where it is 2.25x larger; 0 for transforms) */
 } infur_kernel_record;
 
 /* ---- library ---- */

@@ -38,6 +38,7 @@ class Options(C.Structure):
         ("compute_aux", C.c_uint32),
         ("profile", C.c_uint32),
         ("keep_activations", C.c_uint32),
+        ("winograd_min_cin", C.c_uint32),
         ("stream", C.c_void_p),
     ]
 
@@ -62,6 +63,7 @@ class KernelRecord(C.Structure):
         ("ms", C.c_float),
         ("flops", C.c_double),
         ("bytes", C.c_double),
+        ("algo_flops", C.c_double),
     ]
 
 

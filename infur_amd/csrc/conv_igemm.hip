@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 
     // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of
     // tiles (n fastest) so the N-tiles that share an activation tile share one L2.
-    const int nblk = mtiles * ntiles;
+    const int nblk = mtiles * ntiles * (a.batch > 1 ? a.batch : 1);
     int tile;
     {
         const int b = blockIdx.x;
@@ -70,8 +70,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         const int q = nblk >> 3, r = nblk & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    const int per_batch = mtiles * ntiles;
+    const int bidx = tile / per_batch;  // 0 for a plain convolution
+    tile -= bidx * per_batch;
     const int mt = tile / ntiles, nt = tile - mt * ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
+    const char* in_base = static_cast<const char*>(a.in) + (size_t)bidx * a.in_bs;
+    const char* wt_base = static_cast<const char*>(a.wt) + (size_t)bidx * a.wt_bs;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,9 +89,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // Buffer descriptors: hardware bounds checking turns an out-of-range offset into a
     // zero result, so padding taps and ragged tiles need no branches in the K loop.
     const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.in), 0, (unsigned)((size_t)a.H * a.W * a.Cin * ES), 0x00020000);
+        const_cast<char*>(in_base), 0, (unsigned)((size_t)a.H * a.W * a.Cin * ES), 0x00020000);
     const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.wt), 0, (unsigned)((size_t)a.Cout * Ktot * ES), 0x00020000);
+        const_cast<char*>(wt_base), 0, (unsigned)((size_t)a.Cout * Ktot * ES), 0x00020000);
 
     // per-thread gather coordinates of the A rows it stages
     int a_iy0[A_IT], a_ix0[A_IT];
@@ -287,7 +292,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // 4 * (lane >> 5)) a lane owns ONE pixel (col) and, per group g = e >> 2, FOUR consecutive
     // output channels: NHWC stores, residual loads and bias loads are 16 (f32) / 8 (f16) bytes wide.
     const T* res = static_cast<const T*>(a.res);
-    OutT* out = static_cast<OutT*>(a.out);
+    OutT* out = reinterpret_cast<OutT*>(static_cast<char*>(a.out) + (size_t)bidx * a.out_bs);
+    const bool has_bias = a.bias != nullptr;
     const bool vec_ok = (a.Cout & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
@@ -302,8 +308,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 const size_t o = (size_t)m * a.Cout + n;
                 float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (vec_ok) {
-                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    if (has_bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    }
                     if (res) {
                         if constexpr (F32) {
                             const float4 rv = *reinterpret_cast<const float4*>(res + o);
@@ -326,7 +334,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         if (n + t >= a.Cout) break;
-                        float x = v[t] + a.bias[n + t];
+                        float x = v[t] + (has_bias ? a.bias[n + t] : 0.f);
                         if (res) x += (float)res[o + t];
                         if (a.relu) x = fmaxf(x, 0.f);
                         out[o + t] = (OutT)x;
@@ -351,7 +359,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(mtiles * ntiles), dim3(WM * WN * 64), lds, s, a, mtiles, ntiles);
+    hipLaunchKernelGGL(k, dim3(mtiles * ntiles * (a.batch > 1 ? a.batch : 1)), dim3(WM * WN * 64), lds, s, a, mtiles, ntiles);
     return hipGetLastError();
 }
 

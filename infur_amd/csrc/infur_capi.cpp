@@ -51,12 +51,13 @@ struct ConvLayer {
     char role = 0;        // s stem, 1 2 3 block convs, d downsample, h head3x3, c classifier
     void* d_w = nullptr;   // repacked weights (context dtype; the stem's stay f32)
     float* d_b = nullptr;  // bias, always f32
+    float* d_u = nullptr;  // Winograd-domain weights U[16][cout][cin] (f32 stride-1 3x3 convs only)
 };
 
 struct ProfRec {
     std::string name;
     const char* kernel;
-    double flops, bytes;
+    double flops, bytes, algo_flops;
     hipEvent_t e0, e1;
 };
 
@@ -192,13 +193,15 @@ struct ProfScope {
     infur_ctx* c;
     bool on;
     ProfRec r;
-    ProfScope(infur_ctx* c_, const std::string& name, const char* kernel, double flops, double bytes)
+    ProfScope(infur_ctx* c_, const std::string& name, const char* kernel, double flops, double bytes,
+              double algo_flops = -1.0)
         : c(c_), on(c_->opt.profile != 0) {
         if (!on) return;
         r.name = name;
         r.kernel = kernel;
         r.flops = flops;
         r.bytes = bytes;
+        r.algo_flops = algo_flops < 0.0 ? flops : algo_flops;
         for (hipEvent_t* e : {&r.e0, &r.e1}) {
             if (!c->ev_free.empty()) {
                 *e = c->ev_free.back();
@@ -292,6 +295,14 @@ uint32_t f32_as_u32(float v) {  // Rust `as u32`: saturating, NaN -> 0
 }
 
 int conv_out(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
+
+// stride-1 3x3 convs whose direct form is MFMA-bound run in the Winograd domain (f32 mode only:
+// the transforms amplify f16 rounding)
+bool wino_eligible(const infur_ctx* c, const ConvLayer& L) {
+    if (c->opt.compute_dtype != INFUR_DTYPE_F32 || L.k != 3 || L.stride != 1 || L.pad != L.dil) return false;
+    const uint32_t thr = c->opt.winograd_min_cin ? c->opt.winograd_min_cin : 512u;
+    return thr != 0xFFFFFFFFu && (uint32_t)L.cin >= thr && (L.cin % 32) == 0 && (L.cout % 4) == 0;
+}
 
 // ---- graph description: torchvision fcn_resnet{50,101}, output stride 8 ----
 bool layer_blocks(int depth, int lb[4]) {
@@ -395,6 +406,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         if (ents[i].w_off % 4 || ents[i].b_off % 4 || ents[i].w_off + wn > len || ents[i].b_off + bn > len)
             return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' data out of range", name);
         total += align_up(wn, 256) + align_up(bn, 256);  // upper bound (f16 weights take half)
+        if (wino_eligible(c, L)) total += align_up((size_t)16 * L.cout * L.cin * 4, 256);
     }
 
     model_free(c);
@@ -415,6 +427,11 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         else
             HIPCHK(c, launch_repack_oihw_to_ohwi(src_w, L.d_w, ctx_f16(c) ? 1 : 0, L.cout, L.cin, L.k, L.k, c->stream));
         HIPCHK(c, hipMemcpyAsync(L.d_b, (const uint8_t*)d_blob + ents[i].b_off, bn, hipMemcpyDeviceToDevice, c->stream));
+        if (wino_eligible(c, L)) {
+            L.d_u = (float*)((uint8_t*)c->d_weights + off);
+            off += align_up((size_t)16 * L.cout * L.cin * 4, 256);
+            HIPCHK(c, launch_wino_weights(src_w, L.cout, L.cin, L.d_u, c->stream));
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->convs.swap(g);
@@ -444,6 +461,37 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
     const int f16 = ctx_f16(c) ? 1 : 0;
     const int out_f32 = (!f16 || L.role == 'c') ? 1 : 0;  // the logits leave the conv stack in f32
     RETIF(talloc(c, oh, ow, L.cout, out_f32 ? 4 : 2, out));
+    if (L.d_u && !res) {
+        // Winograd F(2x2,3x3): input transform -> 16 batched GEMMs -> output transform (+bias, ReLU)
+        const int T = wino_num_tiles(in.h, in.w, L.dil);
+        Tensor V, M;
+        RETIF(talloc(c, 16, T, in.c, 4, &V));
+        RETIF(talloc(c, 16, T, L.cout, 4, &M));
+        const double direct = 2.0 * oh * ow * (double)L.cout * L.cin * 9.0;
+        {
+            ProfScope ps(c, L.name + "/in", "wino_input", 0, (double)in.bytes() + (double)V.bytes(), 0.0);
+            HIPCHK(c, launch_wino_input((const float*)in.p, in.h, in.w, in.c, L.dil, (float*)V.p, c->stream));
+        }
+        ConvArgs g;
+        g.in = V.p; g.wt = L.d_u; g.bias = nullptr; g.res = nullptr; g.out = M.p;
+        g.H = 1; g.W = T; g.Cin = in.c; g.OH = 1; g.OW = T; g.Cout = L.cout;
+        g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
+        g.batch = 16;
+        g.in_bs = (size_t)T * in.c * 4; g.wt_bs = (size_t)L.cout * L.cin * 4; g.out_bs = (size_t)T * L.cout * 4;
+        {
+            ProfScope ps(c, L.name, conv_igemm_config(g, 0), 2.0 * 16.0 * T * (double)L.cout * L.cin,
+                         (double)V.bytes() + (double)M.bytes() + 16.0 * L.cout * L.cin * 4, direct);
+            HIPCHK(c, launch_conv_igemm(g, 0, 1, c->stream));
+        }
+        pool_release(c, V);
+        {
+            ProfScope ps(c, L.name + "/out", "wino_output", 0, (double)M.bytes() + (double)out->bytes(), 0.0);
+            HIPCHK(c, launch_wino_output((const float*)M.p, oh, ow, L.cout, L.dil, L.d_b, L.relu ? 1 : 0, (float*)out->p, c->stream));
+        }
+        pool_release(c, M);
+        if (c->opt.keep_activations) c->kept.push_back(*out);
+        return INFUR_OK;
+    }
     ConvArgs a;
     a.in = in.p; a.wt = L.d_w; a.bias = L.d_b; a.res = res ? res->p : nullptr; a.out = out->p;
     a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = L.cout;
@@ -1180,6 +1228,7 @@ int32_t infur_profile_get(infur_ctx* c, uint32_t i, infur_kernel_record* rec) {
     rec->ms = ms;
     rec->flops = r.flops;
     rec->bytes = r.bytes;
+    rec->algo_flops = r.algo_flops;
     return INFUR_OK;
 }
 

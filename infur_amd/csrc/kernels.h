@@ -11,13 +11,17 @@ namespace infur {
 struct ConvArgs {
     const void* in;     // [H][W][Cin]
     const void* wt;     // [Cout][KH*KW*Cin]
-    const float* bias;  // [Cout]
+    const float* bias;  // [Cout], may be null (no bias)
     const void* res;    // optional residual, same shape and type as the input activations
     void* out;          // [OH][OW][Cout]
     int H, W, Cin;
     int OH, OW, Cout;
     int KH, KW, stride, pad, dil;
     int relu;
+    // batched use (Winograd-domain GEMMs): `batch` independent problems of the same shape,
+    // operand b starts at base + b * stride (bytes).  batch <= 1: plain convolution.
+    int batch = 1;
+    size_t in_bs = 0, wt_bs = 0, out_bs = 0;
 };
 
 // conv as implicit GEMM on the matrix cores.  f16 = 0: f32 operands (Cin % 32 == 0);
@@ -25,6 +29,13 @@ struct ConvArgs {
 hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, hipStream_t s);
 // name of the tile configuration launch_conv_igemm picks for these arguments
 const char* conv_igemm_config(const ConvArgs& a, int f16);
+
+// Winograd F(2x2,3x3) for stride-1 3x3 convs (f32, any dilation d with pad = d); see winograd.hip
+int wino_num_tiles(int H, int W, int d);
+hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, float* V, hipStream_t s);
+hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, const float* bias, int relu, float* out,
+                              hipStream_t s);
+hipError_t launch_wino_weights(const float* w_oihw, int O, int I, float* U, hipStream_t s);
 
 // stem: packed BGR u8 -> (LUT normalise, BGR->RGB) -> conv 7x7/2 pad 3 (3->64) + bias + ReLU,
 // NHWC out (f32, or f16 when f16 != 0; the arithmetic is f32 either way).

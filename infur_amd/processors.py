@@ -98,7 +98,8 @@ class Context:
     """One GPU + one HIP stream + device arena (``infur_ctx``).  Not thread-safe."""
 
     def __init__(self, device: int = 0, compute_aux: bool = True, profile: bool = False,
-                 keep_activations: bool = False, stream: Optional[int] = None, dtype: str = "f32"):
+                 keep_activations: bool = False, stream: Optional[int] = None, dtype: str = "f32",
+                 winograd_min_cin: int = 0):
         L = self.L = _lib.load()
         o = _lib.Options()
         L.infur_options_default(C.byref(o))
@@ -108,6 +109,7 @@ class Context:
         o.compute_aux = 1 if compute_aux else 0
         o.profile = 1 if profile else 0
         o.keep_activations = 1 if keep_activations else 0
+        o.winograd_min_cin = winograd_min_cin  # 0 = default (512), 0xFFFFFFFF = direct convs only
         o.stream = stream
         h = C.c_void_p(None)
         rc = L.infur_ctx_create(C.byref(o), C.byref(h))
@@ -140,7 +142,7 @@ class Context:
         for i in range(n.value):
             self.check(self.L.infur_profile_get(self.h, i, C.byref(rec)))
             out.append({"name": rec.name.decode(), "kernel": rec.kernel.decode(), "ms": rec.ms,
-                        "flops": rec.flops, "bytes": rec.bytes})
+                        "flops": rec.flops, "bytes": rec.bytes, "algo_flops": rec.algo_flops})
         return out
 
     def close(self):
