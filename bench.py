@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="conv-stack arithmetic: f32 (BASELINE configs[1], the default and the parity mode) or f16 "
                          "operands with f32 accumulation (configs[4]'s mode)")
+    ap.add_argument("--winograd-min-cin", type=int, default=0,
+                    help="f32 stride-1 3x3 convs with Cin >= this run as Winograd F(2x2,3x3); 0 = library default, -1 = never")
+    ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4], help="Winograd output tile (0 = default)")
     ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="backbone: FCN-ResNet50 (default) / 101")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
@@ -124,7 +127,8 @@ def main():
             dist.init_process_group("gloo")
 
     stream = torch.cuda.Stream()
-    ctx = Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=stream.cuda_stream, dtype=a.dtype)
+    ctx = Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=stream.cuda_stream, dtype=a.dtype,
+                  winograd_min_cin=a.winograd_min_cin & 0xFFFFFFFF, winograd_tile=a.winograd_tile)
 
     # ---- weights: rank 0 synthesises, RCCL broadcast over xGMI, every rank repacks locally ----
     blob = W.synth_blob(depth=a.depth) if rank == 0 else None

@@ -74,8 +74,9 @@ typedef struct infur_options {
     uint32_t compute_aux;  /* 1: evaluate the aux head as the ONNX graph does (default 1) */
     uint32_t profile;      /* 1: bracket every kernel with HIP events (infur_profile_*) */
     uint32_t keep_activations; /* 1: debug -- every conv output keeps its own buffer */
-    uint32_t winograd_min_cin; /* f32 stride-1 3x3 convs with Cin >= this use Winograd F(2x2,3x3);
-                                  0 = default (512), 0xFFFFFFFF = never */
+    uint32_t winograd_min_cin; /* f32 stride-1 3x3 convs with Cin >= this run in the Winograd domain;
+                                  0 = default (256), 0xFFFFFFFF = never */
+    uint32_t winograd_tile;    /* output tile: 2 = F(2x2,3x3), 4 = F(4x4,3x3); 0 = default (4) */
     void* stream;          /* optional caller-owned hipStream_t; NULL = context creates one */
 } infur_options;
 

@@ -39,6 +39,7 @@ class Options(C.Structure):
         ("profile", C.c_uint32),
         ("keep_activations", C.c_uint32),
         ("winograd_min_cin", C.c_uint32),
+        ("winograd_tile", C.c_uint32),
         ("stream", C.c_void_p),
     ]
 

@@ -296,11 +296,14 @@ uint32_t f32_as_u32(float v) {  // Rust `as u32`: saturating, NaN -> 0
 
 int conv_out(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
 
+inline int wino_mt(const infur_ctx* c) { return c->opt.winograd_tile == 2 ? 2 : 4; }
+inline int wino_planes(const infur_ctx* c) { return (wino_mt(c) + 2) * (wino_mt(c) + 2); }
+
 // stride-1 3x3 convs whose direct form is MFMA-bound run in the Winograd domain (f32 mode only:
 // the transforms amplify f16 rounding)
 bool wino_eligible(const infur_ctx* c, const ConvLayer& L) {
     if (c->opt.compute_dtype != INFUR_DTYPE_F32 || L.k != 3 || L.stride != 1 || L.pad != L.dil) return false;
-    const uint32_t thr = c->opt.winograd_min_cin ? c->opt.winograd_min_cin : 512u;
+    const uint32_t thr = c->opt.winograd_min_cin ? c->opt.winograd_min_cin : 256u;
     return thr != 0xFFFFFFFFu && (uint32_t)L.cin >= thr && (L.cin % 32) == 0 && (L.cout % 4) == 0;
 }
 
@@ -406,7 +409,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         if (ents[i].w_off % 4 || ents[i].b_off % 4 || ents[i].w_off + wn > len || ents[i].b_off + bn > len)
             return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' data out of range", name);
         total += align_up(wn, 256) + align_up(bn, 256);  // upper bound (f16 weights take half)
-        if (wino_eligible(c, L)) total += align_up((size_t)16 * L.cout * L.cin * 4, 256);
+        if (wino_eligible(c, L)) total += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
     }
 
     model_free(c);
@@ -429,8 +432,8 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         HIPCHK(c, hipMemcpyAsync(L.d_b, (const uint8_t*)d_blob + ents[i].b_off, bn, hipMemcpyDeviceToDevice, c->stream));
         if (wino_eligible(c, L)) {
             L.d_u = (float*)((uint8_t*)c->d_weights + off);
-            off += align_up((size_t)16 * L.cout * L.cin * 4, 256);
-            HIPCHK(c, launch_wino_weights(src_w, L.cout, L.cin, L.d_u, c->stream));
+            off += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
+            HIPCHK(c, launch_wino_weights(src_w, L.cout, L.cin, wino_mt(c), L.d_u, c->stream));
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -462,31 +465,32 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
     const int out_f32 = (!f16 || L.role == 'c') ? 1 : 0;  // the logits leave the conv stack in f32
     RETIF(talloc(c, oh, ow, L.cout, out_f32 ? 4 : 2, out));
     if (L.d_u && !res) {
-        // Winograd F(2x2,3x3): input transform -> 16 batched GEMMs -> output transform (+bias, ReLU)
-        const int T = wino_num_tiles(in.h, in.w, L.dil);
+        // Winograd F(mt x mt, 3x3): input transform -> (mt+2)^2 batched GEMMs -> output transform (+bias, ReLU)
+        const int mt = wino_mt(c), P = wino_planes(c);
+        const int T = wino_num_tiles(in.h, in.w, L.dil, mt);
         Tensor V, M;
-        RETIF(talloc(c, 16, T, in.c, 4, &V));
-        RETIF(talloc(c, 16, T, L.cout, 4, &M));
+        RETIF(talloc(c, P, T, in.c, 4, &V));
+        RETIF(talloc(c, P, T, L.cout, 4, &M));
         const double direct = 2.0 * oh * ow * (double)L.cout * L.cin * 9.0;
         {
             ProfScope ps(c, L.name + "/in", "wino_input", 0, (double)in.bytes() + (double)V.bytes(), 0.0);
-            HIPCHK(c, launch_wino_input((const float*)in.p, in.h, in.w, in.c, L.dil, (float*)V.p, c->stream));
+            HIPCHK(c, launch_wino_input((const float*)in.p, in.h, in.w, in.c, L.dil, mt, (float*)V.p, c->stream));
         }
         ConvArgs g;
         g.in = V.p; g.wt = L.d_u; g.bias = nullptr; g.res = nullptr; g.out = M.p;
         g.H = 1; g.W = T; g.Cin = in.c; g.OH = 1; g.OW = T; g.Cout = L.cout;
         g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
-        g.batch = 16;
+        g.batch = P;
         g.in_bs = (size_t)T * in.c * 4; g.wt_bs = (size_t)L.cout * L.cin * 4; g.out_bs = (size_t)T * L.cout * 4;
         {
-            ProfScope ps(c, L.name, conv_igemm_config(g, 0), 2.0 * 16.0 * T * (double)L.cout * L.cin,
-                         (double)V.bytes() + (double)M.bytes() + 16.0 * L.cout * L.cin * 4, direct);
+            ProfScope ps(c, L.name, conv_igemm_config(g, 0), 2.0 * P * T * (double)L.cout * L.cin,
+                         (double)V.bytes() + (double)M.bytes() + (double)P * L.cout * L.cin * 4, direct);
             HIPCHK(c, launch_conv_igemm(g, 0, 1, c->stream));
         }
         pool_release(c, V);
         {
             ProfScope ps(c, L.name + "/out", "wino_output", 0, (double)M.bytes() + (double)out->bytes(), 0.0);
-            HIPCHK(c, launch_wino_output((const float*)M.p, oh, ow, L.cout, L.dil, L.d_b, L.relu ? 1 : 0, (float*)out->p, c->stream));
+            HIPCHK(c, launch_wino_output((const float*)M.p, oh, ow, L.cout, L.dil, mt, L.d_b, L.relu ? 1 : 0, (float*)out->p, c->stream));
         }
         pool_release(c, M);
         if (c->opt.keep_activations) c->kept.push_back(*out);

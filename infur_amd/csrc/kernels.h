@@ -30,12 +30,13 @@ hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, hipStream_
 // name of the tile configuration launch_conv_igemm picks for these arguments
 const char* conv_igemm_config(const ConvArgs& a, int f16);
 
-// Winograd F(2x2,3x3) for stride-1 3x3 convs (f32, any dilation d with pad = d); see winograd.hip
-int wino_num_tiles(int H, int W, int d);
-hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, float* V, hipStream_t s);
-hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, const float* bias, int relu, float* out,
-                              hipStream_t s);
-hipError_t launch_wino_weights(const float* w_oihw, int O, int I, float* U, hipStream_t s);
+// Winograd F(mt x mt, 3x3), mt = 2 or 4, for stride-1 3x3 convs (f32, any dilation d with pad = d);
+// (mt+2)^2 transform planes; see winograd.hip
+int wino_num_tiles(int H, int W, int d, int mt);
+hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, hipStream_t s);
+hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int mt, const float* bias, int relu,
+                              float* out, hipStream_t s);
+hipError_t launch_wino_weights(const float* w_oihw, int O, int I, int mt, float* U, hipStream_t s);
 
 // stem: packed BGR u8 -> (LUT normalise, BGR->RGB) -> conv 7x7/2 pad 3 (3->64) + bias + ReLU,
 // NHWC out (f32, or f16 when f16 != 0; the arithmetic is f32 either way).

@@ -1,18 +1,22 @@
-// winograd.hip -- Winograd F(2x2, 3x3) transforms around the batched implicit-GEMM kernel.
+// winograd.hip -- Winograd F(m x m, 3x3) transforms (m = 2 or 4) around the batched implicit-GEMM
+// kernel.
 //
 // A stride-1 3x3 convolution (any dilation d, pad = d) costs 9 multiplies per output in the direct
-// form and 4 (16 per 2x2 output tile) in the Winograd domain: 2.25x fewer MFMA FLOPs, still plain
-// f32 arithmetic.  The conv nodes of FCN-ResNet that run inside `session.run`
-// (infur/src/predict_onnx.rs:138) with >= 512 input channels are MFMA-bound and take this route:
+// form, 4 with F(2x2,3x3) and 2.25 with F(4x4,3x3): 2.25x / 4x fewer MFMA FLOPs, still plain f32
+// arithmetic.  The stride-1 3x3 conv nodes of FCN-ResNet that run inside `session.run`
+// (infur/src/predict_onnx.rs:138) and are MFMA-bound in the direct form take this route:
 //
-//   V[xi][tile][c]  = (B^T d B)[xi]            input transform   (this file, HBM-bound)
-//   M[xi][tile][o]  = sum_c V[xi][tile][c] * U[xi][o][c]         16 batched GEMMs (conv_igemm.hip)
-//   Y[tile 2x2][o]  = A^T M A, + bias, ReLU     output transform  (this file, HBM-bound)
-//   U[xi][o][c]     = (G g G^T)[xi]             weight transform, once at model load
+//   V[xi][tile][c]  = (B^T d B)[xi]                  input transform   (this file, HBM-bound)
+//   M[xi][tile][o]  = sum_c V[xi][tile][c] * U[xi][o][c]    (m+2)^2 batched GEMMs (conv_igemm.hip)
+//   Y[tile m x m][o] = A^T M A, + bias, ReLU         output transform  (this file, HBM-bound)
+//   U[xi][o][c]     = (G g G^T)[xi]                  weight transform, once at model load
+//
+// (matrices: Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks", F(2x2,3x3) and
+// F(4x4,3x3) with interpolation points 0, +-1, +-2, inf.)
 //
 // Dilation: the output grid splits into d x d interleaved sub-grids (oy = d*y' + ry); on each the
 // dilated conv is an ordinary 3x3 / pad-1 conv over the equally sub-sampled input, so a tile is
-// (ry, rx, ty, tx) and its 4x4 input patch sits at rows d*(2*ty - 1 + i) + ry.
+// (ry, rx, ty, tx) and its (m+2)^2 input patch sits at rows d*(m*ty - 1 + i) + ry.
 #include "kernels.h"
 
 namespace infur {
@@ -31,161 +35,210 @@ __device__ __forceinline__ void tile_coords(const WinoGeom& g, int t, int& ry, i
     ry = r / g.d;
 }
 
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// ---- input transform: one thread = one tile x 4 channels ----
-__global__ void __launch_bounds__(256)
-    wino_input_kernel(const float* __restrict__ in, WinoGeom g, int C, int T, float* __restrict__ V) {
-    const int c4n = C >> 2;
-    const size_t total = (size_t)T * c4n;
-    const size_t plane = (size_t)T * C;  // floats per xi plane
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % c4n);
-        const int t = (int)(i / c4n);
-        int ry, rx, ty, tx;
-        tile_coords(g, t, ry, rx, ty, tx);
-        float4 d[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const int y = g.d * (2 * ty - 1 + a) + ry;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int x = g.d * (2 * tx - 1 + b) + rx;
-                d[a][b] = ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
-                              ? *reinterpret_cast<const float4*>(in + ((size_t)y * g.W + x) * C + c4 * 4)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        // B^T d: rows (d0-d2, d1+d2, d2-d1, d1-d3)
-        float4 r[4][4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            r[0][b] = f4sub(d[0][b], d[2][b]);
-            r[1][b] = f4add(d[1][b], d[2][b]);
-            r[2][b] = f4sub(d[2][b], d[1][b]);
-            r[3][b] = f4sub(d[1][b], d[3][b]);
-        }
-        float* o = V + (size_t)t * C + c4 * 4;
-#pragma unroll
-        for (int a = 0; a < 4; a++) {  // (.) B: columns (c0-c2, c1+c2, c2-c1, c1-c3)
-            *reinterpret_cast<float4*>(o + (size_t)(4 * a + 0) * plane) = f4sub(r[a][0], r[a][2]);
-            *reinterpret_cast<float4*>(o + (size_t)(4 * a + 1) * plane) = f4add(r[a][1], r[a][2]);
-            *reinterpret_cast<float4*>(o + (size_t)(4 * a + 2) * plane) = f4sub(r[a][2], r[a][1]);
-            *reinterpret_cast<float4*>(o + (size_t)(4 * a + 3) * plane) = f4sub(r[a][1], r[a][3]);
-        }
+// 1-D transforms on strided arrays of vectors (all loops unrolled; S = element stride)
+template <int MT, int S, typename V>
+__device__ __forceinline__ void bt_1d(const V* d, V* t) {  // B^T d : (MT+2) -> (MT+2)
+    if constexpr (MT == 2) {
+        t[0 * S] = d[0 * S] - d[2 * S];
+        t[1 * S] = d[1 * S] + d[2 * S];
+        t[2 * S] = d[2 * S] - d[1 * S];
+        t[3 * S] = d[1 * S] - d[3 * S];
+    } else {
+        const V d0 = d[0 * S], d1 = d[1 * S], d2 = d[2 * S], d3 = d[3 * S], d4 = d[4 * S], d5 = d[5 * S];
+        t[0 * S] = 4.0f * d0 - 5.0f * d2 + d4;
+        t[1 * S] = -4.0f * d1 - 4.0f * d2 + d3 + d4;
+        t[2 * S] = 4.0f * d1 - 4.0f * d2 - d3 + d4;
+        t[3 * S] = -2.0f * d1 - d2 + 2.0f * d3 + d4;
+        t[4 * S] = 2.0f * d1 - d2 - 2.0f * d3 + d4;
+        t[5 * S] = 4.0f * d1 - 5.0f * d3 + d5;
     }
 }
 
-// ---- output transform: one thread = one tile x 4 output channels; + bias, ReLU ----
+template <int MT, int S, typename V>
+__device__ __forceinline__ void at_1d(const V* m, V* y) {  // A^T m : (MT+2) -> MT
+    if constexpr (MT == 2) {
+        y[0 * S] = m[0 * S] + m[1 * S] + m[2 * S];
+        y[1 * S] = m[1 * S] - m[2 * S] - m[3 * S];
+    } else {
+        const V m0 = m[0 * S], m1 = m[1 * S], m2 = m[2 * S], m3 = m[3 * S], m4 = m[4 * S], m5 = m[5 * S];
+        y[0 * S] = m0 + m1 + m2 + m3 + m4;
+        y[1 * S] = m1 - m2 + 2.0f * m3 - 2.0f * m4;
+        y[2 * S] = m1 + m2 + 4.0f * m3 + 4.0f * m4;
+        y[3 * S] = m1 - m2 + 8.0f * m3 - 8.0f * m4 + m5;
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void g_1d(float g0, float g1, float g2, float* u) {  // G g : 3 -> (MT+2)
+    if constexpr (MT == 2) {
+        u[0] = g0;
+        u[1] = 0.5f * (g0 + g1 + g2);
+        u[2] = 0.5f * (g0 - g1 + g2);
+        u[3] = g2;
+    } else {
+        u[0] = 0.25f * g0;
+        u[1] = -(g0 + g1 + g2) * (1.0f / 6.0f);
+        u[2] = -(g0 - g1 + g2) * (1.0f / 6.0f);
+        u[3] = g0 * (1.0f / 24.0f) + g1 * (1.0f / 12.0f) + g2 * (1.0f / 6.0f);
+        u[4] = g0 * (1.0f / 24.0f) - g1 * (1.0f / 12.0f) + g2 * (1.0f / 6.0f);
+        u[5] = g2;
+    }
+}
+
+// ---- input transform: one thread = one tile x 2 channels ----
+template <int MT>
+__global__ void __launch_bounds__(256)
+    wino_input_kernel(const float* __restrict__ in, WinoGeom g, int C, int T, float* __restrict__ V) {
+    constexpr int AL = MT + 2;
+    const int cvn = C >> 1;
+    const size_t total = (size_t)T * cvn;
+    const size_t plane = (size_t)T * C;  // floats per xi plane
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cv = (int)(i % cvn);
+        const int t = (int)(i / cvn);
+        int ry, rx, ty, tx;
+        tile_coords(g, t, ry, rx, ty, tx);
+        f32x2 d[AL * AL], r[AL * AL];
+#pragma unroll
+        for (int a = 0; a < AL; a++) {
+            const int y = g.d * (MT * ty - 1 + a) + ry;
+#pragma unroll
+            for (int b = 0; b < AL; b++) {
+                const int x = g.d * (MT * tx - 1 + b) + rx;
+                f32x2 v = {0.f, 0.f};
+                if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
+                    v = *reinterpret_cast<const f32x2*>(in + ((size_t)y * g.W + x) * C + cv * 2);
+                d[a * AL + b] = v;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < AL; b++) bt_1d<MT, AL>(d + b, r + b);      // columns: B^T d
+#pragma unroll
+        for (int a = 0; a < AL; a++) bt_1d<MT, 1>(r + a * AL, d + a * AL);  // rows: (.) B
+        float* o = V + (size_t)t * C + cv * 2;
+#pragma unroll
+        for (int xi = 0; xi < AL * AL; xi++) *reinterpret_cast<f32x2*>(o + (size_t)xi * plane) = d[xi];
+    }
+}
+
+// ---- output transform: one thread = one tile x 2 output channels; + bias, ReLU ----
+template <int MT>
 __global__ void __launch_bounds__(256)
     wino_output_kernel(const float* __restrict__ M, WinoGeom g, int Cout, int T, const float* __restrict__ bias,
                        int relu, float* __restrict__ out) {
-    const int n4n = Cout >> 2;
-    const size_t total = (size_t)T * n4n;
+    constexpr int AL = MT + 2;
+    const int nvn = Cout >> 1;
+    const size_t total = (size_t)T * nvn;
     const size_t plane = (size_t)T * Cout;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int n4 = (int)(i % n4n);
-        const int t = (int)(i / n4n);
+        const int nv = (int)(i % nvn);
+        const int t = (int)(i / nvn);
         int ry, rx, ty, tx;
         tile_coords(g, t, ry, rx, ty, tx);
-        const float* mp = M + (size_t)t * Cout + n4 * 4;
-        float4 m[4][4];
+        const float* mp = M + (size_t)t * Cout + nv * 2;
+        f32x2 m[AL * AL], s[MT * AL], yv[MT * MT];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int xi = 0; xi < AL * AL; xi++) m[xi] = *reinterpret_cast<const f32x2*>(mp + (size_t)xi * plane);
 #pragma unroll
-            for (int b = 0; b < 4; b++) m[a][b] = *reinterpret_cast<const float4*>(mp + (size_t)(4 * a + b) * plane);
-        // A^T m: rows (m0+m1+m2, m1-m2-m3)
-        float4 s[2][4];
+        for (int b = 0; b < AL; b++) at_1d<MT, AL>(m + b, s + b);        // columns: A^T m  -> [MT][AL]
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            s[0][b] = f4add(f4add(m[0][b], m[1][b]), m[2][b]);
-            s[1][b] = f4sub(f4sub(m[1][b], m[2][b]), m[3][b]);
-        }
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n4 * 4);
+        for (int a = 0; a < MT; a++) at_1d<MT, 1>(s + a * AL, yv + a * MT);  // rows: (.) A -> [MT][MT]
+        const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + nv * 2);
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const int y = g.d * (2 * ty + a) + ry;
+        for (int a = 0; a < MT; a++) {
+            const int y = g.d * (MT * ty + a) + ry;
             if (y >= g.H) continue;
-            float4 yv[2];
-            yv[0] = f4add(f4add(s[a][0], s[a][1]), s[a][2]);
-            yv[1] = f4sub(f4sub(s[a][1], s[a][2]), s[a][3]);
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const int x = g.d * (2 * tx + b) + rx;
+            for (int b = 0; b < MT; b++) {
+                const int x = g.d * (MT * tx + b) + rx;
                 if (x >= g.W) continue;
-                float4 v = f4add(yv[b], bv);
-                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                *reinterpret_cast<float4*>(out + ((size_t)y * g.W + x) * Cout + n4 * 4) = v;
+                f32x2 v = yv[a * MT + b] + bv;
+                if (relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                }
+                *reinterpret_cast<f32x2*>(out + ((size_t)y * g.W + x) * Cout + nv * 2) = v;
             }
         }
     }
 }
 
 // ---- weight transform: U[xi][o][c] = (G g G^T)[xi],  g = w[o][c][3][3] (OIHW) ----
+template <int MT>
 __global__ void wino_weight_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ U) {
+    constexpr int AL = MT + 2;
     const size_t total = (size_t)O * I;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const float* gk = w + i * 9;  // [o][c][ky][kx], i = o*I + c
-        float t[4][3];
+        float t[AL][3], u[AL];
 #pragma unroll
-        for (int b = 0; b < 3; b++) {  // G g : rows (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
-            const float g0 = gk[0 * 3 + b], g1 = gk[1 * 3 + b], g2 = gk[2 * 3 + b];
-            t[0][b] = g0;
-            t[1][b] = 0.5f * (g0 + g1 + g2);
-            t[2][b] = 0.5f * (g0 - g1 + g2);
-            t[3][b] = g2;
+        for (int b = 0; b < 3; b++) {  // G g (over ky)
+            g_1d<MT>(gk[0 * 3 + b], gk[1 * 3 + b], gk[2 * 3 + b], u);
+#pragma unroll
+            for (int a = 0; a < AL; a++) t[a][b] = u[a];
         }
 #pragma unroll
-        for (int a = 0; a < 4; a++) {  // (.) G^T
-            const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
-                        u3 = t[a][2];
-            U[(size_t)(4 * a + 0) * total + i] = u0;
-            U[(size_t)(4 * a + 1) * total + i] = u1;
-            U[(size_t)(4 * a + 2) * total + i] = u2;
-            U[(size_t)(4 * a + 3) * total + i] = u3;
+        for (int a = 0; a < AL; a++) {  // (.) G^T (over kx)
+            g_1d<MT>(t[a][0], t[a][1], t[a][2], u);
+#pragma unroll
+            for (int b = 0; b < AL; b++) U[(size_t)(AL * a + b) * total + i] = u[b];
         }
     }
 }
 
-static WinoGeom geom(int H, int W, int d) {
+static WinoGeom geom(int H, int W, int d, int mt) {
     WinoGeom g;
     g.H = H;
     g.W = W;
     g.d = d;
-    g.TY = ((H + d - 1) / d + 1) / 2;
-    g.TX = ((W + d - 1) / d + 1) / 2;
+    g.TY = ((H + d - 1) / d + mt - 1) / mt;
+    g.TX = ((W + d - 1) / d + mt - 1) / mt;
     return g;
 }
 
-int wino_num_tiles(int H, int W, int d) {
-    const WinoGeom g = geom(H, W, d);
+int wino_num_tiles(int H, int W, int d, int mt) {
+    const WinoGeom g = geom(H, W, d, mt);
     return d * d * g.TY * g.TX;
 }
 
-hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, float* V, hipStream_t s) {
-    const WinoGeom g = geom(H, W, d);
-    const int T = d * d * g.TY * g.TX;
-    size_t blocks = ((size_t)T * (C / 4) + 255) / 256;
+static unsigned grid_for(size_t work) {
+    size_t blocks = (work + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, g, C, T, V);
+    return (unsigned)blocks;
+}
+
+hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, hipStream_t s) {
+    const WinoGeom g = geom(H, W, d, mt);
+    const int T = d * d * g.TY * g.TX;
+    const unsigned blocks = grid_for((size_t)T * (C / 2));
+    if (mt == 2)
+        hipLaunchKernelGGL(wino_input_kernel<2>, dim3(blocks), dim3(256), 0, s, in, g, C, T, V);
+    else
+        hipLaunchKernelGGL(wino_input_kernel<4>, dim3(blocks), dim3(256), 0, s, in, g, C, T, V);
     return hipGetLastError();
 }
 
-hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, const float* bias, int relu, float* out,
-                              hipStream_t s) {
-    const WinoGeom g = geom(H, W, d);
+hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int mt, const float* bias, int relu,
+                              float* out, hipStream_t s) {
+    const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
-    size_t blocks = ((size_t)T * (Cout / 4) + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out);
+    const unsigned blocks = grid_for((size_t)T * (Cout / 2));
+    if (mt == 2)
+        hipLaunchKernelGGL(wino_output_kernel<2>, dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out);
+    else
+        hipLaunchKernelGGL(wino_output_kernel<4>, dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out);
     return hipGetLastError();
 }
 
-hipError_t launch_wino_weights(const float* w_oihw, int O, int I, float* U, hipStream_t s) {
+hipError_t launch_wino_weights(const float* w_oihw, int O, int I, int mt, float* U, hipStream_t s) {
     size_t blocks = ((size_t)O * I + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, O, I, U);
+    if (mt == 2)
+        hipLaunchKernelGGL(wino_weight_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, O, I, U);
+    else
+        hipLaunchKernelGGL(wino_weight_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, O, I, U);
     return hipGetLastError();
 }
 

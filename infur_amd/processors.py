@@ -99,7 +99,7 @@ class Context:
 
     def __init__(self, device: int = 0, compute_aux: bool = True, profile: bool = False,
                  keep_activations: bool = False, stream: Optional[int] = None, dtype: str = "f32",
-                 winograd_min_cin: int = 0):
+                 winograd_min_cin: int = 0, winograd_tile: int = 0):
         L = self.L = _lib.load()
         o = _lib.Options()
         L.infur_options_default(C.byref(o))
@@ -109,7 +109,8 @@ class Context:
         o.compute_aux = 1 if compute_aux else 0
         o.profile = 1 if profile else 0
         o.keep_activations = 1 if keep_activations else 0
-        o.winograd_min_cin = winograd_min_cin  # 0 = default (512), 0xFFFFFFFF = direct convs only
+        o.winograd_min_cin = winograd_min_cin  # 0 = default (256), 0xFFFFFFFF = direct convs only
+        o.winograd_tile = winograd_tile  # 0 = default F(4x4,3x3), 2 = F(2x2,3x3)
         o.stream = stream
         h = C.c_void_p(None)
         rc = L.infur_ctx_create(C.byref(o), C.byref(h))

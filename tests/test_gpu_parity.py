@@ -364,14 +364,14 @@ def test_profile_records(blob50):
     rgba, _ = FramePath(c2).advance(W.synth_frame(96, 128), 1.0)
     recs = c2.profile()
     names = [r["name"] for r in recs]
-    # 57 convs + maxpool + fused post; the 5 convs with Cin >= 512 (layer4 x3, both heads) run in the
-    # Winograd domain and add an input and an output transform each
+    # 57 convs + maxpool + fused post; the 11 stride-1 3x3 convs with Cin >= 256 (layer3 x6, layer4 x3,
+    # both heads) run in the Winograd domain and add an input and an output transform each
     wino = [r for r in recs if r["kernel"] in ("wino_input", "wino_output")]
     assert names[0] == "backbone.conv1" and names[-1] == "out.resize+colorcode"
-    assert len(wino) == 10 and len(recs) == 57 + 2 + len(wino)
+    assert len(wino) == 22 and len(recs) == 57 + 2 + len(wino)
     algo = sum(r["algo_flops"] for r in recs)
     assert abs(algo - W.conv_flops(96, 128)["total"]) < 1e-6 * algo
-    assert sum(r["flops"] for r in recs) < algo  # Winograd executes 2.25x fewer MACs on those layers
+    assert sum(r["flops"] for r in recs) < algo  # Winograd executes 2.25x - 4x fewer MACs on those layers
     assert all(r["ms"] > 0 for r in recs)
     c2.close()
 
@@ -424,4 +424,32 @@ def test_model_load_from_onnx_file(blob50, tmp_path, oracle_model):
     with pytest.raises(ModelCmdError) as e:
         m.control(ModelCmd.Load(str(bad)))
     assert e.value.code == _lib.E_MODEL_FORMAT and "quantised" in str(e.value)
+    c2.close()
+
+
+@pytest.mark.parametrize("tile,min_cin", [(2, 64), (4, 64), (4, 0xFFFFFFFF)])
+def test_winograd_variants_per_layer(blob50, tile, min_cin):
+    """Every conv output with Winograd F(2x2) / F(4x4) forced onto ALL stride-1 3x3 convs (dilation 1, 2
+    and 4, ragged tile edges), and with Winograd disabled, against the torch-CPU restatement."""
+    from oracle.infur_oracle import COracle, TorchModel
+
+    co = COracle()
+    tm = TorchModel(blob50)
+    c2 = Context(device=0, keep_activations=True, winograd_min_cin=min_cin, winograd_tile=tile)
+    m = Model(c2).control(ModelCmd.LoadBlob(blob50))
+    fr = W.synth_frame(75, 109, index=6)  # odd size: sub-grids of unequal extent, partial tiles
+    out = []
+    m.advance(fr, out)
+    taps = {}
+    tm.forward_lowres(co.pack_normalize(fr), taps=taps)
+    worst = 0.0
+    for i, spec in enumerate(W.graph(50)):
+        ref = taps[spec.name].numpy()
+        buf = np.empty(ref.shape, np.float32)
+        c, h, w = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        c2.check(c2.L.infur_debug_read_activation(c2.h, i, buf.ctypes.data, buf.size, C.byref(c), C.byref(h), C.byref(w)))
+        e = rel_err(buf, ref)
+        worst = max(worst, e)
+        assert e < REL_TOL, (spec.name, e)
+    print(f"winograd tile {tile} min_cin {min_cin}: worst per-layer rel err {worst:.2e}")
     c2.close()
