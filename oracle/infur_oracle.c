@@ -418,7 +418,8 @@ static void conv2d(const float* in, uint32_t cin, uint32_t h, uint32_t w, const 
                     /* valid ox range: 0 <= ox*stride - pad + kx*dil < w */
                     int64_t off_x = (int64_t)kx * dil - pad;
                     int64_t ox0 = off_x < 0 ? (-off_x + stride - 1) / stride : 0;
-                    int64_t ox1 = ((int64_t)w - 1 - off_x) / stride; /* inclusive */
+                    int64_t num = (int64_t)w - 1 - off_x;
+                    int64_t ox1 = num < 0 ? -1 : num / stride; /* inclusive; floor, not C's truncation */
                     if (ox1 >= (int64_t)ow) ox1 = ow - 1;
                     for (uint32_t oy = 0; oy < oh; oy++) {
                         int64_t iy = (int64_t)oy * stride - pad + (int64_t)ky * dil;

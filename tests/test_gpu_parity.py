@@ -453,3 +453,20 @@ def test_winograd_variants_per_layer(blob50, tile, min_cin):
         assert e < REL_TOL, (spec.name, e)
     print(f"winograd tile {tile} min_cin {min_cin}: worst per-layer rel err {worst:.2e}")
     c2.close()
+
+
+@pytest.mark.parametrize("wh", [(1, 1), (7, 5), (33, 17), (8, 8), (130, 66)])
+def test_tiny_and_ragged_frames(ctx, model, oracle_model, wh):
+    """Degenerate sizes: 1-pixel feature maps, ragged GEMM tiles, partial Winograd tiles."""
+    w, h = wh
+    fr = W.synth_frame(h, w, index=w + h)
+    rgba, _ = FramePath(ctx).advance(fr, 1.0)
+    lo, la = model.lowres()
+    ref = oracle_model.model_forward(oracle_model.pack_normalize(fr), full=False)
+    assert lo.shape == ref["out_low"].shape
+    assert rel_err(lo, ref["out_low"]) < REL_TOL and rel_err(la, ref["aux_low"]) < REL_TOL
+    assert (rgba == oracle_model.colorcode(oracle_model.upsample_bilinear(lo, h, w))).all()
+    out = []
+    model.advance(fr, out)
+    assert out[0].shape == (21, h, w)
+    assert (out[0].view(np.uint32) == oracle_model.upsample_bilinear(lo, h, w).view(np.uint32)).all()

@@ -127,6 +127,20 @@ def test_c_oracle_vs_torch_oracle(oracle_model, blob50):
         assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
 
 
+@pytest.mark.parametrize("wh", [(1, 1), (3, 3), (2, 5), (9, 4)])
+def test_c_oracle_vs_torch_oracle_tiny_frames(oracle_model, blob50, wh):
+    """1-pixel feature maps: stride-2 convs whose taps fall entirely outside (floor, not truncation)."""
+    from oracle.infur_oracle import TorchModel
+
+    w, h = wh
+    fr = W.synth_frame(h, w, index=w + h)
+    chw = oracle_model.pack_normalize(fr)
+    r = oracle_model.model_forward(chw, full=False)
+    tl, ta = TorchModel(blob50).forward_lowres(chw)
+    for a, b in ((r["out_low"], tl.numpy()), (r["aux_low"], ta.numpy())):
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
+
+
 def test_upsample_integer_ratio(oracle):
     """x8 up-sample: interior samples follow the half-pixel rule, borders clamp."""
     x = np.arange(12, dtype=np.float32).reshape(1, 3, 4)
