@@ -219,7 +219,18 @@ int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint3
 int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t rgba_capacity, uint8_t* scaled_bgr,
                              uint64_t* frame_id, uint32_t* ow, uint32_t* oh);
 
+/* ---- frame batch (BASELINE configs[3]: a batch of independent frames; across GPUs the host
+ * layer gives each rank a contiguous slice, infur_amd/dist.py) ----
+ * n frames through the fused path on this context, masks written in frame order.  Internally a
+ * depth-3 ring, so uploads / kernels / downloads of neighbouring frames overlap.  frames[i] is
+ * ws[i] x hs[i] packed BGR; rgba[i] has caps[i] bytes; ows/ohs (optional) receive mask dims. */
+int32_t infur_batch_advance(infur_ctx* ctx, const uint8_t* const* frames, const uint32_t* ws,
+                            const uint32_t* hs, uint32_t n, float factor, uint32_t scale_mode,
+                            uint8_t* const* rgba, const size_t* caps, uint32_t* ows, uint32_t* ohs);
+
 /* ---- profiling (options.profile = 1) ---- */
+/* switch per-kernel event recording on/off at run time (e.g. only for the last frame of a timed run) */
+int32_t infur_profile_enable(infur_ctx* ctx, uint32_t on);
 /* number of kernel records of the last advance (synchronises the stream) */
 int32_t infur_profile_count(infur_ctx* ctx, uint32_t* n);
 int32_t infur_profile_get(infur_ctx* ctx, uint32_t i, infur_kernel_record* rec);

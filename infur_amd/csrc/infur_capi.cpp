@@ -1213,7 +1213,47 @@ int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t cap, uint8_
     return INFUR_OK;
 }
 
+// ---- frame batch ----
+int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const uint32_t* ws, const uint32_t* hs, uint32_t n,
+                            float factor, uint32_t mode, uint8_t* const* rgba, const size_t* caps, uint32_t* ows,
+                            uint32_t* ohs) {
+    if (!c || (n && (!frames || !ws || !hs || !rgba || !caps))) return INFUR_E_INVALID_ARG;
+    if (n == 0) return INFUR_OK;
+    infur_stream* st = nullptr;
+    RETIF(infur_stream_create(c, 3, &st));
+    int32_t rc = INFUR_OK;
+    uint32_t done = 0;
+    auto collect_one = [&]() -> int32_t {
+        uint64_t id = 0;
+        uint32_t ow = 0, oh = 0;
+        int32_t r = infur_stream_next_dims(st, &id, &ow, &oh);
+        if (r != INFUR_OK) return r;
+        r = infur_stream_collect(st, rgba[id], caps[id], nullptr, &id, &ow, &oh);
+        if (r == INFUR_OK) {
+            if (ows) ows[id] = ow;
+            if (ohs) ohs[id] = oh;
+            done++;
+        }
+        return r;
+    };
+    for (uint32_t i = 0; i < n && rc == INFUR_OK; i++) {
+        if (infur_stream_pending(st) >= 3) rc = collect_one();
+        if (rc == INFUR_OK) rc = infur_stream_submit(st, frames[i], ws[i], hs[i], factor, mode, i);
+    }
+    while (rc == INFUR_OK && infur_stream_pending(st) > 0) rc = collect_one();
+    const std::string keep = c->err;  // destroy() synchronises and must not lose the message
+    infur_stream_destroy(st);
+    c->err = keep;
+    return rc;
+}
+
 // ---- profiling ----
+int32_t infur_profile_enable(infur_ctx* c, uint32_t on) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    c->opt.profile = on ? 1 : 0;
+    return INFUR_OK;
+}
+
 int32_t infur_profile_count(infur_ctx* c, uint32_t* n) {
     if (!c || !n) return INFUR_E_INVALID_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -391,6 +391,27 @@ class FramePath:
         self.ctx.check(rc)
         return rgba, scaled
 
+    def advance_batch(self, imgs, factor: float = 1.0):
+        """A batch of independent frames (BASELINE configs[3]) -> list of masks, in order."""
+        L = self.ctx.L
+        imgs = [_check_bgr(i) for i in imgs]
+        n = len(imgs)
+        f = float(np.float32(factor))
+        outs = []
+        for im in imgs:
+            ow, oh = C.c_uint32(0), C.c_uint32(0)
+            rc = L.infur_scale_out_dims(im.shape[1], im.shape[0], f, C.byref(ow), C.byref(oh))
+            if rc:
+                raise ScaleProcError(rc)
+            outs.append(np.empty((oh.value, ow.value, 4), np.uint8))
+        fp = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ws = (C.c_uint32 * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_uint32 * n)(*[im.shape[0] for im in imgs])
+        caps = (C.c_size_t * n)(*[o.nbytes for o in outs])
+        self.ctx.check(L.infur_batch_advance(self.ctx.h, fp, ws, hs, n, f, self.scale_mode, op, caps, None, None))
+        return outs
+
     def advance_dev(self, d_bgr: int, w: int, h: int, factor: float, d_rgba: int, rgba_capacity: int,
                     d_scaled: int = 0):
         """Device-resident form: pointers are raw device addresses; asynchronous on ctx.stream."""

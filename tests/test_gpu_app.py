@@ -167,3 +167,15 @@ def test_streaming_full_size_throughput(ctx, model):
     print(f"streamed 1080p->960x540: {n / el:.1f} frames/s from host buffers (PCIe inclusive)")
     assert n / el > 30.0  # the 30 fps stream of configs[2] is sustained
     sp.close()
+
+
+def test_batch_advance(ctx, model):
+    """BASELINE configs[3] on one rank: a batch of independent frames (mixed sizes) == frame by frame."""
+    imgs = [W.synth_frame(96 + 8 * (i % 3), 128, index=i) for i in range(8)]
+    fp = FramePath(ctx)
+    masks = fp.advance_batch(imgs, 0.5)
+    assert len(masks) == 8
+    for im, m in zip(imgs, masks):
+        ref, _ = fp.advance(im, 0.5)
+        assert m.shape == ref.shape and (m == ref).all()
+    assert fp.advance_batch([], 1.0) == []
