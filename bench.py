@@ -202,7 +202,12 @@ def main():
             k3 = {c.name for c in W.graph(a.depth) if c.k == 3}
             peak = PEAK_F32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_F16_MFMA_TFLOPS
             conv = [r for r in recs if r["kernel"].startswith("conv_igemm_")]
-            dom = [r for r in conv if r["kernel"] == f"conv_igemm_{a.dtype}<128,128>"]
+            # dominant kernel = the tile configuration of conv_igemm that takes the most time in a frame
+            by_cfg = {}
+            for r in conv:
+                by_cfg[r["kernel"]] = by_cfg.get(r["kernel"], 0.0) + r["ms"]
+            dom_name = max(by_cfg, key=by_cfg.get)
+            dom = [r for r in conv if r["kernel"] == dom_name]
             c3 = [r for r in conv if r["name"] in k3]
             c1 = [r for r in conv if r["name"] not in k3]
             wino = [r for r in recs if r["kernel"].startswith("wino_")]
@@ -212,7 +217,9 @@ def main():
             traffic = None
             tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tj) and (Wd, H, a.scale) == (1920, 1080, 1.0):
-                t = json.load(open(tj))["kernels"].get("conv_igemm_kernel<float, float, 128, 128, 2, 2>") if a.dtype == "f32" and a.depth == 50 else None
+                bm, bn = dom_name.split("<")[1].rstrip(">").split(",")
+                waves = {"128,256": "2, 4", "256,32": "4, 1"}.get(f"{bm},{bn}", "2, 2")
+                t = json.load(open(tj))["kernels"].get(f"conv_igemm_kernel<float, float, {bm}, {bn}, {waves}>") if a.dtype == "f32" and a.depth == 50 else None
                 if t:
                     traffic = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
             others = {}
@@ -233,7 +240,8 @@ def main():
             algo_dom = sum(r["algo_flops"] for r in dom)
             ach = algo_dom / max(ms(dom) + dom_tf_ms, 1e-9) / 1e9
             out["roofline"] = {
-                "bound": "mfma", "kernel": f"conv_igemm_kernel<{a.dtype}, 128,128,2,2> ({len(dom)} of the {len(conv)} conv launches of a frame)",
+                "bound": "mfma", "kernel": f"{dom_name} ({len(dom)} of the {len(conv)} conv launches of a frame; tile "
+                                            f"configurations per layer shape are picked by measurement: {dict((k, round(v, 3)) for k, v in by_cfg.items())} ms)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes "
                                                     "(profiles/traffic_latest.json); null if not collected for this shape",

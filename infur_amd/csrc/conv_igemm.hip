@@ -363,27 +363,69 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- tile configurations ----
+// All configurations accumulate k in the same order for every output element, so the choice only
+// changes speed, never a single bit of the result.
+struct CfgInfo {
+    int bm, bn;
+    const char* f32_name;
+    const char* f16_name;
+};
+static const CfgInfo kCfgs[] = {
+    {128, 128, "conv_igemm_f32<128,128>", "conv_igemm_f16<128,128>"},
+    {64, 128, "conv_igemm_f32<64,128>", "conv_igemm_f16<64,128>"},
+    {128, 64, "conv_igemm_f32<128,64>", "conv_igemm_f16<128,64>"},
+    {64, 64, "conv_igemm_f32<64,64>", "conv_igemm_f16<64,64>"},
+    {256, 32, "conv_igemm_f32<256,32>", "conv_igemm_f16<256,32>"},
+    {128, 256, "conv_igemm_f32<128,256>", "conv_igemm_f16<128,256>"},
+};
+constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+
+int conv_igemm_num_configs() { return kNumCfgs; }
+
+const char* conv_igemm_config_name(int cfg, int f16) {
+    if (cfg < 0 || cfg >= kNumCfgs) return "conv_igemm<?>";
+    return f16 ? kCfgs[cfg].f16_name : kCfgs[cfg].f32_name;
+}
+
+// the heuristic used when no measurement is available
+int conv_igemm_default_config(const ConvArgs& a) {
+    if (a.Cout >= 128) return 0;
+    if (a.Cout > 32) return 2;
+    return 4;
+}
+
+// a configuration is a candidate when its N tile is not mostly padding
+bool conv_igemm_config_valid(const ConvArgs& a, int cfg) {
+    if (cfg < 0 || cfg >= kNumCfgs) return false;
+    const int bn = kCfgs[cfg].bn;
+    if (a.Cout <= 32) return bn == 32;
+    if (bn == 32) return false;
+    return bn <= a.Cout || bn == 64;  // Cout = 64 -> BN 64 only; Cout >= 128 -> 64 and 128 (and 256 when Cout >= 256)
+}
+
 template <typename T, typename OutT>
-static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
     constexpr size_t ES = sizeof(T);
     if (a.Cin % (int)(ROW_BYTES / ES) != 0) return hipErrorInvalidValue;
     // 32-bit buffer offsets with 0x80000000 as the out-of-range marker
     if ((size_t)a.H * a.W * a.Cin * ES >= 0x80000000ull || (size_t)a.Cout * a.KH * a.KW * a.Cin * ES >= 0x80000000ull)
         return hipErrorInvalidValue;
-    if (a.Cout >= 128) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
-    if (a.Cout > 32) return launch_cfg<T, OutT, 128, 64, 2, 2>(a, s);
-    return launch_cfg<T, OutT, 256, 32, 4, 1>(a, s);
+    if (cfg < 0) cfg = conv_igemm_default_config(a);
+    switch (cfg) {
+        case 0: return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
+        case 1: return launch_cfg<T, OutT, 64, 128, 2, 2>(a, s);
+        case 2: return launch_cfg<T, OutT, 128, 64, 2, 2>(a, s);
+        case 3: return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
+        case 4: return launch_cfg<T, OutT, 256, 32, 4, 1>(a, s);
+        case 5: return launch_cfg<T, OutT, 128, 256, 2, 4>(a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
-hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, hipStream_t s) {
-    if (!f16) return launch_t<float, float>(a, s);
-    return out_f32 ? launch_t<_Float16, float>(a, s) : launch_t<_Float16, _Float16>(a, s);
-}
-
-const char* conv_igemm_config(const ConvArgs& a, int f16) {
-    if (a.Cout >= 128) return f16 ? "conv_igemm_f16<128,128>" : "conv_igemm_f32<128,128>";
-    if (a.Cout > 32) return f16 ? "conv_igemm_f16<128,64>" : "conv_igemm_f32<128,64>";
-    return f16 ? "conv_igemm_f16<256,32>" : "conv_igemm_f32<256,32>";
+hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, int cfg, hipStream_t s) {
+    if (!f16) return launch_t<float, float>(a, cfg, s);
+    return out_f32 ? launch_t<_Float16, float>(a, cfg, s) : launch_t<_Float16, _Float16>(a, cfg, s);
 }
 
 }  // namespace infur

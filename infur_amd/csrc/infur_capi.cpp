@@ -18,7 +18,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -95,6 +97,9 @@ struct infur_ctx {
     // profiling
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_free;
+
+    // measured tile configuration per conv shape (see pick_cfg)
+    std::map<std::array<int, 13>, int> tuned;
 };
 
 namespace {
@@ -458,6 +463,45 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     return INFUR_OK;
 }
 
+// ---- tile configuration of the conv kernel for one problem shape ----
+// The first time a shape is seen (a new frame size), every candidate configuration is launched
+// for real on the actual operands and timed with HIP events; the fastest is remembered for the
+// context's lifetime.  All configurations give bit-identical outputs, so the trial launches are
+// simply redundant evaluations of the layer.
+int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int f16, int out_f32, int* cfg) {
+    *cfg = conv_igemm_default_config(a);
+    if (c->opt.no_autotune) return INFUR_OK;
+    const std::array<int, 13> key = {a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.stride, a.dil, a.batch,
+                                     a.res ? 1 : 0, f16, out_f32};
+    auto it = c->tuned.find(key);
+    if (it != c->tuned.end()) {
+        *cfg = it->second;
+        return INFUR_OK;
+    }
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int k = 0; k < conv_igemm_num_configs(); k++) {
+        if (!conv_igemm_config_valid(a, k)) continue;
+        HIPCHK(c, launch_conv_igemm(a, f16, out_f32, k, c->stream));  // warm-up (attributes, caches)
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        for (int r = 0; r < 2; r++) HIPCHK(c, launch_conv_igemm(a, f16, out_f32, k, c->stream));
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) {
+            best = ms;
+            *cfg = k;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    c->tuned[key] = *cfg;
+    return INFUR_OK;
+}
+
 // ---- one convolution on the implicit-GEMM kernel ----
 int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, Tensor* out) {
     const int oh = conv_out(in.h, L.k, L.stride, L.pad, L.dil), ow = conv_out(in.w, L.k, L.stride, L.pad, L.dil);
@@ -482,10 +526,12 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
         g.batch = P;
         g.in_bs = (size_t)T * in.c * 4; g.wt_bs = (size_t)L.cout * L.cin * 4; g.out_bs = (size_t)T * L.cout * 4;
+        int gcfg = -1;
+        RETIF(pick_cfg(c, g, 0, 1, &gcfg));
         {
-            ProfScope ps(c, L.name, conv_igemm_config(g, 0), 2.0 * P * T * (double)L.cout * L.cin,
+            ProfScope ps(c, L.name, conv_igemm_config_name(gcfg, 0), 2.0 * P * T * (double)L.cout * L.cin,
                          (double)V.bytes() + (double)M.bytes() + (double)P * L.cout * L.cin * 4, direct);
-            HIPCHK(c, launch_conv_igemm(g, 0, 1, c->stream));
+            HIPCHK(c, launch_conv_igemm(g, 0, 1, gcfg, c->stream));
         }
         pool_release(c, V);
         {
@@ -503,9 +549,11 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
     const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
     const double bytes = (double)in.bytes() + (double)out->bytes() + (res ? (double)res->bytes() : 0.0) +
                          (double)L.cout * L.cin * L.k * L.k * in.es;
+    int cfg = -1;
+    RETIF(pick_cfg(c, a, f16, out_f32, &cfg));
     {
-        ProfScope ps(c, L.name, conv_igemm_config(a, f16), flops, bytes);
-        HIPCHK(c, launch_conv_igemm(a, f16, out_f32, c->stream));
+        ProfScope ps(c, L.name, conv_igemm_config_name(cfg, f16), flops, bytes);
+        HIPCHK(c, launch_conv_igemm(a, f16, out_f32, cfg, c->stream));
     }
     if (c->opt.keep_activations) c->kept.push_back(*out);
     return INFUR_OK;

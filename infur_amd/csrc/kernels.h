@@ -26,9 +26,13 @@ struct ConvArgs {
 
 // conv as implicit GEMM on the matrix cores.  f16 = 0: f32 operands (Cin % 32 == 0);
 // f16 = 1: f16 operands, f32 accumulation (Cin % 64 == 0), output f16 or (out_f32) f32.
-hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, hipStream_t s);
-// name of the tile configuration launch_conv_igemm picks for these arguments
-const char* conv_igemm_config(const ConvArgs& a, int f16);
+// cfg: tile configuration index (conv_igemm_num_configs), -1 = built-in heuristic.  Every
+// configuration produces bit-identical results; only the speed differs.
+hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, int cfg, hipStream_t s);
+int conv_igemm_num_configs();
+int conv_igemm_default_config(const ConvArgs& a);
+bool conv_igemm_config_valid(const ConvArgs& a, int cfg);
+const char* conv_igemm_config_name(int cfg, int f16);
 
 // Winograd F(mt x mt, 3x3), mt = 2 or 4, for stride-1 3x3 convs (f32, any dilation d with pad = d);
 // (mt+2)^2 transform planes; see winograd.hip
