@@ -42,7 +42,10 @@ constexpr unsigned OOB = 0x80000000u;
 
 // T = operand type (float: v_mfma_f32_32x32x2_f32, exact f32; _Float16: v_mfma_f32_32x32x16_f16
 // with f32 accumulation), OutT = type of the stored activation (f32 for the classifier logits).
-template <typename T, typename OutT, int BM, int BN, int WM, int WN>
+// NBUF = 2: double-buffered LDS, one barrier per K step (the latency-optimised form).
+// NBUF = 1: one LDS image, two barriers per K step -- half the LDS footprint, so twice the
+// workgroups per CU cover each other's stalls (the occupancy-optimised form).
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
     conv_igemm_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
     constexpr bool F32 = std::is_same<T, float>::value;
@@ -57,8 +60,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                     // [2][BM][LDS_ROW]
-    char* Bs = smem + 2 * BM * LDS_ROW;  // [2][BN][LDS_ROW]
+    char* As = smem;                        // [NBUF][BM][LDS_ROW]
+    char* Bs = smem + NBUF * BM * LDS_ROW;  // [NBUF][BN][LDS_ROW]
 
     // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of
     // tiles (n fastest) so the N-tiles that share an activation tile share one L2.
@@ -280,12 +283,48 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     store_step(0);
     if (ksteps > 1) load_step(1);
     __syncthreads();
-    read_frags(0, 0, fa, fb);
 
-    int ks = 0;
-    for (; ks + 2 < ksteps; ks++) k_step(ks, Y, Y, Y);  // steady state
-    if (ks + 1 < ksteps) k_step(ks++, Y, N, Y);          // last but one: nothing left to load
-    k_step(ks, N, N, N);                                 // last: nothing left to stage
+    if constexpr (NBUF == 2) {
+        read_frags(0, 0, fa, fb);
+        int ks = 0;
+        for (; ks + 2 < ksteps; ks++) k_step(ks, Y, Y, Y);  // steady state
+        if (ks + 1 < ksteps) k_step(ks++, Y, N, Y);          // last but one: nothing left to load
+        k_step(ks, N, N, N);                                 // last: nothing left to stage
+    } else {
+        // single LDS image: compute a K step, barrier, overwrite the image with the registers
+        // (K step ks+1), refill the registers (ks+2), barrier.  Fragment prefetch only within a step.
+        for (int ks = 0; ks < ksteps; ks++) {
+            read_frags(0, 0, fa, fb);
+#pragma unroll
+            for (int kk = 0; kk < NSL; kk++) {
+                if (kk < NSL - 1) read_frags(0, kk + 1, fa_n, fb_n);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        if constexpr (F32) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
+                                                                             __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                for (int i = 0; i < TM; i++) fa[i] = fa_n[i];
+#pragma unroll
+                for (int j = 0; j < TN; j++) fb[j] = fb_n[j];
+            }
+            if (ks + 1 < ksteps) {
+                __syncthreads();  // every wave has read the image
+                store_step(0);
+                if (ks + 2 < ksteps) load_step(ks + 2);
+                __syncthreads();  // the new image is complete
+            }
+        }
+    }
 
     // epilogue: + bias, + residual, ReLU.  The MFMA was issued with the weight fragment as the
     // row operand, so in the 32x32 C/D layout (col = lane & 31, row = (e & 3) + 8 * (e >> 2) +
@@ -345,13 +384,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM;
     const int ntiles = (a.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_ROW;
-    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN>;
+    const size_t lds = (size_t)NBUF * (BM + BN) * LDS_ROW;
+    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -378,6 +417,11 @@ static const CfgInfo kCfgs[] = {
     {64, 64, "conv_igemm_f32<64,64>", "conv_igemm_f16<64,64>"},
     {256, 32, "conv_igemm_f32<256,32>", "conv_igemm_f16<256,32>"},
     {128, 256, "conv_igemm_f32<128,256>", "conv_igemm_f16<128,256>"},
+    {256, 128, "conv_igemm_f32<256,128>", "conv_igemm_f16<256,128>"},
+    {128, 128, "conv_igemm_f32<128,128,1buf>", "conv_igemm_f16<128,128,1buf>"},
+    {128, 64, "conv_igemm_f32<128,64,1buf>", "conv_igemm_f16<128,64,1buf>"},
+    {64, 128, "conv_igemm_f32<64,128,1buf>", "conv_igemm_f16<64,128,1buf>"},
+    {64, 64, "conv_igemm_f32<64,64,1buf>", "conv_igemm_f16<64,64,1buf>"},
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -419,6 +463,11 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 3: return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
         case 4: return launch_cfg<T, OutT, 256, 32, 4, 1>(a, s);
         case 5: return launch_cfg<T, OutT, 128, 256, 2, 4>(a, s);
+        case 6: return launch_cfg<T, OutT, 256, 128, 4, 2>(a, s);
+        case 7: return launch_cfg<T, OutT, 128, 128, 2, 2, 1>(a, s);
+        case 8: return launch_cfg<T, OutT, 128, 64, 2, 2, 1>(a, s);
+        case 9: return launch_cfg<T, OutT, 64, 128, 2, 2, 1>(a, s);
+        case 10: return launch_cfg<T, OutT, 64, 64, 2, 2, 1>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

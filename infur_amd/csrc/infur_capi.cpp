@@ -470,6 +470,12 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
 // simply redundant evaluations of the layer.
 int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int f16, int out_f32, int* cfg) {
     *cfg = conv_igemm_default_config(a);
+    // test hook: INFUR_CONV_CFG=<k> forces configuration k wherever it is a candidate
+    static const int forced = getenv("INFUR_CONV_CFG") ? atoi(getenv("INFUR_CONV_CFG")) : -1;
+    if (forced >= 0) {
+        if (conv_igemm_config_valid(a, forced)) *cfg = forced;
+        return INFUR_OK;
+    }
     if (c->opt.no_autotune) return INFUR_OK;
     const std::array<int, 13> key = {a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.stride, a.dil, a.batch,
                                      a.res ? 1 : 0, f16, out_f32};
