@@ -217,9 +217,12 @@ def main():
             traffic = None
             tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tj) and (Wd, H, a.scale) == (1920, 1080, 1.0):
-                bm, bn = dom_name.split("<")[1].rstrip(">").split(",")
-                waves = {"128,256": "2, 4", "256,32": "4, 1"}.get(f"{bm},{bn}", "2, 2")
-                t = json.load(open(tj))["kernels"].get(f"conv_igemm_kernel<float, float, {bm}, {bn}, {waves}>") if a.dtype == "f32" and a.depth == 50 else None
+                parts = dom_name.split("<")[1].rstrip(">").split(",")  # "64,64" or "64,64,1buf"
+                bm, bn = parts[0], parts[1]
+                nbuf = "1" if len(parts) > 2 else "2"
+                waves = {"128,256": "2, 4", "256,128": "4, 2", "256,32": "4, 1"}.get(f"{bm},{bn}", "2, 2")
+                key = f"conv_igemm_kernel<float, float, {bm}, {bn}, {waves}, {nbuf}>"
+                t = json.load(open(tj))["kernels"].get(key) if a.dtype == "f32" and a.depth == 50 else None
                 if t:
                     traffic = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
             others = {}

@@ -231,6 +231,14 @@ int32_t infur_batch_advance(infur_ctx* ctx, const uint8_t* const* frames, const 
                             const uint32_t* hs, uint32_t n, float factor, uint32_t scale_mode,
                             uint8_t* const* rgba, const size_t* caps, uint32_t* ows, uint32_t* ohs);
 
+/* ---- tuning database (tile configuration per conv shape, see options.no_autotune) ----
+ * Text form: one line per shape, 13 shape integers + the configuration index.  Importing a
+ * database makes the kernel mix reproducible from run to run and skips the trial launches of
+ * the first frame; shapes it does not list are still measured on first use.  Results never
+ * depend on it (all configurations are bit-identical). */
+int32_t infur_tune_export(infur_ctx* ctx, char* buf, size_t cap, size_t* len);
+int32_t infur_tune_import(infur_ctx* ctx, const char* text, size_t len);
+
 /* ---- profiling (options.profile = 1) ---- */
 /* switch per-kernel event recording on/off at run time (e.g. only for the last frame of a timed run) */
 int32_t infur_profile_enable(infur_ctx* ctx, uint32_t on);

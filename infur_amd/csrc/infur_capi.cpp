@@ -100,6 +100,7 @@ struct infur_ctx {
 
     // measured tile configuration per conv shape (see pick_cfg)
     std::map<std::array<int, 13>, int> tuned;
+    bool tune_warm = false;
 };
 
 namespace {
@@ -480,25 +481,34 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int f16, int out_f32, int* cfg
     const std::array<int, 13> key = {a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.stride, a.dil, a.batch,
                                      a.res ? 1 : 0, f16, out_f32};
     auto it = c->tuned.find(key);
-    if (it != c->tuned.end()) {
+    if (it != c->tuned.end() && conv_igemm_config_valid(a, it->second)) {
         *cfg = it->second;
         return INFUR_OK;
     }
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
+    if (!c->tune_warm) {  // bring clocks and caches to their steady state before the first measurement
+        for (int r = 0; r < 12; r++) HIPCHK(c, launch_conv_igemm(a, f16, out_f32, *cfg, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->tune_warm = true;
+    }
     float best = 1e30f;
     for (int k = 0; k < conv_igemm_num_configs(); k++) {
         if (!conv_igemm_config_valid(a, k)) continue;
         HIPCHK(c, launch_conv_igemm(a, f16, out_f32, k, c->stream));  // warm-up (attributes, caches)
-        HIPCHK(c, hipEventRecord(e0, c->stream));
-        for (int r = 0; r < 2; r++) HIPCHK(c, launch_conv_igemm(a, f16, out_f32, k, c->stream));
-        HIPCHK(c, hipEventRecord(e1, c->stream));
-        HIPCHK(c, hipEventSynchronize(e1));
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-        if (ms < best) {
-            best = ms;
+        float fastest = 1e30f;
+        for (int r = 0; r < 4; r++) {  // minimum of 4 single-launch timings
+            HIPCHK(c, hipEventRecord(e0, c->stream));
+            HIPCHK(c, launch_conv_igemm(a, f16, out_f32, k, c->stream));
+            HIPCHK(c, hipEventRecord(e1, c->stream));
+            HIPCHK(c, hipEventSynchronize(e1));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+            if (ms < fastest) fastest = ms;
+        }
+        if (fastest < best) {
+            best = fastest;
             *cfg = k;
         }
     }
@@ -1299,6 +1309,48 @@ int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const ui
     infur_stream_destroy(st);
     c->err = keep;
     return rc;
+}
+
+// ---- tuning database ----
+int32_t infur_tune_export(infur_ctx* c, char* buf, size_t cap, size_t* len) {
+    if (!c || !len) return INFUR_E_INVALID_ARG;
+    std::string out;
+    char line[256];
+    for (const auto& kv : c->tuned) {
+        int n = 0;
+        for (int v : kv.first) n += snprintf(line + n, sizeof line - n, "%d ", v);
+        snprintf(line + n, sizeof line - n, "%d\n", kv.second);
+        out += line;
+    }
+    *len = out.size();
+    if (!buf) return INFUR_OK;
+    if (cap < out.size()) return fail(c, INFUR_E_CAPACITY, "tuning text needs %zu bytes", out.size());
+    memcpy(buf, out.data(), out.size());
+    return INFUR_OK;
+}
+
+int32_t infur_tune_import(infur_ctx* c, const char* text, size_t len) {
+    if (!c || (!text && len)) return INFUR_E_INVALID_ARG;
+    std::string t(text ? text : "", len);
+    size_t pos = 0;
+    while (pos < t.size()) {
+        size_t eol = t.find('\n', pos);
+        if (eol == std::string::npos) eol = t.size();
+        const std::string ln = t.substr(pos, eol - pos);
+        pos = eol + 1;
+        if (ln.empty() || ln[0] == '#') continue;
+        std::array<int, 13> key;
+        int cfg = -1, off = 0, n = 0;
+        bool ok = true;
+        for (int i = 0; i < 13 && ok; i++) {
+            ok = sscanf(ln.c_str() + off, "%d%n", &key[i], &n) == 1;
+            off += n;
+        }
+        ok = ok && sscanf(ln.c_str() + off, "%d", &cfg) == 1;
+        if (!ok || cfg < 0 || cfg >= conv_igemm_num_configs()) return fail(c, INFUR_E_INVALID_ARG, "bad tuning line: %s", ln.c_str());
+        c->tuned[key] = cfg;
+    }
+    return INFUR_OK;
 }
 
 // ---- profiling ----

@@ -15,6 +15,7 @@ exceptions carrying the status code of include/infur_hip.h.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Generic, List, Optional, TypeVar
 
@@ -23,6 +24,9 @@ import numpy as np
 from . import _lib
 
 T = TypeVar("T")
+
+# tile configurations measured on MI355X for the BASELINE configs (scripts/tune.py writes it)
+TUNE_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tune_gfx950.txt")
 
 
 # --------------------------------------------------------------------------- #
@@ -120,6 +124,19 @@ class Context:
                                  f"({L.infur_device_count()} HIP devices visible; there is no CPU fallback)")
         self.h = h
         self.device = device
+        if autotune and os.path.exists(TUNE_DB):  # measured tile configurations for the common shapes
+            self.load_tuning(TUNE_DB)
+
+    def load_tuning(self, path: str) -> None:
+        txt = open(path, "rb").read()
+        self.check(self.L.infur_tune_import(self.h, txt, len(txt)))
+
+    def tuning_text(self) -> str:
+        n = C.c_size_t(0)
+        self.check(self.L.infur_tune_export(self.h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value + 1)
+        self.check(self.L.infur_tune_export(self.h, buf, n.value, C.byref(n)))
+        return buf.raw[: n.value].decode()
 
     def last_error(self) -> str:
         return self.L.infur_last_error(self.h).decode()
