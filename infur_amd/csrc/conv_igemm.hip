@@ -422,6 +422,7 @@ static const CfgInfo kCfgs[] = {
     {128, 64, "conv_igemm_f32<128,64,1buf>", "conv_igemm_f16<128,64,1buf>"},
     {64, 128, "conv_igemm_f32<64,128,1buf>", "conv_igemm_f16<64,128,1buf>"},
     {64, 64, "conv_igemm_f32<64,64,1buf>", "conv_igemm_f16<64,64,1buf>"},
+    {256, 256, "conv_igemm_f32<256,256>", "conv_igemm_f16<256,256>"},
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -468,6 +469,7 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 8: return launch_cfg<T, OutT, 128, 64, 2, 2, 1>(a, s);
         case 9: return launch_cfg<T, OutT, 64, 128, 2, 2, 1>(a, s);
         case 10: return launch_cfg<T, OutT, 64, 64, 2, 2, 1>(a, s);
+        case 11: return launch_cfg<T, OutT, 256, 256, 2, 4>(a, s);  // 8 waves of 128x64: least staging per MFMA
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,23 @@
+"""dev: PCIe-inclusive rates of the host-pointer entry points at 1080p (for DESIGN.md)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from infur_amd import weights as W
+from infur_amd.app import StreamPath
+from infur_amd.processors import Context, FramePath, Model, ModelCmd
+c = Context(device=0); Model(c).control(ModelCmd.LoadBlob(W.synth_blob()))
+frames = [W.synth_frame(1080, 1920, index=i) for i in range(4)]
+fp = FramePath(c)
+for f in frames[:2]: fp.advance(f, 1.0)
+t = time.perf_counter(); n = 16
+for i in range(n): fp.advance(frames[i % 4], 1.0)
+print(f"infur_frame_advance (host buffers, synchronous) 1080p scale 1.0: {n / (time.perf_counter() - t):.1f} frames/s")
+for depth in (2, 3):
+    sp = StreamPath(c, depth=depth)
+    list(sp.run([(i, frames[i % 4]) for i in range(4)], 1.0))
+    t = time.perf_counter(); n = 48
+    out = list(sp.run([(i, frames[i % 4]) for i in range(n)], 1.0))
+    print(f"infur_stream depth {depth} 1080p scale 1.0: {n / (time.perf_counter() - t):.1f} frames/s")
+    sp.close()
+m = fp.advance_batch([frames[i % 4] for i in range(16)], 1.0)
+t = time.perf_counter(); m = fp.advance_batch([frames[i % 4] for i in range(32)], 1.0)
+print(f"infur_batch_advance 32 x 1080p: {32 / (time.perf_counter() - t):.1f} frames/s")

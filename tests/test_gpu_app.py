@@ -2,6 +2,7 @@
 (infur/src/app.rs:175-253) re-expressed on synthetic clips of the same dimensions, plus
 fused-vs-unfused and streamed-vs-direct equality."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -179,3 +180,24 @@ def test_batch_advance(ctx, model):
         ref, _ = fp.advance(im, 0.5)
         assert m.shape == ref.shape and (m == ref).all()
     assert fp.advance_batch([], 1.0) == []
+
+
+def test_stream_cli_raw_bgr24_in_rgba_out(ctx, model, tmp_path):
+    """the CLI reads the ffmpeg image2pipe/bgr24 wire format and writes masks in order."""
+    import subprocess
+    import sys
+
+    frames = [W.synth_frame(96, 160, index=i) for i in range(5)]
+    fin, fout = tmp_path / "clip.bgr", tmp_path / "masks.rgba"
+    fin.write_bytes(b"".join(f.tobytes() for f in frames))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "infur_amd.stream_cli", "--width", "160", "--height", "96", "--scale", "0.5",
+                        "--synthetic-weights", "--input", str(fin), "--output", str(fout)], cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "5 frames" in r.stderr
+    got = np.frombuffer(fout.read_bytes(), np.uint8).reshape(5, 48, 80, 4)
+    fp = FramePath(ctx)
+    for g, f in zip(got, frames):
+        ref, _ = fp.advance(f, 0.5)
+        assert (g == ref).all()
