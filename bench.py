@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU baseline budget")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s"],
                     help="conv-stack arithmetic: f32 (BASELINE configs[1], the default and the parity mode) or f16 "
                          "operands with f32 accumulation (configs[4]'s mode)")
     ap.add_argument("--winograd-min-cin", type=int, default=0,
@@ -200,7 +200,8 @@ def main():
         if not a.no_profile:
             recs = ctx.profile()
             k3 = {c.name for c in W.graph(a.depth) if c.k == 3}
-            peak = PEAK_F32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_F16_MFMA_TFLOPS
+            # f32s: three f16 MFMAs per product -> the ceiling for f32-equivalent FLOPs is a third of the f16 peak
+            peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "f32s": PEAK_F16_MFMA_TFLOPS / 3.0}[a.dtype]
             conv = [r for r in recs if r["kernel"].startswith("conv_igemm_")]
             # dominant kernel = the tile configuration of conv_igemm that takes the most time in a frame
             by_cfg = {}

@@ -61,8 +61,12 @@ enum {
 /* arithmetic type of the conv stack */
 enum {
     INFUR_DTYPE_F32 = 0, /* exact f32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode */
-    INFUR_DTYPE_F16 = 1  /* f16 activations/weights on v_mfma_f32_32x32x16_f16, f32 accumulation,
+    INFUR_DTYPE_F16 = 1, /* f16 activations/weights on v_mfma_f32_32x32x16_f16, f32 accumulation,
                             bias/residual/ReLU in f32, logits f32 (BASELINE configs[4]) */
+    INFUR_DTYPE_F32_SPLIT = 2 /* f32 tensors everywhere; inside the conv GEMMs every operand value is
+                            split into an f16 pair hi + lo (22 significand bits) and the product is
+                            accumulated in f32 from three f16 MFMAs (lo*hi + hi*lo + hi*hi).  f32-grade
+                            logits (tests: <= 2e-5 of the f32 oracle) at a multiple of the f32 MFMA rate */
 };
 
 typedef struct infur_ctx infur_ctx;

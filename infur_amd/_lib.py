@@ -28,6 +28,7 @@ E_CAPACITY = 11
 SCALE_NEAREST, SCALE_BILINEAR = 0, 1
 DTYPE_F32 = 0
 DTYPE_F16 = 1
+DTYPE_F32_SPLIT = 2
 
 
 class Options(C.Structure):

@@ -40,18 +40,41 @@ constexpr int LDS_ROW = ROW_BYTES + 16;
 // load then returns zeros -- branch-free zero padding / tail predication.
 constexpr unsigned OOB = 0x80000000u;
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// four f32 (one staged 16-byte chunk) * scale -> 4 x f16 hi at dst, 4 x f16 lo at dst + 64
+// (round to nearest even twice: |x - hi| <= 2^-11 |x| is exact in f32, so hi + lo = x to 2^-22)
+__device__ __forceinline__ void store_split(char* dst, const u32x4 r, const float scale) {
+    const f32x4 x = __builtin_bit_cast(f32x4, r) * scale;
+    const f16x4 hi = __builtin_convertvector(x, f16x4);
+    const f16x4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), f16x4);
+    *reinterpret_cast<f16x4*>(dst) = hi;
+    *reinterpret_cast<f16x4*>(dst + 64) = lo;
+}
+
 // T = operand type (float: v_mfma_f32_32x32x2_f32, exact f32; _Float16: v_mfma_f32_32x32x16_f16
 // with f32 accumulation), OutT = type of the stored activation (f32 for the classifier logits).
 // NBUF = 2: double-buffered LDS, one barrier per K step (the latency-optimised form).
 // NBUF = 1: one LDS image, two barriers per K step -- half the LDS footprint, so twice the
 // workgroups per CU cover each other's stalls (the occupancy-optimised form).
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF>
+//
+// SPLIT (T = float only): f32 tensors in HBM, f16 matrix cores.  Every f32 value x is split into
+// hi = f16(x) and lo = f16(x - hi) (both round-to-nearest; the subtraction is exact), so hi + lo carries
+// 22 significand bits of x: activations while their tile is staged into LDS (after a power-of-two
+// a_scale that keeps lo out of the f16 subnormals), weights once at model load (launch_split_weights).  The product is accumulated in f32 as
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_f16 (the a_lo*b_lo term, 2^-22 relative,
+// is dropped): f32-grade results (measured against the f32 oracle in tests/) at three f16 MFMAs per
+// f32 MFMA-equivalent, i.e. a ceiling of 2.5 PFLOP/s / 3 = 833 TFLOP/s instead of 157.  An LDS row is
+// [hi: 32 x f16][lo: 32 x f16] (128 bytes, same as the f32 row) and a K step is two 16-wide MFMA slices.
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF, bool SPLIT = false>
 __global__ void __launch_bounds__(WM* WN * 64, 2)
     conv_igemm_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
-    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr bool F32 = std::is_same<T, float>::value && !SPLIT;
+    static_assert(!SPLIT || std::is_same<T, float>::value, "SPLIT stages f32 tensors");
     constexpr int ES = sizeof(T);              // operand element size
     constexpr int BK = ROW_BYTES / ES;         // channels per K step
-    constexpr int NSL = 4;                     // slices per K step (32 bytes of k each)
+    constexpr int NSL = SPLIT ? 2 : 4;         // slices per K step (32 bytes of k each; SPLIT: 16 k as hi + lo)
+    constexpr int NF = SPLIT ? 2 : 1;          // fragment planes per row block (SPLIT: hi, lo)
     constexpr int NT = WM * WN * 64;           // threads
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -163,7 +186,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
-            *reinterpret_cast<u32x4*>(Ab + row * LDS_ROW + c4 * 16) = ra[i];
+            if constexpr (SPLIT)
+                store_split(Ab + row * LDS_ROW + c4 * 8, ra[i], a.a_scale);
+            else
+                *reinterpret_cast<u32x4*>(Ab + row * LDS_ROW + c4 * 16) = ra[i];
         }
     };
     auto store_b = [&](int buf) {
@@ -171,7 +197,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
         for (int i = 0; i < B_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
-            *reinterpret_cast<u32x4*>(Bb + row * LDS_ROW + c4 * 16) = rb[i];
+            *reinterpret_cast<u32x4*>(Bb + row * LDS_ROW + c4 * 16) = rb[i];  // SPLIT: split at load time
         }
     };
     auto store_step = [&](int buf) {
@@ -183,16 +209,44 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // first 16 bytes (4 f32 / 8 f16 consecutive k), lanes 32-63 the second
     const int a_lds = (wm * TM * 32 + (lane & 31)) * LDS_ROW + (lane >> 5) * 16;
     const int b_lds = (wn * TN * 32 + (lane & 31)) * LDS_ROW + (lane >> 5) * 16;
-    auto read_frags = [&](int buf, int kk, float4 (&fa)[TM], float4 (&fb)[TN]) {
+    auto read_frags = [&](int buf, int kk, float4 (&fa)[TM * NF], float4 (&fb)[TN * NF]) {
         const char* Ab = As + buf * BM * LDS_ROW + a_lds + kk * 32;
         const char* Bb = Bs + buf * BN * LDS_ROW + b_lds + kk * 32;
 #pragma unroll
-        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW);
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW);
+            for (int p = 0; p < NF; p++) fa[i * NF + p] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + p * 64);
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int p = 0; p < NF; p++) fb[j * NF + p] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + p * 64);
     };
 
-    float4 fa[TM], fb[TN], fa_n[TM], fb_n[TN];
+    float4 fa[TM * NF], fb[TN * NF], fa_n[TM * NF], fb_n[TN * NF];
+
+    // the MFMAs of one slice.  D rows = output channels, D cols = pixels (operands swapped on purpose)
+    auto mma_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                if constexpr (F32) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
+                } else if constexpr (SPLIT) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, fa[2 * i]), al = __builtin_bit_cast(f16x8, fa[2 * i + 1]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, fb[2 * j]), bl = __builtin_bit_cast(f16x8, fb[2 * j + 1]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
+                                                                     __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
+                }
+            }
+    };
 
     // One K step = 4 slices of 32 bytes of k.  Software pipeline with ONE barrier per K step, placed
     // mid-step, and no control flow inside a step, so the scheduler can hide the staging
@@ -213,27 +267,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 read_frags(buf, kk + 1, fa_n, fb_n);
             else if (NEXT)
                 read_frags(buf ^ 1, 0, fa_n, fb_n);
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    // D rows = output channels, D cols = pixels (operands swapped on purpose)
-                    if constexpr (F32) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
-                                                                         __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
-                    }
-                }
+            mma_slice();
             // staging spread over two slices: activations at slice 0, weights at slice 1
             if (kk == 0 && STORE) {
                 store_a(buf ^ 1);
                 if (LOAD) load_a();
             }
-            if (kk == 1 && STORE) {
+            if (kk == (SPLIT ? 0 : 1) && STORE) {
                 store_b(buf ^ 1);
                 if (LOAD) load_b(ks + 2);
             }
@@ -266,14 +306,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                     __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
                 }
             }
-            if (kk == 2 && STORE) {
+            if (kk == NSL - 2 && STORE) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
 #pragma unroll
-            for (int i = 0; i < TM; i++) fa[i] = fa_n[i];
+            for (int i = 0; i < TM * NF; i++) fa[i] = fa_n[i];
 #pragma unroll
-            for (int j = 0; j < TN; j++) fb[j] = fb_n[j];
+            for (int j = 0; j < TN * NF; j++) fb[j] = fb_n[j];
         }
     };
     constexpr auto Y = std::true_type{};
@@ -298,24 +338,11 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
             for (int kk = 0; kk < NSL; kk++) {
                 if (kk < NSL - 1) read_frags(0, kk + 1, fa_n, fb_n);
+                mma_slice();
 #pragma unroll
-                for (int i = 0; i < TM; i++)
+                for (int i = 0; i < TM * NF; i++) fa[i] = fa_n[i];
 #pragma unroll
-                    for (int j = 0; j < TN; j++) {
-                        if constexpr (F32) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].w, fa[i].w, acc[i][j], 0, 0, 0);
-                        } else {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]),
-                                                                             __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                for (int i = 0; i < TM; i++) fa[i] = fa_n[i];
-#pragma unroll
-                for (int j = 0; j < TN; j++) fb[j] = fb_n[j];
+                for (int j = 0; j < TN * NF; j++) fb[j] = fb_n[j];
             }
             if (ks + 1 < ksteps) {
                 __syncthreads();  // every wave has read the image
@@ -346,13 +373,17 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 if (n >= a.Cout) continue;
                 const size_t o = (size_t)m * a.Cout + n;
                 float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v[t] *= a.acc_scale;
+                }
                 if (vec_ok) {
                     if (has_bias) {
                         const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
                         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                     }
                     if (res) {
-                        if constexpr (F32) {
+                        if constexpr (std::is_same<T, float>::value) {
                             const float4 rv = *reinterpret_cast<const float4*>(res + o);
                             v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                         } else {
@@ -384,13 +415,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF = 2>
+template <typename T, typename OutT, bool SPLIT, int BM, int BN, int WM, int WN, int NBUF = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM;
     const int ntiles = (a.Cout + BN - 1) / BN;
     const size_t lds = (size_t)NBUF * (BM + BN) * LDS_ROW;
-    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF>;
+    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -407,30 +438,29 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 // changes speed, never a single bit of the result.
 struct CfgInfo {
     int bm, bn;
-    const char* f32_name;
-    const char* f16_name;
+    const char* name[3];  // per mode: f32, f16, f32 split into f16 pairs
 };
 static const CfgInfo kCfgs[] = {
-    {128, 128, "conv_igemm_f32<128,128>", "conv_igemm_f16<128,128>"},
-    {64, 128, "conv_igemm_f32<64,128>", "conv_igemm_f16<64,128>"},
-    {128, 64, "conv_igemm_f32<128,64>", "conv_igemm_f16<128,64>"},
-    {64, 64, "conv_igemm_f32<64,64>", "conv_igemm_f16<64,64>"},
-    {256, 32, "conv_igemm_f32<256,32>", "conv_igemm_f16<256,32>"},
-    {128, 256, "conv_igemm_f32<128,256>", "conv_igemm_f16<128,256>"},
-    {256, 128, "conv_igemm_f32<256,128>", "conv_igemm_f16<256,128>"},
-    {128, 128, "conv_igemm_f32<128,128,1buf>", "conv_igemm_f16<128,128,1buf>"},
-    {128, 64, "conv_igemm_f32<128,64,1buf>", "conv_igemm_f16<128,64,1buf>"},
-    {64, 128, "conv_igemm_f32<64,128,1buf>", "conv_igemm_f16<64,128,1buf>"},
-    {64, 64, "conv_igemm_f32<64,64,1buf>", "conv_igemm_f16<64,64,1buf>"},
-    {256, 256, "conv_igemm_f32<256,256>", "conv_igemm_f16<256,256>"},
+    {128, 128, {"conv_igemm_f32<128,128>", "conv_igemm_f16<128,128>", "conv_igemm_f32s<128,128>"}},
+    {64, 128, {"conv_igemm_f32<64,128>", "conv_igemm_f16<64,128>", "conv_igemm_f32s<64,128>"}},
+    {128, 64, {"conv_igemm_f32<128,64>", "conv_igemm_f16<128,64>", "conv_igemm_f32s<128,64>"}},
+    {64, 64, {"conv_igemm_f32<64,64>", "conv_igemm_f16<64,64>", "conv_igemm_f32s<64,64>"}},
+    {256, 32, {"conv_igemm_f32<256,32>", "conv_igemm_f16<256,32>", "conv_igemm_f32s<256,32>"}},
+    {128, 256, {"conv_igemm_f32<128,256>", "conv_igemm_f16<128,256>", "conv_igemm_f32s<128,256>"}},
+    {256, 128, {"conv_igemm_f32<256,128>", "conv_igemm_f16<256,128>", "conv_igemm_f32s<256,128>"}},
+    {128, 128, {"conv_igemm_f32<128,128,1buf>", "conv_igemm_f16<128,128,1buf>", "conv_igemm_f32s<128,128,1buf>"}},
+    {128, 64, {"conv_igemm_f32<128,64,1buf>", "conv_igemm_f16<128,64,1buf>", "conv_igemm_f32s<128,64,1buf>"}},
+    {64, 128, {"conv_igemm_f32<64,128,1buf>", "conv_igemm_f16<64,128,1buf>", "conv_igemm_f32s<64,128,1buf>"}},
+    {64, 64, {"conv_igemm_f32<64,64,1buf>", "conv_igemm_f16<64,64,1buf>", "conv_igemm_f32s<64,64,1buf>"}},
+    {256, 256, {"conv_igemm_f32<256,256>", "conv_igemm_f16<256,256>", "conv_igemm_f32s<256,256>"}},
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
 int conv_igemm_num_configs() { return kNumCfgs; }
 
-const char* conv_igemm_config_name(int cfg, int f16) {
-    if (cfg < 0 || cfg >= kNumCfgs) return "conv_igemm<?>";
-    return f16 ? kCfgs[cfg].f16_name : kCfgs[cfg].f32_name;
+const char* conv_igemm_config_name(int cfg, int mode) {
+    if (cfg < 0 || cfg >= kNumCfgs || mode < 0 || mode > 2) return "conv_igemm<?>";
+    return kCfgs[cfg].name[mode];
 }
 
 // the heuristic used when no measurement is available
@@ -449,7 +479,7 @@ bool conv_igemm_config_valid(const ConvArgs& a, int cfg) {
     return bn <= a.Cout || bn == 64;  // Cout = 64 -> BN 64 only; Cout >= 128 -> 64 and 128 (and 256 when Cout >= 256)
 }
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, bool SPLIT = false>
 static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
     constexpr size_t ES = sizeof(T);
     if (a.Cin % (int)(ROW_BYTES / ES) != 0) return hipErrorInvalidValue;
@@ -458,24 +488,25 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         return hipErrorInvalidValue;
     if (cfg < 0) cfg = conv_igemm_default_config(a);
     switch (cfg) {
-        case 0: return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
-        case 1: return launch_cfg<T, OutT, 64, 128, 2, 2>(a, s);
-        case 2: return launch_cfg<T, OutT, 128, 64, 2, 2>(a, s);
-        case 3: return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
-        case 4: return launch_cfg<T, OutT, 256, 32, 4, 1>(a, s);
-        case 5: return launch_cfg<T, OutT, 128, 256, 2, 4>(a, s);
-        case 6: return launch_cfg<T, OutT, 256, 128, 4, 2>(a, s);
-        case 7: return launch_cfg<T, OutT, 128, 128, 2, 2, 1>(a, s);
-        case 8: return launch_cfg<T, OutT, 128, 64, 2, 2, 1>(a, s);
-        case 9: return launch_cfg<T, OutT, 64, 128, 2, 2, 1>(a, s);
-        case 10: return launch_cfg<T, OutT, 64, 64, 2, 2, 1>(a, s);
-        case 11: return launch_cfg<T, OutT, 256, 256, 2, 4>(a, s);  // 8 waves of 128x64: least staging per MFMA
+        case 0: return launch_cfg<T, OutT, SPLIT, 128, 128, 2, 2>(a, s);
+        case 1: return launch_cfg<T, OutT, SPLIT, 64, 128, 2, 2>(a, s);
+        case 2: return launch_cfg<T, OutT, SPLIT, 128, 64, 2, 2>(a, s);
+        case 3: return launch_cfg<T, OutT, SPLIT, 64, 64, 2, 2>(a, s);
+        case 4: return launch_cfg<T, OutT, SPLIT, 256, 32, 4, 1>(a, s);
+        case 5: return launch_cfg<T, OutT, SPLIT, 128, 256, 2, 4>(a, s);
+        case 6: return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2>(a, s);
+        case 7: return launch_cfg<T, OutT, SPLIT, 128, 128, 2, 2, 1>(a, s);
+        case 8: return launch_cfg<T, OutT, SPLIT, 128, 64, 2, 2, 1>(a, s);
+        case 9: return launch_cfg<T, OutT, SPLIT, 64, 128, 2, 2, 1>(a, s);
+        case 10: return launch_cfg<T, OutT, SPLIT, 64, 64, 2, 2, 1>(a, s);
+        case 11: return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4>(a, s);  // 8 waves of 128x64: least staging per MFMA
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, int cfg, hipStream_t s) {
-    if (!f16) return launch_t<float, float>(a, cfg, s);
+hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, hipStream_t s) {
+    if (mode == 0) return launch_t<float, float>(a, cfg, s);
+    if (mode == 2) return launch_t<float, float, true>(a, cfg, s);
     return out_f32 ? launch_t<_Float16, float>(a, cfg, s) : launch_t<_Float16, _Float16>(a, cfg, s);
 }
 

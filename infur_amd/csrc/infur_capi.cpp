@@ -54,6 +54,8 @@ struct ConvLayer {
     void* d_w = nullptr;   // repacked weights (context dtype; the stem's stay f32)
     float* d_b = nullptr;  // bias, always f32
     float* d_u = nullptr;  // Winograd-domain weights U[16][cout][cin] (f32 stride-1 3x3 convs only)
+    // INFUR_DTYPE_F32_SPLIT: d_w / d_u hold f16 (hi, lo) pairs of w * w_scale / u * u_scale (powers of two)
+    float w_scale = 1.0f, u_scale = 1.0f;
 };
 
 struct ProfRec {
@@ -192,6 +194,8 @@ int32_t talloc(infur_ctx* c, int h, int w, int ch, int es, Tensor* t) {
 }
 
 inline bool ctx_f16(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F16; }
+// GEMM arithmetic of launch_conv_igemm: 0 f32 MFMA, 1 f16, 2 f32 tensors split into f16 pairs
+inline int ctx_mode(const infur_ctx* c) { return (int)c->opt.compute_dtype; }
 inline int act_es(const infur_ctx* c) { return ctx_f16(c) ? 2 : 4; }
 
 // ---- profiling ----
@@ -308,7 +312,7 @@ inline int wino_planes(const infur_ctx* c) { return (wino_mt(c) + 2) * (wino_mt(
 // stride-1 3x3 convs whose direct form is MFMA-bound run in the Winograd domain (f32 mode only:
 // the transforms amplify f16 rounding)
 bool wino_eligible(const infur_ctx* c, const ConvLayer& L) {
-    if (c->opt.compute_dtype != INFUR_DTYPE_F32 || L.k != 3 || L.stride != 1 || L.pad != L.dil) return false;
+    if (ctx_f16(c) || L.k != 3 || L.stride != 1 || L.pad != L.dil) return false;
     const uint32_t thr = c->opt.winograd_min_cin ? c->opt.winograd_min_cin : 256u;
     return thr != 0xFFFFFFFFu && (uint32_t)L.cin >= thr && (L.cin % 32) == 0 && (L.cout % 4) == 0;
 }
@@ -371,6 +375,42 @@ void model_free(infur_ctx* c) {
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// INFUR_DTYPE_F32_SPLIT: scale every conv's GEMM weights (and Winograd-domain weights) by the power of
+// two that puts max |w| in [2^13, 2^14) -- lo = w - hi then stays a normal f16 for all weights within
+// 2^-16 of the largest -- and replace them in place by (hi, lo) f16 pairs.  The stem is not a GEMM.
+int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
+    const size_t n = g.size();
+    float* d_max = nullptr;
+    HIPCHK(c, hipMalloc(&d_max, 2 * n * sizeof(float)));
+    hipError_t e = hipMemsetAsync(d_max, 0, 2 * n * sizeof(float), c->stream);
+    for (size_t i = 0; i < n && e == hipSuccess; i++) {
+        const ConvLayer& L = g[i];
+        if (L.role == 's') continue;
+        e = launch_absmax((const float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, d_max + 2 * i, c->stream);
+        if (e == hipSuccess && L.d_u) e = launch_absmax(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, d_max + 2 * i + 1, c->stream);
+    }
+    std::vector<float> mx(2 * n, 0.0f);
+    if (e == hipSuccess) e = hipMemcpyAsync(mx.data(), d_max, 2 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_max);
+    HIPCHK(c, e);
+    auto pow2_for = [](float amax) {
+        if (!(amax > 0.0f) || !std::isfinite(amax)) return 1.0f;
+        return std::ldexp(1.0f, 13 - std::ilogb(amax));
+    };
+    for (size_t i = 0; i < n; i++) {
+        ConvLayer& L = g[i];
+        if (L.role == 's') continue;
+        L.w_scale = pow2_for(mx[2 * i]);
+        HIPCHK(c, launch_split_weights((float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, L.w_scale, c->stream));
+        if (L.d_u) {
+            L.u_scale = pow2_for(mx[2 * i + 1]);
+            HIPCHK(c, launch_split_weights(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, L.u_scale, c->stream));
+        }
+    }
+    return INFUR_OK;
+}
 
 // d_blob: INFURW01 blob resident on the device.  Parses the directory (copied to the host),
 // checks it against the expected graph and repacks every tensor into kernel layout.
@@ -442,6 +482,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
             HIPCHK(c, launch_wino_weights(src_w, L.cout, L.cin, wino_mt(c), L.d_u, c->stream));
         }
     }
+    if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT) RETIF(split_weights(c, g));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->convs.swap(g);
     c->depth = depth;
@@ -469,7 +510,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
 // for real on the actual operands and timed with HIP events; the fastest is remembered for the
 // context's lifetime.  All configurations give bit-identical outputs, so the trial launches are
 // simply redundant evaluations of the layer.
-int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int f16, int out_f32, int* cfg) {
+int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cfg) {
     *cfg = conv_igemm_default_config(a);
     // test hook: INFUR_CONV_CFG=<k> forces configuration k wherever it is a candidate
     static const int forced = getenv("INFUR_CONV_CFG") ? atoi(getenv("INFUR_CONV_CFG")) : -1;
@@ -479,7 +520,7 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int f16, int out_f32, int* cfg
     }
     if (c->opt.no_autotune) return INFUR_OK;
     const std::array<int, 13> key = {a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.stride, a.dil, a.batch,
-                                     a.res ? 1 : 0, f16, out_f32};
+                                     a.res ? 1 : 0, mode, out_f32};
     auto it = c->tuned.find(key);
     if (it != c->tuned.end() && conv_igemm_config_valid(a, it->second)) {
         *cfg = it->second;
@@ -489,18 +530,18 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int f16, int out_f32, int* cfg
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
     if (!c->tune_warm) {  // bring clocks and caches to their steady state before the first measurement
-        for (int r = 0; r < 12; r++) HIPCHK(c, launch_conv_igemm(a, f16, out_f32, *cfg, c->stream));
+        for (int r = 0; r < 12; r++) HIPCHK(c, launch_conv_igemm(a, mode, out_f32, *cfg, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->tune_warm = true;
     }
     float best = 1e30f;
     for (int k = 0; k < conv_igemm_num_configs(); k++) {
         if (!conv_igemm_config_valid(a, k)) continue;
-        HIPCHK(c, launch_conv_igemm(a, f16, out_f32, k, c->stream));  // warm-up (attributes, caches)
+        HIPCHK(c, launch_conv_igemm(a, mode, out_f32, k, c->stream));  // warm-up (attributes, caches)
         float fastest = 1e30f;
         for (int r = 0; r < 4; r++) {  // minimum of 4 single-launch timings
             HIPCHK(c, hipEventRecord(e0, c->stream));
-            HIPCHK(c, launch_conv_igemm(a, f16, out_f32, k, c->stream));
+            HIPCHK(c, launch_conv_igemm(a, mode, out_f32, k, c->stream));
             HIPCHK(c, hipEventRecord(e1, c->stream));
             HIPCHK(c, hipEventSynchronize(e1));
             float ms = 0;
@@ -518,11 +559,16 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int f16, int out_f32, int* cfg
     return INFUR_OK;
 }
 
+// INFUR_DTYPE_F32_SPLIT: activations are multiplied by 2^4 while they are staged: |x| >= 2^-7 keeps a normal
+// f16 lo part (full 22 bits), smaller values keep an absolute error <= 2^-29 (f16 subnormals) and the
+// f16 pair saturates only beyond |x| ~ 8000 -- FCN-ResNet activations are O(1..100).
+constexpr float kSplitActScale = 16.0f;
+
 // ---- one convolution on the implicit-GEMM kernel ----
 int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, Tensor* out) {
     const int oh = conv_out(in.h, L.k, L.stride, L.pad, L.dil), ow = conv_out(in.w, L.k, L.stride, L.pad, L.dil);
-    const int f16 = ctx_f16(c) ? 1 : 0;
-    const int out_f32 = (!f16 || L.role == 'c') ? 1 : 0;  // the logits leave the conv stack in f32
+    const int mode = ctx_mode(c);
+    const int out_f32 = (mode != 1 || L.role == 'c') ? 1 : 0;  // the logits leave the conv stack in f32
     RETIF(talloc(c, oh, ow, L.cout, out_f32 ? 4 : 2, out));
     if (L.d_u && !res) {
         // Winograd F(mt x mt, 3x3): input transform -> (mt+2)^2 batched GEMMs -> output transform (+bias, ReLU)
@@ -542,12 +588,17 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
         g.batch = P;
         g.in_bs = (size_t)T * in.c * 4; g.wt_bs = (size_t)L.cout * L.cin * 4; g.out_bs = (size_t)T * L.cout * 4;
+        if (mode == INFUR_DTYPE_F32_SPLIT) {
+            // the input transform amplifies activations (F(4x4): up to 100x, typically ~40x; F(2x2): up to 4x)
+            g.a_scale = mt == 4 ? 0.5f : 4.0f;
+            g.acc_scale = 1.0f / (g.a_scale * L.u_scale);
+        }
         int gcfg = -1;
-        RETIF(pick_cfg(c, g, 0, 1, &gcfg));
+        RETIF(pick_cfg(c, g, mode, 1, &gcfg));
         {
-            ProfScope ps(c, L.name, conv_igemm_config_name(gcfg, 0), 2.0 * P * T * (double)L.cout * L.cin,
+            ProfScope ps(c, L.name, conv_igemm_config_name(gcfg, mode), 2.0 * P * T * (double)L.cout * L.cin,
                          (double)V.bytes() + (double)M.bytes() + (double)P * L.cout * L.cin * 4, direct);
-            HIPCHK(c, launch_conv_igemm(g, 0, 1, gcfg, c->stream));
+            HIPCHK(c, launch_conv_igemm(g, mode, 1, gcfg, c->stream));
         }
         pool_release(c, V);
         {
@@ -565,11 +616,15 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
     const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
     const double bytes = (double)in.bytes() + (double)out->bytes() + (res ? (double)res->bytes() : 0.0) +
                          (double)L.cout * L.cin * L.k * L.k * in.es;
+    if (mode == INFUR_DTYPE_F32_SPLIT) {
+        a.a_scale = kSplitActScale;
+        a.acc_scale = 1.0f / (a.a_scale * L.w_scale);
+    }
     int cfg = -1;
-    RETIF(pick_cfg(c, a, f16, out_f32, &cfg));
+    RETIF(pick_cfg(c, a, mode, out_f32, &cfg));
     {
-        ProfScope ps(c, L.name, conv_igemm_config_name(cfg, f16), flops, bytes);
-        HIPCHK(c, launch_conv_igemm(a, f16, out_f32, cfg, c->stream));
+        ProfScope ps(c, L.name, conv_igemm_config_name(cfg, mode), flops, bytes);
+        HIPCHK(c, launch_conv_igemm(a, mode, out_f32, cfg, c->stream));
     }
     if (c->opt.keep_activations) c->kept.push_back(*out);
     return INFUR_OK;
@@ -696,7 +751,7 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
         if (opts->struct_size != sizeof(infur_options)) return INFUR_E_INVALID_ARG;
         o = *opts;
     }
-    if (o.compute_dtype != INFUR_DTYPE_F32 && o.compute_dtype != INFUR_DTYPE_F16) return INFUR_E_INVALID_ARG;
+    if (o.compute_dtype > INFUR_DTYPE_F32_SPLIT) return INFUR_E_INVALID_ARG;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || o.device < 0 || o.device >= n) return INFUR_E_HIP;
     if (hipSetDevice(o.device) != hipSuccess) return INFUR_E_HIP;

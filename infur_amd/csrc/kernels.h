@@ -22,17 +22,24 @@ struct ConvArgs {
     // operand b starts at base + b * stride (bytes).  batch <= 1: plain convolution.
     int batch = 1;
     size_t in_bs = 0, wt_bs = 0, out_bs = 0;
+    // mode 2 (f32 split into f16 pairs) only: activations are multiplied by a_scale (a power of two
+    // that centres them in the f16 range) while they are staged, the weights were scaled and split at
+    // load time (launch_split_weights), and the accumulators are multiplied by acc_scale =
+    // 1 / (a_scale * weight scale) before bias / residual / ReLU.  Powers of two: exact.
+    float a_scale = 1.0f, acc_scale = 1.0f;
 };
 
-// conv as implicit GEMM on the matrix cores.  f16 = 0: f32 operands (Cin % 32 == 0);
-// f16 = 1: f16 operands, f32 accumulation (Cin % 64 == 0), output f16 or (out_f32) f32.
+// conv as implicit GEMM on the matrix cores.  mode 0: f32 operands on the f32 MFMA (Cin % 32 == 0);
+// mode 1: f16 operands, f32 accumulation (Cin % 64 == 0), output f16 or (out_f32) f32;
+// mode 2: f32 tensors, each value split into an f16 hi + lo pair while it is staged, three f16
+// MFMAs per product, f32 accumulation (Cin % 32 == 0) -- f32-grade results at f16 matrix rate / 3.
 // cfg: tile configuration index (conv_igemm_num_configs), -1 = built-in heuristic.  Every
 // configuration produces bit-identical results; only the speed differs.
-hipError_t launch_conv_igemm(const ConvArgs& a, int f16, int out_f32, int cfg, hipStream_t s);
+hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, hipStream_t s);
 int conv_igemm_num_configs();
 int conv_igemm_default_config(const ConvArgs& a);
 bool conv_igemm_config_valid(const ConvArgs& a, int cfg);
-const char* conv_igemm_config_name(int cfg, int f16);
+const char* conv_igemm_config_name(int cfg, int mode);
 
 // Winograd F(mt x mt, 3x3), mt = 2 or 4, for stride-1 3x3 convs (f32, any dilation d with pad = d);
 // (mt+2)^2 transform planes; see winograd.hip
@@ -56,6 +63,11 @@ hipError_t launch_maxpool3x3s2(const void* in, int H, int W, int C, void* out, i
 // OIHW f32 -> OHWI f32 / f16 weight repack (one-off at model load)
 hipError_t launch_repack_oihw_to_ohwi(const float* src, void* dst, int f16, int O, int I, int KH, int KW,
                                       hipStream_t s);
+// mode 2 weight preparation (one-off at model load).  absmax: *out = max |w[i]| (out must be zeroed).
+// split: in place, every 32 consecutive f32 (one 128-byte K-step row chunk) become
+// [32 x f16 hi][32 x f16 lo] of w * scale, hi = rne(w*scale), lo = rne(w*scale - hi).
+hipError_t launch_absmax(const float* w, size_t n, float* out, hipStream_t s);
+hipError_t launch_split_weights(float* w, size_t n, float scale, hipStream_t s);
 // OIHW (O=64,I=3,7x7) -> [ky][kx][c][o] for the stem kernel
 hipError_t launch_repack_stem(const float* src, float* dst, hipStream_t s);
 

@@ -205,4 +205,50 @@ hipError_t launch_repack_stem(const float* src, float* dst, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- weight preparation for the f32-split GEMM mode (conv_igemm.hip, SPLIT) ----
+__global__ void absmax_kernel(const float* __restrict__ w, size_t n, float* __restrict__ out) {
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
+hipError_t launch_absmax(const float* w, size_t n, float* out, hipStream_t s) {
+    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, w, n, out);
+    return hipGetLastError();
+}
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// one thread per 128-byte group: 32 f32 in, 32 f16 hi + 32 f16 lo out (in place)
+__global__ void split_weights_kernel(float* __restrict__ w, size_t groups, float scale) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    f32x8* p = reinterpret_cast<f32x8*>(w + g * 32);
+    h16x8 hi[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x8 x = p[q] * scale;
+        hi[q] = __builtin_convertvector(x, h16x8);
+        lo[q] = __builtin_convertvector(x - __builtin_convertvector(hi[q], f32x8), h16x8);
+    }
+    h16x8* o = reinterpret_cast<h16x8*>(w + g * 32);
+#pragma unroll
+    for (int q = 0; q < 4; q++) o[q] = hi[q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) o[4 + q] = lo[q];
+}
+
+hipError_t launch_split_weights(float* w, size_t n, float scale, hipStream_t s) {
+    if (n % 32 != 0) return hipErrorInvalidValue;
+    const size_t groups = n / 32;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, w, groups, scale);
+    return hipGetLastError();
+}
+
 }  // namespace infur

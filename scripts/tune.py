@@ -14,16 +14,28 @@ ROUNDS = 3
 JOBS = [  # (dtype, depth, (w, h), factor)
     ("f32", 50, (1920, 1080), 1.0), ("f32", 50, (1920, 1080), 0.5), ("f32", 50, (640, 480), 1.0), ("f32", 50, (320, 240), 1.0),
     ("f16", 50, (1920, 1080), 1.0), ("f16", 101, (3840, 2160), 1.0),
+    ("f32s", 50, (1920, 1080), 1.0), ("f32s", 50, (1920, 1080), 0.5), ("f32s", 50, (640, 480), 1.0),
 ]
+MODE = {"f32": "0", "f16": "1", "f32s": "2"}  # the `mode` column of the database
 
 
 def main():
+    # python scripts/tune.py [dtype ...]: re-measure only the given modes, keep the other lines
+    only = set(sys.argv[1:])
     db = P.TUNE_DB
-    if os.path.exists(db):
-        os.remove(db)
     votes = collections.defaultdict(collections.Counter)
+    if os.path.exists(db):
+        if only:
+            redo = {MODE[d] for d in only}
+            for ln in open(db):
+                if ln.strip() and not ln.startswith("#") and ln.split()[11] not in redo:
+                    *key, cfg = ln.split()
+                    votes[" ".join(key)][cfg] += 1000
+        os.rename(db, db + ".old")  # contexts created below must not import it
     blobs = {}
     for dtype, depth, (w, h), factor in JOBS:
+        if only and dtype not in only:
+            continue
         blob = blobs.setdefault(depth, W.synth_blob(depth=depth))
         fr = W.synth_frame(h, w)
         for _ in range(ROUNDS):
@@ -36,10 +48,12 @@ def main():
             c.close()
         print(f"tuned {dtype} R{depth} {w}x{h} x{factor}: {len(votes)} shapes so far", flush=True)
     with open(db, "w") as f:
-        f.write("# conv_igemm tile configuration per shape: H W Cin OH OW Cout KH stride dil batch res f16 outf32 cfg\n")
+        f.write("# conv_igemm tile configuration per shape: H W Cin OH OW Cout KH stride dil batch res mode outf32 cfg\n")
         f.write("# measured on MI355X (gfx950) by scripts/tune.py; results are bit-identical for every configuration\n")
         for key in sorted(votes, key=lambda k: [int(x) for x in k.split()]):
             f.write(f"{key} {votes[key].most_common(1)[0][0]}\n")
+    if os.path.exists(db + ".old"):
+        os.remove(db + ".old")
     print("wrote", db, len(votes), "shapes")
 
 
