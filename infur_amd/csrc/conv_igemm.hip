@@ -19,11 +19,21 @@
 // A lane reads 4 consecutive k of its row with one ds_read_b128 (lanes 0-31: k 0-3,
 // lanes 32-63: k 4-7 of an 8-wide slice) and feeds them to 4 MFMAs; A and B use the same
 // permutation of k, so the sum is complete.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
 
 namespace infur {
+
+#ifdef KTRACE
+#ifndef KT_CIN
+#define KT_CIN 1024
+#define KT_COUT 2048
+#endif
+__device__ unsigned long long g_ktrace[8 * 8 * 8];
+hipError_t ktrace_read(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktrace), sizeof(g_ktrace)); }
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -52,9 +62,27 @@ __device__ __forceinline__ void store_split(char* dst, const u32x4 r, const floa
     *reinterpret_cast<f16x4*>(dst + 64) = lo;
 }
 
+// dynamic LDS of a workgroup: the operand images, or the epilogue's per-wave staging slices
+// (32 pixel rows of BN / WN f32 channels + 16 bytes) if those need more
+constexpr int lds_bytes(int bm, int bn, int wm, int wn, int nbuf) {
+    const int operands = (nbuf == 1 ? 1 : 2) * (bm + bn) * LDS_ROW;
+    const int staging = wm * wn * 32 * (bn / wn * 4 + 16);
+    return operands > staging ? operands : staging;
+}
+
+// waves per SIMD the register budget is planned for: what the LDS footprint lets a CU hold, at most 2
+constexpr int min_waves_per_simd(int bm, int bn, int wm, int wn, int nbuf) {
+    const int waves = wm * wn;
+    const int blocks = 160 * 1024 / lds_bytes(bm, bn, wm, wn, nbuf);
+    const int w = blocks * waves / 4;
+    return w < 1 ? 1 : (w > 2 ? 2 : w);
+}
+
 // T = operand type (float: v_mfma_f32_32x32x2_f32, exact f32; _Float16: v_mfma_f32_32x32x16_f16
 // with f32 accumulation), OutT = type of the stored activation (f32 for the classifier logits).
 // NBUF = 2: double-buffered LDS, one barrier per K step (the latency-optimised form).
+// NBUF = 3: two LDS images, one barrier per K step, fragments NOT double-buffered (big tiles: 8 waves keep 128
+// accumulators each and the register file has no room for a second fragment set).
 // NBUF = 1: one LDS image, two barriers per K step -- half the LDS footprint, so twice the
 // workgroups per CU cover each other's stalls (the occupancy-optimised form).
 //
@@ -66,8 +94,17 @@ __device__ __forceinline__ void store_split(char* dst, const u32x4 r, const floa
 // is dropped): f32-grade results (measured against the f32 oracle in tests/) at three f16 MFMAs per
 // f32 MFMA-equivalent, i.e. a ceiling of 2.5 PFLOP/s / 3 = 833 TFLOP/s instead of 157.  An LDS row is
 // [hi: 32 x f16][lo: 32 x f16] (128 bytes, same as the f32 row) and a K step is two 16-wide MFMA slices.
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF, bool SPLIT = false>
-__global__ void __launch_bounds__(WM* WN * 64, 2)
+// G1: the convolution is 1x1 without padding (a plain GEMM over pixels, any stride): every staged row
+// has ONE per-lane byte offset for the whole K loop and the K step advances through the scalar offset of
+// the buffer load -- no vector address arithmetic in the loop (it competes with the MFMAs for the
+// SIMD's issue port, which is what bounds the f16-rate modes).
+// RESPF: the layer has a residual input and the tile keeps <= 64 accumulators per lane: the residual
+// tile is fetched into registers right after the prologue, so its latency hides behind the whole K
+// loop and the epilogue only adds and stores (stores need no waiting: the wave retires at once and
+// its CU slot starts the next tile).  Without it the epilogue of a 1x1 conv with K = 512 takes
+// longer than its K loop (measured with s_memtime: 36.5k vs 30.6k cycles).
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF, bool SPLIT = false, bool G1 = false, bool RESPF = false>
+__global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN, NBUF))
     conv_igemm_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
     constexpr bool F32 = std::is_same<T, float>::value && !SPLIT;
     static_assert(!SPLIT || std::is_same<T, float>::value, "SPLIT stages f32 tensors");
@@ -82,9 +119,17 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     constexpr int B_IT = BN * 8 / NT;
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
 
+#ifdef KTRACE
+    const unsigned long long kt_start = __builtin_amdgcn_s_memtime();
+#endif
+    // SPLIT: MODE.FP16_OVFL = 1 -- an f32 -> f16 conversion that overflows clamps to +-65504 instead of
+    // producing inf, so an activation beyond the f16 pair's range (|x| * a_scale > 131008) saturates
+    // instead of poisoning the accumulators with inf - inf
+    if constexpr (SPLIT) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                        // [NBUF][BM][LDS_ROW]
-    char* Bs = smem + NBUF * BM * LDS_ROW;  // [NBUF][BN][LDS_ROW]
+    constexpr int NIMG = NBUF == 1 ? 1 : 2;     // LDS images (NBUF 3 = two images, fragments single-buffered)
+    char* Bs = smem + NIMG * BM * LDS_ROW;  // [NIMG][BN][LDS_ROW]
 
     // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of
     // tiles (n fastest) so the N-tiles that share an activation tile share one L2.
@@ -130,6 +175,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         // rows past M get coordinates that fail the bounds test for every tap
         a_iy0[i] = m < M ? oy * a.stride - a.pad : -0x100000;
         a_ix0[i] = ox * a.stride - a.pad;
+        if constexpr (G1)  // reuse a_iy0 as the fixed byte offset of the row's pixel
+            a_iy0[i] = m < M ? (int)((unsigned)(oy * a.stride * a.W + ox * a.stride) * (unsigned)(a.Cin * ES) + c4 * 16u) : (int)OOB;
     }
     unsigned b_off[B_IT];
 #pragma unroll
@@ -147,12 +194,39 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    u32x4 ra[A_IT], rb[B_IT];
+    // staging registers.  SPLIT keeps TWO sets: K step k travels in set k % 2 and its global loads are
+    // issued three steps before its MFMAs (a split K step is 768 MFMA cycles, a third of the f32 one --
+    // one step of distance no longer covers an L2 miss)
+    #ifndef SPLIT_NSETS
+#define SPLIT_NSETS 1
+#endif
+    constexpr int NSETS = SPLIT ? SPLIT_NSETS : 1;
+    u32x4 ra[NSETS][A_IT], rb[NSETS][B_IT];
+#ifdef XABL
+    if (XABL & 1)
+        for (int q = 0; q < NSETS; q++) {
+            for (int i = 0; i < A_IT; i++) ra[q][i] = u32x4{1, 2, 3, 4};
+            for (int i = 0; i < B_IT; i++) rb[q][i] = u32x4{1, 2, 3, 4};
+        }
+#endif
     const int cchunks = a.Cin / BK;  // K steps per filter tap
     const int ksteps = a.KH * a.KW * cchunks;
     int ky = 0, kx = 0, cc = 0;  // coordinates of the K step being LOADED
 
-    auto load_a = [&]() {
+    int kload = 0;  // G1: K step the next load_a fetches
+#ifndef XABL
+#define XABL 0
+#endif
+    auto load_a = [&](auto SETC) {
+        constexpr int S = decltype(SETC)::value;
+        if (XABL & 1) return;
+        if constexpr (G1) {
+            const unsigned so = (unsigned)kload * (unsigned)ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < A_IT; i++) ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (unsigned)a_iy0[i], so, 0);
+            kload++;
+            return;
+        }
         const int dy = ky * a.dil, dx = kx * a.dil;
         const unsigned coff = (unsigned)(cc * ROW_BYTES + c4 * 16);
 #pragma unroll
@@ -160,7 +234,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
             const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const unsigned off = (unsigned)(iy * a.W + ix) * (unsigned)(a.Cin * ES) + coff;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
+            ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
         }
         // advance (ky,kx,cc) to the next K step, branch-free (all wave-uniform scalars)
         cc += 1;
@@ -171,38 +245,54 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
         kx = w2 ? 0 : kx;
         ky += w2;
     };
-    auto load_b = [&](int ks) {
+    auto load_b = [&](int ks, auto SETC) {
+        constexpr int S = decltype(SETC)::value;
+        if (XABL & 1) return;
         const unsigned koff = (unsigned)ks * (unsigned)ROW_BYTES;
 #pragma unroll
         for (int i = 0; i < B_IT; i++)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, b_off[i] == OOB ? OOB : b_off[i] + koff, 0, 0);
+            rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, b_off[i], koff, 0);  // K step in the scalar offset
     };
-    auto load_step = [&](int ks) {
-        load_a();
-        load_b(ks);
+    constexpr auto S0 = std::integral_constant<int, 0>{};
+    constexpr auto S1 = std::integral_constant<int, NSETS - 1>{};  // the second set (set 0 again when there is one)
+    auto load_step = [&](int ks, auto SETC) {
+        load_a(SETC);
+        load_b(ks, SETC);
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int buf, auto SETC) {
+        constexpr int S = decltype(SETC)::value;
+        if (XABL & 2) {
+#pragma unroll
+            for (int i = 0; i < A_IT; i++) asm volatile("" ::"v"(ra[S][i]));
+            return;
+        }
         char* Ab = As + buf * BM * LDS_ROW;
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
             if constexpr (SPLIT)
-                store_split(Ab + row * LDS_ROW + c4 * 8, ra[i], a.a_scale);
+                store_split(Ab + row * LDS_ROW + c4 * 8, ra[S][i], a.a_scale);
             else
-                *reinterpret_cast<u32x4*>(Ab + row * LDS_ROW + c4 * 16) = ra[i];
+                *reinterpret_cast<u32x4*>(Ab + row * LDS_ROW + c4 * 16) = ra[S][i];
         }
     };
-    auto store_b = [&](int buf) {
+    auto store_b = [&](int buf, auto SETC) {
+        constexpr int S = decltype(SETC)::value;
+        if (XABL & 2) {
+#pragma unroll
+            for (int i = 0; i < B_IT; i++) asm volatile("" ::"v"(rb[S][i]));
+            return;
+        }
         char* Bb = Bs + buf * BN * LDS_ROW;
 #pragma unroll
         for (int i = 0; i < B_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
-            *reinterpret_cast<u32x4*>(Bb + row * LDS_ROW + c4 * 16) = rb[i];  // SPLIT: split at load time
+            *reinterpret_cast<u32x4*>(Bb + row * LDS_ROW + c4 * 16) = rb[S][i];  // SPLIT: split at load time
         }
     };
-    auto store_step = [&](int buf) {
-        store_a(buf);
-        store_b(buf);
+    auto store_step = [&](int buf, auto SETC) {
+        store_a(buf, SETC);
+        store_b(buf, SETC);
     };
 
     // LDS -> register fragments for one 32-byte k slice of buffer `buf`: lanes 0-31 take the
@@ -259,7 +349,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     //                 every read of the current buffer has completed (lgkmcnt(0)) before it
     //                 is overwritten one step later.
     // STORE / LOAD / NEXT are compile-time so the steady-state body is straight-line code.
-    auto k_step = [&](int ks, auto STORE, auto LOAD, auto NEXT) {
+    auto k_step = [&](int ks, auto SETC, auto STORE, auto LOAD, auto NEXT) {
         const int buf = ks & 1;
 #pragma unroll
         for (int kk = 0; kk < NSL; kk++) {
@@ -270,12 +360,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             mma_slice();
             // staging spread over two slices: activations at slice 0, weights at slice 1
             if (kk == 0 && STORE) {
-                store_a(buf ^ 1);
-                if (LOAD) load_a();
+                store_a(buf ^ 1, SETC);
+                if (LOAD) load_a(SETC);
             }
             if (kk == (SPLIT ? 0 : 1) && STORE) {
-                store_b(buf ^ 1);
-                if (LOAD) load_b(ks + 2);
+                store_b(buf ^ 1, SETC);
+                if (LOAD) load_b(ks + 1 + NSETS, SETC);
             }
             // Ask the scheduler for an even interleave instead of clusters of LDS/VMEM/VALU
             // work between two MFMAs (a cluster longer than the 64-cycle MFMA shadow is a
@@ -319,17 +409,87 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     constexpr auto Y = std::true_type{};
     constexpr auto N = std::false_type{};
 
-    load_step(0);
-    store_step(0);
-    if (ksteps > 1) load_step(1);
+    load_step(0, S0);
+    store_step(0, S0);
+    if (ksteps > 1) load_step(1, S1);
+    if (NSETS == 2 && NBUF == 2 && ksteps > 2) load_step(2, S0);
     __syncthreads();
+#ifdef KTRACE
+    const unsigned long long kt_loop = __builtin_amdgcn_s_memtime();
+#endif
+    // epilogue geometry: a wave's 32-pixel row block is written out with LPR lanes (4 channels each)
+    // on every pixel row, RPI rows per instruction
+    constexpr int LPR = TN * 8;
+    constexpr int RPI = 64 / LPR;
+    const int e_row = lane / LPR, e_col = lane % LPR;
+    const int e_n = n0 + wn * TN * 32 + e_col * 4;
+    const T* res = static_cast<const T*>(a.res);
+    using ResV = typename std::conditional<std::is_same<T, float>::value, float4, f16x4>::type;
+    ResV rres[RESPF ? TM : 1][RESPF ? 32 / RPI : 1];
+    if constexpr (RESPF) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int m = m0 + wm * TM * 32 + i * 32 + it * RPI + e_row;
+                ResV r = {};
+                if (m < M && e_n < a.Cout) r = *reinterpret_cast<const ResV*>(res + (size_t)m * a.Cout + e_n);
+                rres[i][it] = r;
+            }
+    }
 
-    if constexpr (NBUF == 2) {
+    if constexpr (NBUF == 3) {
+        // two LDS images, fragments read slice by slice into ONE register set (the big-tile form: the
+        // 8 waves of a 256x256 tile keep 128 accumulators each; the second wave on the SIMD covers the
+        // ds_read latency).  Stores of K step ks+1 go to the other image during slice 0; one barrier
+        // ends the step.
+#ifdef KTRACE
+        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto now = [&]() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
+#define KT(i, expr) { const unsigned long long t_ = now(); expr; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[i] += now() - t_; }
+#else
+#define KT(i, expr) { expr; }
+#endif
+        for (int ks = 0; ks < ksteps; ks++) {
+            const int buf = ks & 1;
+#pragma unroll
+            for (int kk = 0; kk < NSL; kk++) {
+                KT(0, read_frags(buf, kk, fa, fb));
+                KT(1, mma_slice());
+                if (kk == 0 && ks + 1 < ksteps) {
+                    KT(2, store_step(buf ^ 1, S1));
+                    if (ks + 2 < ksteps) KT(3, load_step(ks + 2, S1));
+                }
+            }
+            KT(4, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier());
+        }
+#ifdef KTRACE
+        if (a.Cin == KT_CIN && a.Cout == KT_COUT && blockIdx.x < 8 && lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) g_ktrace[(blockIdx.x * 8 + wave) * 8 + q] = tacc[q];
+        }
+#endif
+    } else if constexpr (NBUF == 2) {
         read_frags(0, 0, fa, fb);
         int ks = 0;
-        for (; ks + 2 < ksteps; ks++) k_step(ks, Y, Y, Y);  // steady state
-        if (ks + 1 < ksteps) k_step(ks++, Y, N, Y);          // last but one: nothing left to load
-        k_step(ks, N, N, N);                                 // last: nothing left to stage
+        if constexpr (NSETS == 1) {
+            for (; ks + 2 < ksteps; ks++) k_step(ks, S0, Y, Y, Y);  // steady state
+            if (ks + 1 < ksteps) k_step(ks++, S0, Y, N, Y);          // last but one: nothing left to load
+            k_step(ks, S0, N, N, N);                                 // last: nothing left to stage
+        } else {
+            // K step ks stores set (ks + 1) % 2 (K step ks + 1) and refills it with K step ks + 3
+            for (; ks + 4 < ksteps; ks += 2) {  // steady state, two steps per trip: the sets are compile-time
+                k_step(ks, S1, Y, Y, Y);
+                k_step(ks + 1, S0, Y, Y, Y);
+            }
+            for (; ks < ksteps; ks++) {  // the last (up to four) steps: wave-uniform run-time conditions
+                const bool st = ks + 1 < ksteps, ld = ks + 3 < ksteps;
+                if (ks & 1)
+                    k_step(ks, S0, st, ld, st);
+                else
+                    k_step(ks, S1, st, ld, st);
+            }
+        }
     } else {
         // single LDS image: compute a K step, barrier, overwrite the image with the registers
         // (K step ks+1), refill the registers (ks+2), barrier.  Fragment prefetch only within a step.
@@ -346,8 +506,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
             }
             if (ks + 1 < ksteps) {
                 __syncthreads();  // every wave has read the image
-                store_step(0);
-                if (ks + 2 < ksteps) load_step(ks + 2);
+                store_step(0, S1);
+                if (ks + 2 < ksteps) load_step(ks + 2, S1);
                 __syncthreads();  // the new image is complete
             }
         }
@@ -356,11 +516,87 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
     // epilogue: + bias, + residual, ReLU.  The MFMA was issued with the weight fragment as the
     // row operand, so in the 32x32 C/D layout (col = lane & 31, row = (e & 3) + 8 * (e >> 2) +
     // 4 * (lane >> 5)) a lane owns ONE pixel (col) and, per group g = e >> 2, FOUR consecutive
-    // output channels: NHWC stores, residual loads and bias loads are 16 (f32) / 8 (f16) bytes wide.
-    const T* res = static_cast<const T*>(a.res);
+    // output channels.  Stored straight from that layout a wave instruction would touch 32 pixels
+    // x 32 bytes (32 cache lines); instead each wave passes its 32-pixel row block through its
+    // own slice of the (now idle) operand LDS and stores / loads the residual with 16 lanes on the
+    // 256 contiguous bytes of a pixel: 8 full lines per instruction, a quarter of the TA work.
     OutT* out = reinterpret_cast<OutT*>(static_cast<char*>(a.out) + (size_t)bidx * a.out_bs);
     const bool has_bias = a.bias != nullptr;
     const bool vec_ok = (a.Cout & 3) == 0;
+#ifdef KTRACE
+    const unsigned long long kt_epi = __builtin_amdgcn_s_memtime();
+    struct KtEnd {
+        unsigned long long t0, t1, t2; int on, slot;
+        __device__ ~KtEnd() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            if (on) { g_ktrace[slot * 8 + 5] = t1 - t0; g_ktrace[slot * 8 + 6] = t2 - t1; g_ktrace[slot * 8 + 7] = t3 - t2; }
+        }
+    } kt_end{kt_start, kt_loop, kt_epi, (a.Cin == KT_CIN && a.Cout == KT_COUT && blockIdx.x < 8 && lane == 0) ? 1 : 0, (int)(blockIdx.x * 8 + wave)};
+#endif
+    if (vec_ok) {
+        constexpr int ROWB = TN * 128 + 16;  // staged row: TN*32 f32 + pad (conflict-free b128 writes and reads)
+        static_assert(NT / 64 * 32 * ROWB <= lds_bytes(BM, BN, WM, WN, NBUF), "epilogue staging exceeds the LDS allocation");
+        __syncthreads();  // every wave is done with the operand tiles
+        char* stage = smem + wave * 32 * ROWB;
+        const int rrow = e_row, rcol = e_col;
+        const int n = e_n;
+        const bool n_ok = n < a.Cout;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_bias && n_ok) bv = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int jj = 0; jj < TN; jj++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float4 v = make_float4(acc[i][jj][4 * g + 0], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
+                    if constexpr (SPLIT) {
+                        v.x *= a.acc_scale; v.y *= a.acc_scale; v.z *= a.acc_scale; v.w *= a.acc_scale;
+                    }
+                    *reinterpret_cast<float4*>(stage + (lane & 31) * ROWB + (jj * 32 + 8 * g + 4 * (lane >> 5)) * 4) = v;
+                }
+            // the slice is private to this wave and LDS serves a wave's operations in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int mb = m0 + wm * TM * 32 + i * 32;
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int row = it * RPI + rrow;
+                const int m = mb + row;
+                float4 v = *reinterpret_cast<const float4*>(stage + row * ROWB + rcol * 16);
+                if (m < M && n_ok) {
+                    const size_t o = (size_t)m * a.Cout + n;
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (RESPF || res) {
+                        ResV rv;
+                        if constexpr (RESPF)
+                            rv = rres[i][it];
+                        else
+                            rv = *reinterpret_cast<const ResV*>(res + o);
+                        if constexpr (std::is_same<T, float>::value) {
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        } else {
+                            v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
+                        }
+                    }
+                    if (a.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if constexpr (std::is_same<OutT, float>::value) {
+                        *reinterpret_cast<float4*>(out + o) = v;
+                    } else {
+                        f16x4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                        *reinterpret_cast<f16x4*>(out + o) = hv;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // Cout not a multiple of 4 (the 21-class logits): element-wise from the accumulator layout
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int m = m0 + wm * TM * 32 + i * 32 + (lane & 31);
@@ -372,56 +608,28 @@ __global__ void __launch_bounds__(WM* WN * 64, 2)
                 const int n = n0 + wn * TN * 32 + j * 32 + 8 * g + 4 * (lane >> 5);
                 if (n >= a.Cout) continue;
                 const size_t o = (size_t)m * a.Cout + n;
-                float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                if constexpr (SPLIT) {
 #pragma unroll
-                    for (int t = 0; t < 4; t++) v[t] *= a.acc_scale;
-                }
-                if (vec_ok) {
-                    if (has_bias) {
-                        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                    }
-                    if (res) {
-                        if constexpr (std::is_same<T, float>::value) {
-                            const float4 rv = *reinterpret_cast<const float4*>(res + o);
-                            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                        } else {
-                            const f16x4 rv = *reinterpret_cast<const f16x4*>(res + o);
-                            v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
-                        }
-                    }
-                    if (a.relu) {
-                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                    }
-                    if constexpr (std::is_same<OutT, float>::value) {
-                        *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                        *reinterpret_cast<f16x4*>(out + o) = hv;
-                    }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        if (n + t >= a.Cout) break;
-                        float x = v[t] + (has_bias ? a.bias[n + t] : 0.f);
-                        if (res) x += (float)res[o + t];
-                        if (a.relu) x = fmaxf(x, 0.f);
-                        out[o + t] = (OutT)x;
-                    }
+                for (int t = 0; t < 4; t++) {
+                    if (n + t >= a.Cout) break;
+                    float x = acc[i][j][4 * g + t];
+                    if constexpr (SPLIT) x *= a.acc_scale;
+                    x += has_bias ? a.bias[n + t] : 0.f;
+                    if (res) x += (float)res[o + t];
+                    if (a.relu) x = fmaxf(x, 0.f);
+                    out[o + t] = (OutT)x;
                 }
             }
         }
     }
 }
 
-template <typename T, typename OutT, bool SPLIT, int BM, int BN, int WM, int WN, int NBUF = 2>
-static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
+template <typename T, typename OutT, bool SPLIT, bool G1, bool RESPF, int BM, int BN, int WM, int WN, int NBUF>
+static hipError_t launch_cfg_g(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM;
     const int ntiles = (a.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)NBUF * (BM + BN) * LDS_ROW;
-    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT>;
+    const size_t lds = (size_t)lds_bytes(BM, BN, WM, WN, NBUF);
+    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT, G1, RESPF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -431,6 +639,21 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(k, dim3(mtiles * ntiles * (a.batch > 1 ? a.batch : 1)), dim3(WM * WN * 64), lds, s, a, mtiles, ntiles);
     return hipGetLastError();
+}
+
+template <typename T, typename OutT, bool SPLIT, int BM, int BN, int WM, int WN, int NBUF = 2>
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
+    // residual prefetch: only where a lane holds <= 64 accumulators (room for 64 more registers), the
+    // output has the operand type, and -- a residual only ever enters a 1x1 conv -- in the G1 form
+    constexpr bool kCanPf = (BM / WM) * (BN / WN) <= 64 * 64 && std::is_same<T, OutT>::value;
+    const bool g1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
+    if constexpr (kCanPf) {
+        if (a.res && g1 && (a.Cout & 3) == 0) return launch_cfg_g<T, OutT, SPLIT, SPLIT, true, BM, BN, WM, WN, NBUF>(a, s);
+    }
+    // 1x1 without padding: the plain-GEMM addressing form (only built for the f16-rate split mode,
+    // where vector address arithmetic in the K loop costs MFMA issue slots)
+    if (SPLIT && g1) return launch_cfg_g<T, OutT, SPLIT, SPLIT, false, BM, BN, WM, WN, NBUF>(a, s);
+    return launch_cfg_g<T, OutT, SPLIT, false, false, BM, BN, WM, WN, NBUF>(a, s);
 }
 
 // ---- tile configurations ----
@@ -452,7 +675,8 @@ static const CfgInfo kCfgs[] = {
     {128, 64, {"conv_igemm_f32<128,64,1buf>", "conv_igemm_f16<128,64,1buf>", "conv_igemm_f32s<128,64,1buf>"}},
     {64, 128, {"conv_igemm_f32<64,128,1buf>", "conv_igemm_f16<64,128,1buf>", "conv_igemm_f32s<64,128,1buf>"}},
     {64, 64, {"conv_igemm_f32<64,64,1buf>", "conv_igemm_f16<64,64,1buf>", "conv_igemm_f32s<64,64,1buf>"}},
-    {256, 256, {"conv_igemm_f32<256,256>", "conv_igemm_f16<256,256>", "conv_igemm_f32s<256,256>"}},
+    {256, 256, {"conv_igemm_f32<256,256,1frag>", "conv_igemm_f16<256,256,1frag>", "conv_igemm_f32s<256,256,1frag>"}},
+    {256, 128, {"conv_igemm_f32<256,128,1frag>", "conv_igemm_f16<256,128,1frag>", "conv_igemm_f32s<256,128,1frag>"}},
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -499,7 +723,8 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 8: return launch_cfg<T, OutT, SPLIT, 128, 64, 2, 2, 1>(a, s);
         case 9: return launch_cfg<T, OutT, SPLIT, 64, 128, 2, 2, 1>(a, s);
         case 10: return launch_cfg<T, OutT, SPLIT, 64, 64, 2, 2, 1>(a, s);
-        case 11: return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4>(a, s);  // 8 waves of 128x64: least staging per MFMA
+        case 11: return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 3>(a, s);  // 8 waves of 128x64, one fragment set
+        case 12: return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 3>(a, s);  // 8 waves of 64x64, one fragment set
         default: return hipErrorInvalidValue;
     }
 }

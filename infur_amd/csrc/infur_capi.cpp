@@ -1463,3 +1463,8 @@ int32_t infur_memcpy_d2h(infur_ctx* c, void* d, const void* s, size_t n) {
 }
 
 }  // extern "C"
+
+#ifdef KTRACE
+namespace infur { hipError_t ktrace_read(unsigned long long* out); }
+extern "C" int32_t infur_debug_ktrace(unsigned long long* out) { return infur::ktrace_read(out) == hipSuccess ? 0 : 1; }
+#endif
