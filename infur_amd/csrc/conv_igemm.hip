@@ -26,12 +26,16 @@
 
 namespace infur {
 
+// Instrumentation build (make EXTRA="-DKTRACE -DKT_CIN=512 -DKT_COUT=2048", scripts/ktrace.py): the first 8
+// workgroups of every launch with Cin == KT_CIN and Cout == KT_COUT record, per wave, the shader cycles
+// (s_memtime) of prologue, K loop and epilogue.  This is how the epilogue of the residual 1x1 convs was
+// found to outlast their K loop.
 #ifdef KTRACE
 #ifndef KT_CIN
 #define KT_CIN 1024
 #define KT_COUT 2048
 #endif
-__device__ unsigned long long g_ktrace[8 * 8 * 8];
+__device__ unsigned long long g_ktrace[8 * 8 * 4];
 hipError_t ktrace_read(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktrace), sizeof(g_ktrace)); }
 #endif
 
@@ -194,36 +198,20 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    // staging registers.  SPLIT keeps TWO sets: K step k travels in set k % 2 and its global loads are
-    // issued three steps before its MFMAs (a split K step is 768 MFMA cycles, a third of the f32 one --
-    // one step of distance no longer covers an L2 miss)
-    #ifndef SPLIT_NSETS
-#define SPLIT_NSETS 1
-#endif
-    constexpr int NSETS = SPLIT ? SPLIT_NSETS : 1;
-    u32x4 ra[NSETS][A_IT], rb[NSETS][B_IT];
-#ifdef XABL
-    if (XABL & 1)
-        for (int q = 0; q < NSETS; q++) {
-            for (int i = 0; i < A_IT; i++) ra[q][i] = u32x4{1, 2, 3, 4};
-            for (int i = 0; i < B_IT; i++) rb[q][i] = u32x4{1, 2, 3, 4};
-        }
-#endif
+    // staging registers: K step k + 1 waits here while step k is multiplied; the global loads of
+    // step k + 2 refill them right after they were written to LDS.  (A second set -- loads three
+    // steps ahead -- was measured for the split mode: no gain, and 128x128 tiles spill.)
+    u32x4 ra[A_IT], rb[B_IT];
     const int cchunks = a.Cin / BK;  // K steps per filter tap
     const int ksteps = a.KH * a.KW * cchunks;
     int ky = 0, kx = 0, cc = 0;  // coordinates of the K step being LOADED
 
     int kload = 0;  // G1: K step the next load_a fetches
-#ifndef XABL
-#define XABL 0
-#endif
-    auto load_a = [&](auto SETC) {
-        constexpr int S = decltype(SETC)::value;
-        if (XABL & 1) return;
+    auto load_a = [&]() {
         if constexpr (G1) {
             const unsigned so = (unsigned)kload * (unsigned)ROW_BYTES;
 #pragma unroll
-            for (int i = 0; i < A_IT; i++) ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (unsigned)a_iy0[i], so, 0);
+            for (int i = 0; i < A_IT; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (unsigned)a_iy0[i], so, 0);
             kload++;
             return;
         }
@@ -234,7 +222,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
             const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const unsigned off = (unsigned)(iy * a.W + ix) * (unsigned)(a.Cin * ES) + coff;
-            ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
         }
         // advance (ky,kx,cc) to the next K step, branch-free (all wave-uniform scalars)
         cc += 1;
@@ -245,54 +233,38 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         kx = w2 ? 0 : kx;
         ky += w2;
     };
-    auto load_b = [&](int ks, auto SETC) {
-        constexpr int S = decltype(SETC)::value;
-        if (XABL & 1) return;
+    auto load_b = [&](int ks) {
         const unsigned koff = (unsigned)ks * (unsigned)ROW_BYTES;
 #pragma unroll
         for (int i = 0; i < B_IT; i++)
-            rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, b_off[i], koff, 0);  // K step in the scalar offset
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, b_off[i], koff, 0);  // K step in the scalar offset
     };
-    constexpr auto S0 = std::integral_constant<int, 0>{};
-    constexpr auto S1 = std::integral_constant<int, NSETS - 1>{};  // the second set (set 0 again when there is one)
-    auto load_step = [&](int ks, auto SETC) {
-        load_a(SETC);
-        load_b(ks, SETC);
+    auto load_step = [&](int ks) {
+        load_a();
+        load_b(ks);
     };
-    auto store_a = [&](int buf, auto SETC) {
-        constexpr int S = decltype(SETC)::value;
-        if (XABL & 2) {
-#pragma unroll
-            for (int i = 0; i < A_IT; i++) asm volatile("" ::"v"(ra[S][i]));
-            return;
-        }
+    auto store_a = [&](int buf) {
         char* Ab = As + buf * BM * LDS_ROW;
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
             if constexpr (SPLIT)
-                store_split(Ab + row * LDS_ROW + c4 * 8, ra[S][i], a.a_scale);
+                store_split(Ab + row * LDS_ROW + c4 * 8, ra[i], a.a_scale);
             else
-                *reinterpret_cast<u32x4*>(Ab + row * LDS_ROW + c4 * 16) = ra[S][i];
+                *reinterpret_cast<u32x4*>(Ab + row * LDS_ROW + c4 * 16) = ra[i];
         }
     };
-    auto store_b = [&](int buf, auto SETC) {
-        constexpr int S = decltype(SETC)::value;
-        if (XABL & 2) {
-#pragma unroll
-            for (int i = 0; i < B_IT; i++) asm volatile("" ::"v"(rb[S][i]));
-            return;
-        }
+    auto store_b = [&](int buf) {
         char* Bb = Bs + buf * BN * LDS_ROW;
 #pragma unroll
         for (int i = 0; i < B_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
-            *reinterpret_cast<u32x4*>(Bb + row * LDS_ROW + c4 * 16) = rb[S][i];  // SPLIT: split at load time
+            *reinterpret_cast<u32x4*>(Bb + row * LDS_ROW + c4 * 16) = rb[i];  // SPLIT: split at load time
         }
     };
-    auto store_step = [&](int buf, auto SETC) {
-        store_a(buf, SETC);
-        store_b(buf, SETC);
+    auto store_step = [&](int buf) {
+        store_a(buf);
+        store_b(buf);
     };
 
     // LDS -> register fragments for one 32-byte k slice of buffer `buf`: lanes 0-31 take the
@@ -349,7 +321,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     //                 every read of the current buffer has completed (lgkmcnt(0)) before it
     //                 is overwritten one step later.
     // STORE / LOAD / NEXT are compile-time so the steady-state body is straight-line code.
-    auto k_step = [&](int ks, auto SETC, auto STORE, auto LOAD, auto NEXT) {
+    auto k_step = [&](int ks, auto STORE, auto LOAD, auto NEXT) {
         const int buf = ks & 1;
 #pragma unroll
         for (int kk = 0; kk < NSL; kk++) {
@@ -360,12 +332,12 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             mma_slice();
             // staging spread over two slices: activations at slice 0, weights at slice 1
             if (kk == 0 && STORE) {
-                store_a(buf ^ 1, SETC);
-                if (LOAD) load_a(SETC);
+                store_a(buf ^ 1);
+                if (LOAD) load_a();
             }
             if (kk == (SPLIT ? 0 : 1) && STORE) {
-                store_b(buf ^ 1, SETC);
-                if (LOAD) load_b(ks + 1 + NSETS, SETC);
+                store_b(buf ^ 1);
+                if (LOAD) load_b(ks + 2);
             }
             // Ask the scheduler for an even interleave instead of clusters of LDS/VMEM/VALU
             // work between two MFMAs (a cluster longer than the 64-cycle MFMA shadow is a
@@ -409,10 +381,9 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     constexpr auto Y = std::true_type{};
     constexpr auto N = std::false_type{};
 
-    load_step(0, S0);
-    store_step(0, S0);
-    if (ksteps > 1) load_step(1, S1);
-    if (NSETS == 2 && NBUF == 2 && ksteps > 2) load_step(2, S0);
+    load_step(0);
+    store_step(0);
+    if (ksteps > 1) load_step(1);
     __syncthreads();
 #ifdef KTRACE
     const unsigned long long kt_loop = __builtin_amdgcn_s_memtime();
@@ -443,53 +414,26 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         // 8 waves of a 256x256 tile keep 128 accumulators each; the second wave on the SIMD covers the
         // ds_read latency).  Stores of K step ks+1 go to the other image during slice 0; one barrier
         // ends the step.
-#ifdef KTRACE
-        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto now = [&]() { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
-#define KT(i, expr) { const unsigned long long t_ = now(); expr; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[i] += now() - t_; }
-#else
-#define KT(i, expr) { expr; }
-#endif
         for (int ks = 0; ks < ksteps; ks++) {
             const int buf = ks & 1;
 #pragma unroll
             for (int kk = 0; kk < NSL; kk++) {
-                KT(0, read_frags(buf, kk, fa, fb));
-                KT(1, mma_slice());
+                read_frags(buf, kk, fa, fb);
+                mma_slice();
                 if (kk == 0 && ks + 1 < ksteps) {
-                    KT(2, store_step(buf ^ 1, S1));
-                    if (ks + 2 < ksteps) KT(3, load_step(ks + 2, S1));
+                    store_step(buf ^ 1);
+                    if (ks + 2 < ksteps) load_step(ks + 2);
                 }
             }
-            KT(4, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier());
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
-#ifdef KTRACE
-        if (a.Cin == KT_CIN && a.Cout == KT_COUT && blockIdx.x < 8 && lane == 0) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) g_ktrace[(blockIdx.x * 8 + wave) * 8 + q] = tacc[q];
-        }
-#endif
     } else if constexpr (NBUF == 2) {
         read_frags(0, 0, fa, fb);
         int ks = 0;
-        if constexpr (NSETS == 1) {
-            for (; ks + 2 < ksteps; ks++) k_step(ks, S0, Y, Y, Y);  // steady state
-            if (ks + 1 < ksteps) k_step(ks++, S0, Y, N, Y);          // last but one: nothing left to load
-            k_step(ks, S0, N, N, N);                                 // last: nothing left to stage
-        } else {
-            // K step ks stores set (ks + 1) % 2 (K step ks + 1) and refills it with K step ks + 3
-            for (; ks + 4 < ksteps; ks += 2) {  // steady state, two steps per trip: the sets are compile-time
-                k_step(ks, S1, Y, Y, Y);
-                k_step(ks + 1, S0, Y, Y, Y);
-            }
-            for (; ks < ksteps; ks++) {  // the last (up to four) steps: wave-uniform run-time conditions
-                const bool st = ks + 1 < ksteps, ld = ks + 3 < ksteps;
-                if (ks & 1)
-                    k_step(ks, S0, st, ld, st);
-                else
-                    k_step(ks, S1, st, ld, st);
-            }
-        }
+        for (; ks + 2 < ksteps; ks++) k_step(ks, Y, Y, Y);  // steady state
+        if (ks + 1 < ksteps) k_step(ks++, Y, N, Y);          // last but one: nothing left to load
+        k_step(ks, N, N, N);                                 // last: nothing left to stage
     } else {
         // single LDS image: compute a K step, barrier, overwrite the image with the registers
         // (K step ks+1), refill the registers (ks+2), barrier.  Fragment prefetch only within a step.
@@ -506,8 +450,8 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             }
             if (ks + 1 < ksteps) {
                 __syncthreads();  // every wave has read the image
-                store_step(0, S1);
-                if (ks + 2 < ksteps) load_step(ks + 2, S1);
+                store_step(0);
+                if (ks + 2 < ksteps) load_step(ks + 2);
                 __syncthreads();  // the new image is complete
             }
         }
@@ -530,7 +474,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         __device__ ~KtEnd() {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            if (on) { g_ktrace[slot * 8 + 5] = t1 - t0; g_ktrace[slot * 8 + 6] = t2 - t1; g_ktrace[slot * 8 + 7] = t3 - t2; }
+            if (on) { g_ktrace[slot * 4 + 0] = t1 - t0; g_ktrace[slot * 4 + 1] = t2 - t1; g_ktrace[slot * 4 + 2] = t3 - t2; }
         }
     } kt_end{kt_start, kt_loop, kt_epi, (a.Cin == KT_CIN && a.Cout == KT_COUT && blockIdx.x < 8 && lane == 0) ? 1 : 0, (int)(blockIdx.x * 8 + wave)};
 #endif

@@ -1,14 +1,15 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/ on the GPU box (run through gpurun).
-#   bash scripts/gpu_profile.sh        -> gpurun_out/prof/{trace,pmc_*}
+#   bash scripts/gpu_profile.sh [dtype]  -> gpurun_out/prof[_dtype]/{trace,pmc_*}
 # --pmc passes are separate runs with --kernel-trace only (gpurun refuses other combinations).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof
+DT=${1:-f32}
+OUT=$R/gpurun_out/prof$([ $DT = f32 ] || echo _$DT)
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --dtype $DT --no-split --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"
-SMALL="--no-cpu-baseline --no-profile --steps 1 --warmup 1 --frames-per-step 2"
+SMALL="--dtype $DT --no-split --no-cpu-baseline --no-profile --steps 1 --warmup 1 --frames-per-step 2"
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
   timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$P -- python $R/bench.py $SMALL > /dev/null 2> $OUT/pmc_$P.err; echo "pmc $P rc=$?"
 done

@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""Read the per-phase cycle sums a -DKTRACE build of conv_igemm.hip records for the layer4 downsample conv
-(K loop of the 1frag form): run one 1080p frame with every layer forced to tile configuration CFG."""
+"""Per-phase shader cycles of the conv kernel for one layer shape (instrumentation build).
+
+    make -C infur_amd/csrc clean && make -C infur_amd/csrc EXTRA="-DKTRACE -DKT_CIN=512 -DKT_COUT=2048"
+    python scripts/ktrace.py [dtype] [forced tile configuration]        # on an MI355X
+    make -C infur_amd/csrc clean && make -C infur_amd/csrc              # back to the product build
+
+Prints, for the first 8 workgroups of the last launch with Cin == KT_CIN and Cout == KT_COUT, the cycles each
+wave spent in the prologue (first loads -> first barrier), the K loop and the epilogue (to the last store's
+completion)."""
 import ctypes as C
 import os
 import sys
@@ -8,27 +15,26 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["INFUR_CONV_CFG"] = sys.argv[1] if len(sys.argv) > 1 else "15"
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f32s"
+if len(sys.argv) > 2:
+    os.environ["INFUR_CONV_CFG"] = sys.argv[2]
 from infur_amd import _lib  # noqa: E402
 from infur_amd import processors as P  # noqa: E402
 from infur_amd import weights as W  # noqa: E402
 
-c = P.Context(device=0, dtype="f32s")
+c = P.Context(device=0, dtype=dtype)
 P.Model(c).control(P.ModelCmd.LoadBlob(W.synth_blob(depth=50)))
 fp = P.FramePath(c)
 fr = W.synth_frame(1080, 1920)
 for _ in range(3):
     fp.advance(fr, 1.0)
 L = _lib.load()
-buf = np.zeros(8 * 8 * 8, np.uint64)
+if not hasattr(L, "infur_debug_ktrace"):
+    sys.exit("libinfur_hip.so was not built with -DKTRACE")
+buf = np.zeros(8 * 8 * 4, np.uint64)
 L.infur_debug_ktrace.restype = C.c_int32
 assert L.infur_debug_ktrace(C.c_void_p(buf.ctypes.data)) == 0
-t = buf.reshape(8, 8, 8).astype(np.float64)
-names = ["ds_read+wait", "mfma issue", "store(vmcnt wait+cvt+ds_write)", "global load issue", "barrier", "", "", ""]
-print("cycles per K loop (32 K steps), mean over blocks 0-7, per wave:")
-for q in range(5):
-    print(f"  {names[q]:34s}", " ".join(f"{t[:, w, q].mean():9.0f}" for w in range(8)))
-tot = t[:, :, :5].sum(axis=2)
-print("  total".ljust(36), " ".join(f"{tot[:, w].mean():9.0f}" for w in range(8)))
-for q, nm in ((5, "prologue (start -> K loop)"), (6, "K loop"), (7, "epilogue (incl. vmcnt(0))")):
-    print(f"  {nm:34s}", " ".join(f"{t[:, w, q].mean():9.0f}" for w in range(8)))
+t = buf.reshape(8, 8, 4).astype(np.float64)
+print("shader cycles, mean over workgroups 0-7, per wave:")
+for q, nm in ((0, "prologue"), (1, "K loop"), (2, "epilogue")):
+    print(f"  {nm:10s}", " ".join(f"{t[:, w, q].mean():9.0f}" for w in range(8)))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-dispatch SQ / memory counters of one bench configuration (run through gpurun) -> gpurun_out/pmcs/
-#   bash scripts/pmc_split.sh f32s
+#   bash scripts/pmc_detail.sh f32s
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmcs
 DT=${1:-f32s}

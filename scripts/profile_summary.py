@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output (gpurun_out/prof/...) into the tracked files under profiles/.
 
-    python scripts/profile_summary.py gpurun_out/prof r01
+    python scripts/profile_summary.py gpurun_out/prof r01 [dtype]
 
 Inputs (any subset):
   <dir>/trace/**/_kernel_stats.csv        from  rocprofv3 --kernel-trace --stats -- python bench.py
@@ -74,7 +74,8 @@ def main():
             traffic[k] = {"launches": max(len(f), len(w)), "read_bytes_per_launch": rd, "write_bytes_per_launch": wb}
             md.append(f"| `{k}` | {max(len(f), len(w))} | {rd / 1e6:.1f} | {wb / 1e6:.1f} | {sum(du) / max(len(du), 1) / 1e3:.1f} |")
         md.append("")
-        with open(os.path.join(out, "traffic_latest.json"), "w") as fjs:
+        dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
+        with open(os.path.join(out, "traffic_latest.json" if dtype == "f32" else f"traffic_{dtype}.json"), "w") as fjs:
             json.dump({"tag": tag, "note": "bytes per launch, averaged over all launches of the kernel in one frame pass; "
                        "read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB", "kernels": traffic}, fjs, indent=1)
     sq, gr = pmc(os.path.join(d, "pmc_SQ")), pmc(os.path.join(d, "pmc_GRBM"))
