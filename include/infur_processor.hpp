@@ -50,11 +50,14 @@ struct Tensor3 {
 /// RAII owner of an infur_ctx (one GPU, one stream; not thread-safe)
 class Context {
 public:
-    explicit Context(int device = 0, bool compute_aux = true) {
+    /// compute_dtype: INFUR_DTYPE_F32 (exact f32 MFMA), INFUR_DTYPE_F32_SPLIT (f32 tensors, f16 matrix cores with
+    /// hi+lo operand pairs: f32-grade logits at ~1.9x the rate) or INFUR_DTYPE_F16
+    explicit Context(int device = 0, bool compute_aux = true, uint32_t compute_dtype = INFUR_DTYPE_F32) {
         infur_options o;
         infur_options_default(&o);
         o.device = device;
         o.compute_aux = compute_aux ? 1 : 0;
+        o.compute_dtype = compute_dtype;
         status_ = infur_ctx_create(&o, &ctx_);
     }
     ~Context() { infur_ctx_destroy(ctx_); }

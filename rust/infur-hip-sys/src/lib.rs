@@ -47,6 +47,8 @@ pub const INFUR_SCALE_NEAREST: u32 = 0;
 pub const INFUR_SCALE_BILINEAR: u32 = 1;
 pub const INFUR_DTYPE_F32: u32 = 0;
 pub const INFUR_DTYPE_F16: u32 = 1;
+/// f32 tensors, conv GEMMs on the f16 matrix cores with hi+lo operand pairs (f32-grade logits, ~1.9x the f32 MFMA rate)
+pub const INFUR_DTYPE_F32_SPLIT: u32 = 2;
 
 extern "C" {
     pub fn infur_abi_version() -> u32;
