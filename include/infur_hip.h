@@ -84,6 +84,8 @@ typedef struct infur_options {
     uint32_t no_autotune;      /* 0 (default): the first advance at a new frame size times the tile
                                   configurations of the conv kernel per layer shape and keeps the fastest
                                   (results are bit-identical across configurations); 1: fixed heuristic */
+    uint32_t no_fuse_downsample; /* 0 (default): the first block of a stage runs conv3 and its downsample branch as one
+                                  two-source GEMM (the branch tensor is never written); 1: two launches + residual */
     void* stream;          /* optional caller-owned hipStream_t; NULL = context creates one */
 } infur_options;
 

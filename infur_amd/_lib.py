@@ -42,6 +42,7 @@ class Options(C.Structure):
         ("winograd_min_cin", C.c_uint32),
         ("winograd_tile", C.c_uint32),
         ("no_autotune", C.c_uint32),
+        ("no_fuse_downsample", C.c_uint32),
         ("stream", C.c_void_p),
     ]
 

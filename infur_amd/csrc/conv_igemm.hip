@@ -107,7 +107,11 @@ constexpr int min_waves_per_simd(int bm, int bn, int wm, int wn, int nbuf) {
 // loop and the epilogue only adds and stores (stores need no waiting: the wave retires at once and
 // its CU slot starts the next tile).  Without it the epilogue of a 1x1 conv with K = 512 takes
 // longer than its K loop (measured with s_memtime: 36.5k vs 30.6k cycles).
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF, bool SPLIT = false, bool G1 = false, bool RESPF = false>
+// DUAL (with G1): the K loop runs over two activation tensors in turn (ConvArgs.in, then ConvArgs.in2 sampled
+// with stride2) against one weight matrix whose rows are the two 1x1 kernels side by side: conv3 and the
+// downsample branch of a bottleneck's first block in one launch, without writing and re-reading the branch.
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF, bool SPLIT = false, bool G1 = false, bool RESPF = false,
+          bool DUAL = false>
 __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN, NBUF))
     conv_igemm_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
     constexpr bool F32 = std::is_same<T, float>::value && !SPLIT;
@@ -158,8 +162,9 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
+    static_assert(!DUAL || (G1 && !RESPF), "DUAL is a form of the 1x1 GEMM addressing");
     const int M = a.OH * a.OW;
-    const int Ktot = a.KH * a.KW * a.Cin;
+    const int Ktot = DUAL ? a.Cin + a.Cin2 : a.KH * a.KW * a.Cin;
 
     // Buffer descriptors: hardware bounds checking turns an out-of-range offset into a
     // zero result, so padding taps and ragged tiles need no branches in the K loop.
@@ -181,7 +186,11 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         a_ix0[i] = ox * a.stride - a.pad;
         if constexpr (G1)  // reuse a_iy0 as the fixed byte offset of the row's pixel
             a_iy0[i] = m < M ? (int)((unsigned)(oy * a.stride * a.W + ox * a.stride) * (unsigned)(a.Cin * ES) + c4 * 16u) : (int)OOB;
+        if constexpr (DUAL)  // and a_ix0 as the offset of the same output pixel in the second tensor
+            a_ix0[i] = m < M ? (int)((unsigned)(oy * a.stride2 * a.W2 + ox * a.stride2) * (unsigned)(a.Cin2 * ES) + c4 * 16u) : (int)OOB;
     }
+    const auto in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(DUAL ? a.in2 : a.in), 0,
+                                                            DUAL ? (unsigned)((size_t)a.H2 * a.W2 * a.Cin2 * ES) : 0u, 0x00020000);
     unsigned b_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; i++) {
@@ -203,15 +212,21 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     // steps ahead -- was measured for the split mode: no gain, and 128x128 tiles spill.)
     u32x4 ra[A_IT], rb[B_IT];
     const int cchunks = a.Cin / BK;  // K steps per filter tap
-    const int ksteps = a.KH * a.KW * cchunks;
+    const int ksteps = DUAL ? cchunks + a.Cin2 / BK : a.KH * a.KW * cchunks;
     int ky = 0, kx = 0, cc = 0;  // coordinates of the K step being LOADED
 
     int kload = 0;  // G1: K step the next load_a fetches
     auto load_a = [&]() {
         if constexpr (G1) {
-            const unsigned so = (unsigned)kload * (unsigned)ROW_BYTES;
+            if (DUAL && kload >= cchunks) {  // wave-uniform: the second tensor's K steps
+                const unsigned so = (unsigned)(kload - cchunks) * (unsigned)ROW_BYTES;
 #pragma unroll
-            for (int i = 0; i < A_IT; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (unsigned)a_iy0[i], so, 0);
+                for (int i = 0; i < A_IT; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in2_rsrc, (unsigned)a_ix0[i], so, 0);
+            } else {
+                const unsigned so = (unsigned)kload * (unsigned)ROW_BYTES;
+#pragma unroll
+                for (int i = 0; i < A_IT; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (unsigned)a_iy0[i], so, 0);
+            }
             kload++;
             return;
         }
@@ -567,13 +582,13 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     }
 }
 
-template <typename T, typename OutT, bool SPLIT, bool G1, bool RESPF, int BM, int BN, int WM, int WN, int NBUF>
+template <typename T, typename OutT, bool SPLIT, bool G1, bool RESPF, bool DUAL, int BM, int BN, int WM, int WN, int NBUF>
 static hipError_t launch_cfg_g(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM;
     const int ntiles = (a.Cout + BN - 1) / BN;
     const size_t lds = (size_t)lds_bytes(BM, BN, WM, WN, NBUF);
-    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT, G1, RESPF>;
+    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT, G1, RESPF, DUAL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -587,17 +602,25 @@ static hipError_t launch_cfg_g(const ConvArgs& a, hipStream_t s) {
 
 template <typename T, typename OutT, bool SPLIT, int BM, int BN, int WM, int WN, int NBUF = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
-    // residual prefetch: only where a lane holds <= 64 accumulators (room for 64 more registers), the
-    // output has the operand type, and -- a residual only ever enters a 1x1 conv -- in the G1 form
-    constexpr bool kCanPf = (BM / WM) * (BN / WN) <= 64 * 64 && std::is_same<T, OutT>::value;
     const bool g1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
-    if constexpr (kCanPf) {
-        if (a.res && g1 && (a.Cout & 3) == 0) return launch_cfg_g<T, OutT, SPLIT, SPLIT, true, BM, BN, WM, WN, NBUF>(a, s);
+    constexpr bool kSameType = std::is_same<T, OutT>::value;  // the f16 -> f32 kernel only ever runs the classifier
+    if constexpr (kSameType) {
+        if (a.in2) {
+            if (!g1 || a.stride != 1 || a.res) return hipErrorInvalidValue;
+            return launch_cfg_g<T, OutT, SPLIT, true, false, true, BM, BN, WM, WN, NBUF>(a, s);
+        }
+        // residual prefetch: only where a lane holds <= 64 accumulators (room for 64 more registers) -- a
+        // residual only ever enters a 1x1 conv, so this is a G1 form
+        constexpr bool kCanPf = (BM / WM) * (BN / WN) <= 64 * 64;
+        if constexpr (kCanPf) {
+            if (a.res && g1 && (a.Cout & 3) == 0) return launch_cfg_g<T, OutT, SPLIT, true, true, false, BM, BN, WM, WN, NBUF>(a, s);
+        }
+    } else if (a.in2) {
+        return hipErrorInvalidValue;
     }
-    // 1x1 without padding: the plain-GEMM addressing form (only built for the f16-rate split mode,
-    // where vector address arithmetic in the K loop costs MFMA issue slots)
-    if (SPLIT && g1) return launch_cfg_g<T, OutT, SPLIT, SPLIT, false, BM, BN, WM, WN, NBUF>(a, s);
-    return launch_cfg_g<T, OutT, SPLIT, false, false, BM, BN, WM, WN, NBUF>(a, s);
+    // 1x1 without padding: the plain-GEMM addressing form (no vector address arithmetic in the K loop)
+    if (g1) return launch_cfg_g<T, OutT, SPLIT, true, false, false, BM, BN, WM, WN, NBUF>(a, s);
+    return launch_cfg_g<T, OutT, SPLIT, false, false, false, BM, BN, WM, WN, NBUF>(a, s);
 }
 
 // ---- tile configurations ----
@@ -650,7 +673,7 @@ bool conv_igemm_config_valid(const ConvArgs& a, int cfg) {
 template <typename T, typename OutT, bool SPLIT = false>
 static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
     constexpr size_t ES = sizeof(T);
-    if (a.Cin % (int)(ROW_BYTES / ES) != 0) return hipErrorInvalidValue;
+    if (a.Cin % (int)(ROW_BYTES / ES) != 0 || (a.in2 && a.Cin2 % (int)(ROW_BYTES / ES) != 0)) return hipErrorInvalidValue;
     // 32-bit buffer offsets with 0x80000000 as the out-of-range marker
     if ((size_t)a.H * a.W * a.Cin * ES >= 0x80000000ull || (size_t)a.Cout * a.KH * a.KW * a.Cin * ES >= 0x80000000ull)
         return hipErrorInvalidValue;

@@ -56,6 +56,11 @@ struct ConvLayer {
     float* d_u = nullptr;  // Winograd-domain weights U[16][cout][cin] (f32 stride-1 3x3 convs only)
     // INFUR_DTYPE_F32_SPLIT: d_w / d_u hold f16 (hi, lo) pairs of w * w_scale / u * u_scale (powers of two)
     float w_scale = 1.0f, u_scale = 1.0f;
+    // conv3 of a stage's first block: its weights and the downsample branch's side by side ([cout][cin + ds.cin],
+    // context dtype), the two biases summed -- the two-source GEMM of run_conv_dual
+    void* d_wcat = nullptr;
+    float* d_bcat = nullptr;
+    float wcat_scale = 1.0f;
 };
 
 struct ProfRec {
@@ -389,6 +394,9 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         if (L.role == 's') continue;
         e = launch_absmax((const float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, d_max + 2 * i, c->stream);
         if (e == hipSuccess && L.d_u) e = launch_absmax(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, d_max + 2 * i + 1, c->stream);
+        // (a 1x1 conv has no Winograd weights: the second slot takes the conv3 ++ downsample matrix)
+        if (e == hipSuccess && L.d_wcat)
+            e = launch_absmax((const float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), d_max + 2 * i + 1, c->stream);
     }
     std::vector<float> mx(2 * n, 0.0f);
     if (e == hipSuccess) e = hipMemcpyAsync(mx.data(), d_max, 2 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
@@ -407,6 +415,10 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         if (L.d_u) {
             L.u_scale = pow2_for(mx[2 * i + 1]);
             HIPCHK(c, launch_split_weights(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, L.u_scale, c->stream));
+        }
+        if (L.d_wcat) {
+            L.wcat_scale = pow2_for(mx[2 * i + 1]);
+            HIPCHK(c, launch_split_weights((float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), L.wcat_scale, c->stream));
         }
     }
     return INFUR_OK;
@@ -456,6 +468,8 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
             return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' data out of range", name);
         total += align_up(wn, 256) + align_up(bn, 256);  // upper bound (f16 weights take half)
         if (wino_eligible(c, L)) total += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
+        if (L.role == '3' && i + 1 < n && g[i + 1].role == 'd')
+            total += align_up((size_t)L.cout * (L.cin + g[i + 1].cin) * 4, 256) + align_up(bn, 256);
     }
 
     model_free(c);
@@ -481,6 +495,19 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
             off += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
             HIPCHK(c, launch_wino_weights(src_w, L.cout, L.cin, wino_mt(c), L.d_u, c->stream));
         }
+    }
+    // conv3 ++ downsample weight matrices for the two-source GEMM
+    for (uint32_t i = 0; i + 1 < n; i++) {
+        ConvLayer& L = g[i];
+        const ConvLayer& D = g[i + 1];
+        if (L.role != '3' || D.role != 'd') continue;
+        const size_t es = ctx_f16(c) ? 2 : 4;
+        L.d_wcat = (uint8_t*)c->d_weights + off;
+        off += align_up((size_t)L.cout * (L.cin + D.cin) * 4, 256);
+        L.d_bcat = (float*)((uint8_t*)c->d_weights + off);
+        off += align_up((size_t)L.cout * 4, 256);
+        HIPCHK(c, launch_concat_rows(L.d_w, (size_t)L.cin * es, D.d_w, (size_t)D.cin * es, L.d_wcat, L.cout, c->stream));
+        HIPCHK(c, launch_add_f32(L.d_b, D.d_b, L.d_bcat, L.cout, c->stream));
     }
     if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT) RETIF(split_weights(c, g));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -520,7 +547,7 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
     }
     if (c->opt.no_autotune) return INFUR_OK;
     const std::array<int, 13> key = {a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.stride, a.dil, a.batch,
-                                     a.res ? 1 : 0, mode, out_f32};
+                                     a.res ? 1 : (a.in2 ? 2 : 0), mode, out_f32};
     auto it = c->tuned.find(key);
     if (it != c->tuned.end() && conv_igemm_config_valid(a, it->second)) {
         *cfg = it->second;
@@ -630,6 +657,35 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
     return INFUR_OK;
 }
 
+// ---- a stage's first block: conv3(t2) + downsample(x) + biases, ReLU, as one two-source GEMM ----
+// (instead of downsample -> tensor -> conv3 with that tensor as the residual: the branch output is never
+// written or re-read, and one kernel's prologue/epilogue disappears)
+int32_t run_conv_dual(infur_ctx* c, const ConvLayer& L3, const ConvLayer& D, const Tensor& t2, const Tensor& x, Tensor* out) {
+    const int oh = t2.h, ow = t2.w;
+    if (conv_out(x.h, 1, D.stride, 0, 1) != oh || conv_out(x.w, 1, D.stride, 0, 1) != ow)
+        return fail(c, INFUR_E_SHAPE, "downsample branch %dx%d/%d does not land on %dx%d", x.w, x.h, D.stride, ow, oh);
+    const int mode = ctx_mode(c);
+    RETIF(talloc(c, oh, ow, L3.cout, act_es(c), out));
+    ConvArgs a;
+    a.in = t2.p; a.wt = L3.d_wcat; a.bias = L3.d_bcat; a.res = nullptr; a.out = out->p;
+    a.H = t2.h; a.W = t2.w; a.Cin = t2.c; a.OH = oh; a.OW = ow; a.Cout = L3.cout;
+    a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.relu = L3.relu ? 1 : 0;
+    a.in2 = x.p; a.H2 = x.h; a.W2 = x.w; a.Cin2 = x.c; a.stride2 = D.stride;
+    if (mode == INFUR_DTYPE_F32_SPLIT) {
+        a.a_scale = kSplitActScale;
+        a.acc_scale = 1.0f / (a.a_scale * L3.wcat_scale);
+    }
+    const double flops = 2.0 * oh * ow * (double)L3.cout * (L3.cin + D.cin);
+    const double bytes = (double)t2.bytes() + (double)oh * ow * x.c * x.es + (double)out->bytes() + (double)L3.cout * (L3.cin + D.cin) * t2.es;
+    int cfg = -1;
+    RETIF(pick_cfg(c, a, mode, mode != 1 ? 1 : 0, &cfg));
+    {
+        ProfScope ps(c, L3.name + "+downsample", conv_igemm_config_name(cfg, mode), flops, bytes);
+        HIPCHK(c, launch_conv_igemm(a, mode, mode != 1 ? 1 : 0, cfg, c->stream));
+    }
+    return INFUR_OK;
+}
+
 // FCN-ResNet forward from a packed BGR frame resident on the device.
 // Leaves the output-stride-8 logits in c->out_low / c->aux_low (NHWC).
 int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
@@ -664,14 +720,20 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
         RETIF(run_conv(c, c1, x, nullptr, &t1));
         RETIF(run_conv(c, c2, t1, nullptr, &t2));
         pool_release(c, t1);
-        if (has_ds) {
-            // keep_activations order follows the blob (conv3 before downsample): fix up below
-            RETIF(run_conv(c, c->convs[ci + 3], x, nullptr, &idt));
+        // the per-layer read-back (keep_activations) wants the branch tensor, so it runs the unfused form
+        const bool fused = has_ds && c3.d_wcat && !c->opt.keep_activations && !c->opt.no_fuse_downsample;
+        if (fused) {
+            RETIF(run_conv_dual(c, c3, c->convs[ci + 3], t2, x, &y));
+        } else {
+            if (has_ds) {
+                // keep_activations order follows the blob (conv3 before downsample): fix up below
+                RETIF(run_conv(c, c->convs[ci + 3], x, nullptr, &idt));
+            }
+            RETIF(run_conv(c, c3, t2, has_ds ? &idt : &x, &y));
+            if (has_ds && c->opt.keep_activations) std::swap(c->kept[c->kept.size() - 1], c->kept[c->kept.size() - 2]);
         }
-        RETIF(run_conv(c, c3, t2, has_ds ? &idt : &x, &y));
-        if (has_ds && c->opt.keep_activations) std::swap(c->kept[c->kept.size() - 1], c->kept[c->kept.size() - 2]);
         pool_release(c, t2);
-        if (has_ds) pool_release(c, idt);
+        if (has_ds && !fused) pool_release(c, idt);
         ci += has_ds ? 4 : 3;
         const bool end_l3 = c1.name.compare(0, 16, "backbone.layer3.") == 0 &&
                             c->convs[ci].name.compare(0, 16, "backbone.layer4.") == 0;

@@ -27,6 +27,11 @@ struct ConvArgs {
     // load time (launch_split_weights), and the accumulators are multiplied by acc_scale =
     // 1 / (a_scale * weight scale) before bias / residual / ReLU.  Powers of two: exact.
     float a_scale = 1.0f, acc_scale = 1.0f;
+    // two-source 1x1 GEMM (a bottleneck's conv3 and its downsample branch as ONE launch, no residual tensor):
+    // out = W[:, :Cin] * in  +  W[:, Cin:] * in2(stride2)  + bias.  in2 == nullptr: ordinary convolution.
+    // Requires KH = KW = 1, pad = 0, stride = 1; wt rows are Cin + Cin2 long; OH x OW = ceil(H2/stride2) x ...
+    const void* in2 = nullptr;  // [H2][W2][Cin2]
+    int H2 = 0, W2 = 0, Cin2 = 0, stride2 = 1;
 };
 
 // conv as implicit GEMM on the matrix cores.  mode 0: f32 operands on the f32 MFMA (Cin % 32 == 0);
@@ -68,6 +73,10 @@ hipError_t launch_repack_oihw_to_ohwi(const float* src, void* dst, int f16, int 
 // [32 x f16 hi][32 x f16 lo] of w * scale, hi = rne(w*scale), lo = rne(w*scale - hi).
 hipError_t launch_absmax(const float* w, size_t n, float* out, hipStream_t s);
 hipError_t launch_split_weights(float* w, size_t n, float scale, hipStream_t s);
+// two-source GEMM weights (one-off at load): out[r] = a[r] ++ b[r] for `rows` rows of a_bytes / b_bytes
+// (multiples of 16); sum[i] = x[i] + y[i]
+hipError_t launch_concat_rows(const void* a, size_t a_bytes, const void* b, size_t b_bytes, void* out, int rows, hipStream_t s);
+hipError_t launch_add_f32(const float* x, const float* y, float* sum, int n, hipStream_t s);
 // OIHW (O=64,I=3,7x7) -> [ky][kx][c][o] for the stem kernel
 hipError_t launch_repack_stem(const float* src, float* dst, hipStream_t s);
 

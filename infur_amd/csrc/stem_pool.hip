@@ -251,4 +251,33 @@ hipError_t launch_split_weights(float* w, size_t n, float scale, hipStream_t s) 
     return hipGetLastError();
 }
 
+// ---- weights of the two-source 1x1 GEMM (conv3 ++ downsample, conv_igemm.hip DUAL) ----
+__global__ void concat_rows_kernel(const uint4* __restrict__ a, int a16, const uint4* __restrict__ b, int b16,
+                                   uint4* __restrict__ out, size_t total16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total16) return;
+    const int w = a16 + b16;
+    const size_t r = i / w;
+    const int c = (int)(i - r * w);
+    out[i] = c < a16 ? a[r * a16 + c] : b[r * b16 + (c - a16)];
+}
+
+hipError_t launch_concat_rows(const void* a, size_t a_bytes, const void* b, size_t b_bytes, void* out, int rows, hipStream_t s) {
+    if (a_bytes % 16 || b_bytes % 16) return hipErrorInvalidValue;
+    const size_t total16 = (a_bytes + b_bytes) / 16 * (size_t)rows;
+    hipLaunchKernelGGL(concat_rows_kernel, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const uint4*)a,
+                       (int)(a_bytes / 16), (const uint4*)b, (int)(b_bytes / 16), (uint4*)out, total16);
+    return hipGetLastError();
+}
+
+__global__ void add_f32_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ sum, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sum[i] = x[i] + y[i];
+}
+
+hipError_t launch_add_f32(const float* x, const float* y, float* sum, int n, hipStream_t s) {
+    hipLaunchKernelGGL(add_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, sum, n);
+    return hipGetLastError();
+}
+
 }  // namespace infur

@@ -19,6 +19,10 @@ pub struct infur_options {
     pub compute_aux: u32,
     pub profile: u32,
     pub keep_activations: u32,
+    pub winograd_min_cin: u32,
+    pub winograd_tile: u32,
+    pub no_autotune: u32,
+    pub no_fuse_downsample: u32,
     pub stream: *mut c_void,
 }
 

@@ -364,11 +364,13 @@ def test_profile_records(blob50):
     rgba, _ = FramePath(c2).advance(W.synth_frame(96, 128), 1.0)
     recs = c2.profile()
     names = [r["name"] for r in recs]
-    # 57 convs + maxpool + fused post; the 11 stride-1 3x3 convs with Cin >= 256 (layer3 x6, layer4 x3,
-    # both heads) run in the Winograd domain and add an input and an output transform each
+    # 57 convs in 53 launches (conv3 and the downsample branch of each stage's first block are one two-source
+    # GEMM) + maxpool + fused post; the 11 stride-1 3x3 convs with Cin >= 256 (layer3 x6, layer4 x3, both
+    # heads) run in the Winograd domain and add an input and an output transform each
     wino = [r for r in recs if r["kernel"] in ("wino_input", "wino_output")]
     assert names[0] == "backbone.conv1" and names[-1] == "out.resize+colorcode"
-    assert len(wino) == 22 and len(recs) == 57 + 2 + len(wino)
+    assert sum(n.endswith("conv3+downsample") for n in names) == 4
+    assert len(wino) == 22 and len(recs) == 53 + 2 + len(wino)
     algo = sum(r["algo_flops"] for r in recs)
     assert abs(algo - W.conv_flops(96, 128)["total"]) < 1e-6 * algo
     assert sum(r["flops"] for r in recs) < algo  # Winograd executes 2.25x - 4x fewer MACs on those layers

@@ -112,3 +112,20 @@ def test_split_small_and_large_values(oracle):
         print(f"classifier weights x{scale:g}: rel err {e:.2e}")
         assert e < SPLIT_TOL
         c.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f32s", SPLIT_TOL), ("f16", 5e-3)])
+def test_fused_downsample_matches_unfused(blob50, dtype, tol):
+    """conv3 + downsample as one two-source GEMM (default) against the two-launch form with a residual tensor"""
+    fr = W.synth_frame(200, 328, index=4)
+    lows = {}
+    for fuse in (True, False):
+        c = Context(device=0, dtype=dtype, fuse_downsample=fuse)
+        m = Model(c).control(ModelCmd.LoadBlob(blob50))
+        FramePath(c).advance(fr, 1.0)
+        lows[fuse] = [x.copy() for x in m.lowres()]
+        c.close()
+    for a, b in zip(lows[True], lows[False]):
+        e = rel_err(a, b.astype(np.float64))
+        print(f"{dtype}: fused vs unfused {e:.2e}")
+        assert e < tol
