@@ -129,3 +129,29 @@ def test_fused_downsample_matches_unfused(blob50, dtype, tol):
         e = rel_err(a, b.astype(np.float64))
         print(f"{dtype}: fused vs unfused {e:.2e}")
         assert e < tol
+
+
+def test_split_activation_range(oracle):
+    """The static activation scale (2^2; 2^-3 on Winograd-domain inputs) keeps full precision while the scaled value stays inside the f16
+    pair's range: 100x larger activations than the synthetic model's are still f32-grade; 10^4 x larger ones
+    saturate (MODE.FP16_OVFL clamps the conversions) -- finite logits, no inf/NaN poisoning."""
+    from oracle.infur_oracle import TorchModel
+
+    fr = W.synth_frame(64, 96, index=2)
+    for gain, accurate in ((100.0, True), (1.0e4, False)):
+        # scaling the stem's weights and bias scales every activation up to the first BN-free add by `gain`
+        # (ReLU and max-pool are positively homogeneous; biases downstream are not, which is fine)
+        tensors = [(s, w * np.float32(gain), b * np.float32(gain)) if s.name == "backbone.conv1" else (s, w, b)
+                   for s, w, b in W.synth_tensors(depth=50)]
+        blob = W.pack_blob(tensors, 50, W.NUM_CLASSES, True)
+        c = Context(device=0, dtype="f32s")
+        m = Model(c).control(ModelCmd.LoadBlob(blob))
+        FramePath(c).advance(fr, 1.0)
+        lo, _ = m.lowres()
+        assert np.isfinite(lo).all()
+        if accurate:
+            tl, _ = TorchModel(blob).forward_lowres(oracle.pack_normalize(fr))
+            e = rel_err(lo, tl.numpy())
+            print(f"activations x{gain:g}: rel err {e:.2e}")
+            assert e < SPLIT_TOL
+        c.close()
