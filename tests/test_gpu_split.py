@@ -155,3 +155,49 @@ def test_split_activation_range(oracle):
             print(f"activations x{gain:g}: rel err {e:.2e}")
             assert e < SPLIT_TOL
         c.close()
+
+
+@pytest.mark.parametrize("wh", [(1, 1), (7, 5), (33, 17), (130, 66), (257, 129)])
+def test_split_tiny_and_ragged_frames(oracle, blob50, wh):
+    """Degenerate sizes in the split mode: 1-pixel feature maps, ragged GEMM tiles in the two-source and the
+    residual-prefetch forms, partial Winograd tiles."""
+    from oracle.infur_oracle import TorchModel
+
+    w, h = wh
+    fr = W.synth_frame(h, w, index=w + h)
+    c = Context(device=0, dtype="f32s")
+    m = Model(c).control(ModelCmd.LoadBlob(blob50))
+    rgba, _ = FramePath(c).advance(fr, 1.0)
+    lo, la = m.lowres()
+    tl, ta = TorchModel(blob50).forward_lowres(oracle.pack_normalize(fr))
+    assert lo.shape == tuple(tl.shape)
+    assert rel_err(lo, tl.numpy()) < SPLIT_TOL and rel_err(la, ta.numpy()) < SPLIT_TOL
+    assert (rgba == oracle.colorcode(oracle.upsample_bilinear(lo, h, w))).all()
+    c.close()
+
+
+def test_split_resnet101_and_stream(oracle):
+    """FCN-ResNet101 in the split mode, through the streaming entry points (depth-2 ring) and the batch call"""
+    from oracle.infur_oracle import TorchModel
+
+    from infur_amd.app import StreamPath
+
+    blob = W.synth_blob(depth=101)
+    tm = TorchModel(blob)
+    c = Context(device=0, dtype="f32s")
+    m = Model(c).control(ModelCmd.LoadBlob(blob))
+    frames = [W.synth_frame(96, 160, index=i) for i in range(3)]
+    ref = [oracle.colorcode(oracle.upsample_bilinear(tm.forward_lowres(oracle.pack_normalize(f))[0].numpy(), 96, 160)) for f in frames]
+    masks = FramePath(c).advance_batch(frames, 1.0)
+    for rgba, want in zip(masks, ref):
+        assert rgba.shape == want.shape
+        assert (rgba != want).any(axis=-1).mean() < 2e-3  # near-tie pixels only
+    lo, _ = m.lowres()
+    assert rel_err(lo, tm.forward_lowres(oracle.pack_normalize(frames[-1]))[0].numpy()) < SPLIT_TOL
+    sp = StreamPath(c, depth=2)
+    outs = list(sp.run(enumerate(frames), 1.0))
+    assert [fid for fid, _ in outs] == [0, 1, 2]
+    for (_, rgba), got in zip(outs, masks):
+        assert (rgba == got).all()  # the ring and the batch call run the same path
+    sp.close()
+    c.close()
