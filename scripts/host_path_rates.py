@@ -1,16 +1,17 @@
-"""dev: PCIe-inclusive rates of the host-pointer entry points at 1080p (for DESIGN.md)."""
+"""PCIe-inclusive rates of the host-pointer entry points at 1080p (for DESIGN.md):  python scripts/host_path_rates.py [dtype]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from infur_amd import weights as W
 from infur_amd.app import StreamPath
 from infur_amd.processors import Context, FramePath, Model, ModelCmd
-c = Context(device=0); Model(c).control(ModelCmd.LoadBlob(W.synth_blob()))
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
+c = Context(device=0, dtype=dtype); Model(c).control(ModelCmd.LoadBlob(W.synth_blob()))
 frames = [W.synth_frame(1080, 1920, index=i) for i in range(4)]
 fp = FramePath(c)
 for f in frames[:2]: fp.advance(f, 1.0)
 t = time.perf_counter(); n = 16
 for i in range(n): fp.advance(frames[i % 4], 1.0)
-print(f"infur_frame_advance (host buffers, synchronous) 1080p scale 1.0: {n / (time.perf_counter() - t):.1f} frames/s")
+print(f"[{dtype}] infur_frame_advance (host buffers, synchronous) 1080p scale 1.0: {n / (time.perf_counter() - t):.1f} frames/s")
 for depth in (2, 3):
     sp = StreamPath(c, depth=depth)
     list(sp.run([(i, frames[i % 4]) for i in range(4)], 1.0))
