@@ -15,22 +15,36 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------
-// stem: one thread = one output pixel x 64 output channels (64 f32 accumulators);
-// weights are wave-uniform -> scalar loads; the normalised input patch lives in LDS.
-// workgroup = 8 rows x 32 cols of output pixels.
+// stem as an implicit GEMM on the f32 matrix core (v_mfma_f32_32x32x2_f32, exact f32):
+//   M = output pixels, N = 64 channels, K = 7*7*3 = 147 (+1 zero row), k = (ky*7 + kx)*3 + c.
+// workgroup = 8 rows x 32 cols of output pixels, 4 waves; a wave owns 2 rows (two 32-pixel M blocks) x 64
+// channels (two N blocks): 4 accumulator tiles, 74 k-pairs x 4 MFMAs.  The normalised 21 x 69 x 3 input
+// patch (filled straight from the u8 frame through the LUT, zero padding of the NORMALISED tensor) and the
+// 148 x 64 weight matrix live in LDS; a lane reads its A value at patch[pixel base + offset(k)] -- (kx, c) are
+// contiguous in a patch row, so offset(k) = (k / 21) * row + k % 21 is a compile-time constant per k.
+// The MFMA takes the weights as the row operand: a lane ends up with one pixel x 4 consecutive channels per
+// register group (16-byte stores).
 // ---------------------------------------------------------------------------------------
 constexpr int ST_TH = 8, ST_TW = 32;
 constexpr int ST_PH = 2 * ST_TH + 5;  // 21 input rows
 constexpr int ST_PW = 2 * ST_TW + 5;  // 69 input cols
+constexpr int ST_K = 147, ST_KP = 148;
+
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int stem_koff(int k) {  // float offset of tap k relative to the pixel's patch origin
+    return (k / 21) * (ST_PW * 3) + (k % 21);
+}
 
 template <typename OutT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
     stem_conv7x7_kernel(const uint8_t* __restrict__ bgr, int H, int W,
-                        const float* __restrict__ wt,    // [7][7][3][64]
+                        const float* __restrict__ wt,    // [147][64]  (k, cout)
                         const float* __restrict__ bias,  // [64]
                         const float* __restrict__ lut,   // [3][256] RGB order
                         OutT* __restrict__ out, int OH, int OW) {
     __shared__ float patch[ST_PH * ST_PW * 3];
+    __shared__ float wsm[ST_KP * 64];
     const int tid = threadIdx.x;
     const int oy0 = blockIdx.y * ST_TH, ox0 = blockIdx.x * ST_TW;
     const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
@@ -49,49 +63,62 @@ __global__ void __launch_bounds__(256)
         patch[i * 3 + 1] = v1;
         patch[i * 3 + 2] = v2;
     }
+    for (int i = tid; i < ST_KP * 64 / 4; i += 256) {
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);  // row 147: the zero row that pads K to a multiple of 2
+        if (i < ST_K * 64 / 4) w4 = reinterpret_cast<const float4*>(wt)[i];
+        reinterpret_cast<float4*>(wsm)[i] = w4;
+    }
     __syncthreads();
 
-    const int py = tid >> 5, px = tid & 31;
-    float acc[64];
+    const int wave = tid >> 6, lane = tid & 63;
+    const int px = lane & 31, half = lane >> 5;
+    f32x16s acc[2][2];
 #pragma unroll
-    for (int c = 0; c < 64; c++) acc[c] = 0.f;
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    const float* pbase = patch + ((2 * py) * ST_PW + 2 * px) * 3;
-    for (int ky = 0; ky < 7; ky++) {
-        const float* prow = pbase + ky * ST_PW * 3;
-        const float* wrow = wt + ky * 21 * 64;
-#pragma unroll 3
-        for (int j = 0; j < 21; j++) {  // (kx, c) flattened: contiguous in the patch row
-            const float v = prow[j];
-            const float* w = wrow + j * 64;
+    const float* pa0 = patch + ((2 * (2 * wave + 0)) * ST_PW + 2 * px) * 3;
+    const float* pa1 = patch + ((2 * (2 * wave + 1)) * ST_PW + 2 * px) * 3;
+    const float* pw = wsm + half * 64 + px;
 #pragma unroll
-            for (int c = 0; c < 64; c++) acc[c] = fmaf(v, w[c], acc[c]);
-        }
+    for (int s = 0; s < ST_KP / 2; s++) {
+        // lanes 0-31 take k = 2s, lanes 32-63 k = 2s + 1; tap 147 does not exist (its weights are zero): read tap 146
+        constexpr int kLast = ST_K - 1;
+        const int k0 = 2 * s, k1 = 2 * s + 1 > kLast ? kLast : 2 * s + 1;
+        const int off = half ? stem_koff(k1) : stem_koff(k0);
+        const float a0 = pa0[off], a1 = pa1[off];
+        const float b0 = pw[(2 * s) * 64], b1 = pw[(2 * s) * 64 + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
     }
 
-    const int oy = oy0 + py, ox = ox0 + px;
-    if (oy < OH && ox < OW) {
-        if constexpr (sizeof(OutT) == 4) {
-            float4* o = reinterpret_cast<float4*>(out + ((size_t)oy * OW + ox) * 64);
+    // C/D layout: col = lane & 31 (pixel), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (channel of the N block)
+    const int ox = ox0 + px;
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                float4 v;
-                v.x = fmaxf(acc[4 * c + 0] + bias[4 * c + 0], 0.f);
-                v.y = fmaxf(acc[4 * c + 1] + bias[4 * c + 1], 0.f);
-                v.z = fmaxf(acc[4 * c + 2] + bias[4 * c + 2], 0.f);
-                v.w = fmaxf(acc[4 * c + 3] + bias[4 * c + 3], 0.f);
-                o[c] = v;
+    for (int i = 0; i < 2; i++) {
+        const int oy = oy0 + 2 * wave + i;
+        if (oy >= OH || ox >= OW) continue;
+        OutT* o = out + ((size_t)oy * OW + ox) * 64;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = j * 32 + 8 * g + 4 * half;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+                const float v0 = fmaxf(acc[i][j][4 * g + 0] + b4.x, 0.f), v1 = fmaxf(acc[i][j][4 * g + 1] + b4.y, 0.f);
+                const float v2 = fmaxf(acc[i][j][4 * g + 2] + b4.z, 0.f), v3 = fmaxf(acc[i][j][4 * g + 3] + b4.w, 0.f);
+                if constexpr (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float4*>(o + n) = make_float4(v0, v1, v2, v3);
+                } else {
+                    f16x4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                    *reinterpret_cast<f16x4*>(o + n) = hv;
+                }
             }
-        } else {
-            f16x8* o = reinterpret_cast<f16x8*>(out + ((size_t)oy * OW + ox) * 64);
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                f16x8 v;
-#pragma unroll
-                for (int t = 0; t < 8; t++) v[t] = (_Float16)fmaxf(acc[8 * c + t] + bias[8 * c + t], 0.f);
-                o[c] = v;
-            }
-        }
     }
 }
 
