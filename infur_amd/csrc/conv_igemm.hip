@@ -1,24 +1,28 @@
-// conv_igemm.hip -- convolution as an im2col-free implicit GEMM on the gfx950 matrix cores:
-// f32 operands on v_mfma_f32_32x32x2_f32 (exact f32, bitwise an fmaf chain) or f16 operands
-// on v_mfma_f32_32x32x16_f16 (f32 accumulation).  One kernel source: both instructions take a
-// lane's k-slice as one 16-byte register group (4 f32 / 8 f16), so tiles, staging and LDS
-// image are described in BYTES of k.
+// conv_igemm.hip -- convolution as an im2col-free implicit GEMM on the gfx950 matrix cores, three arithmetic modes
+// from one kernel source:
+//   f32   operands on v_mfma_f32_32x32x2_f32 (exact f32, bitwise an fmaf chain)
+//   f16   operands on v_mfma_f32_32x32x16_f16, f32 accumulation
+//   split f32 tensors, each value as an f16 hi + lo pair, three f16 MFMAs per product, f32 accumulation (SPLIT below)
+// Both instructions take a lane's k-slice as one 16-byte register group (4 f32 / 8 f16), so tiles, staging and
+// the LDS image are described in BYTES of k.
 //
-// Replaces the Conv nodes ONNX Runtime executes inside `session.run`
-// (infur/src/predict_onnx.rs:138) for every 1x1 and 3x3 convolution of FCN-ResNet
-// (stride 1/2, dilation 1/2/4), with bias, residual add and ReLU fused into the epilogue.
+// Replaces the Conv nodes ONNX Runtime executes inside `session.run` (infur/src/predict_onnx.rs:138) for every
+// 1x1 and 3x3 convolution of FCN-ResNet (stride 1/2, dilation 1/2/4), with bias, residual add and ReLU fused
+// into the epilogue, and runs the batched Winograd-domain GEMMs of winograd.hip.
 //
 //   GEMM view:  M = OH*OW output pixels, N = Cout, K = KH*KW*Cin  (tap-major, Cin inner)
 //   A[m][k]  = in[(oy*s - p + ky*d), (ox*s - p + kx*d), c]   NHWC, gathered, zero padded
 //   B[n][k]  = wt[n][ky][kx][c]                               OHWI, k contiguous
 //
-// Tiling: BM x BN x 128 bytes of k per workgroup, one wave per SIMD, each wave TM x TN tiles of
-// 32x32.  Operands are staged global -> VGPR -> LDS (row stride 144 bytes: ds_write_b128 and
-// ds_read_b128 both conflict-free) with two LDS buffers and one barrier per K step; global
-// loads run two K steps ahead and LDS fragment reads one slice ahead of the MFMAs.
-// A lane reads 4 consecutive k of its row with one ds_read_b128 (lanes 0-31: k 0-3,
-// lanes 32-63: k 4-7 of an 8-wide slice) and feeds them to 4 MFMAs; A and B use the same
-// permutation of k, so the sum is complete.
+// Tiling: BM x BN x 128 bytes of k per workgroup, 4 or 8 waves, each wave TM x TN tiles of 32x32.  Operands are
+// staged global -> VGPR -> LDS (row stride 144 bytes: ds_write_b128 and ds_read_b128 both conflict-free); three
+// loop forms (NBUF): two LDS images + fragment prefetch + one mid-step barrier; one LDS image, two barriers (half
+// the LDS, more workgroups per CU); two images with one fragment set (big tiles).  A lane reads 4 consecutive k
+// of its row with one ds_read_b128 (lanes 0-31: k 0-3, lanes 32-63: k 4-7 of an 8-wide slice) and feeds them to
+// 4 MFMAs; A and B use the same permutation of k, so the sum is complete.  Template flags select the addressing
+// form (G1: 1x1 GEMM), the residual prefetch (RESPF) and the two-source form (DUAL: conv3 + downsample branch).
+// Every tile configuration accumulates k in the same order: they are bit-identical, the choice is a speed knob
+// (pick_cfg in infur_capi.cpp measures it per layer shape).
 #include <cstdlib>
 #include <type_traits>
 
