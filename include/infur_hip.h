@@ -237,6 +237,14 @@ int32_t infur_batch_advance(infur_ctx* ctx, const uint8_t* const* frames, const 
                             const uint32_t* hs, uint32_t n, float factor, uint32_t scale_mode,
                             uint8_t* const* rgba, const size_t* caps, uint32_t* ows, uint32_t* ohs);
 
+/* ---- INFUR_DTYPE_F32_SPLIT range monitor ----
+ * The split mode carries every GEMM operand as an f16 pair of x * 2^k with static k: exact to
+ * 22 bits while |x * 2^k| <= 65504, saturating beyond.  Every forward records the largest |activation| fed to a
+ * GEMM and the largest |Winograd-domain input|; this call returns them for the last forward and whether either
+ * left the exact range (the logits of that frame are then not f32-grade: re-run it on an INFUR_DTYPE_F32 context).
+ * Synchronises the stream.  INFUR_E_INVALID_ARG in the other modes. */
+int32_t infur_split_range(infur_ctx* ctx, float* act_amax, float* wino_amax, uint32_t* saturated);
+
 /* ---- tuning database (tile configuration per conv shape, see options.no_autotune) ----
  * Text form: one line per shape, 13 shape integers + the configuration index.  Importing a
  * database makes the kernel mix reproducible from run to run and skips the trial launches of

@@ -120,6 +120,7 @@ SIGNATURES = {
     "infur_stream_collect": (C.c_int32, [_vp, _vp, _sz, _vp, C.POINTER(C.c_uint64), _u32p, _u32p]),
     "infur_batch_advance": (C.c_int32, [_vp, C.POINTER(_vp), _u32p, _u32p, _u32, _f, _u32, C.POINTER(_vp),
                                         C.POINTER(_sz), _u32p, _u32p]),
+    "infur_split_range": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _u32p]),
     "infur_tune_export": (C.c_int32, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "infur_tune_import": (C.c_int32, [_vp, C.c_char_p, _sz]),
     "infur_profile_enable": (C.c_int32, [_vp, _u32]),

@@ -507,6 +507,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         const bool n_ok = n < a.Cout;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_bias && n_ok) bv = *reinterpret_cast<const float4*>(a.bias + n);
+        float vmax = 0.f;  // SPLIT: largest |output| of this lane (range monitor)
 #pragma unroll
         for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -546,6 +547,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                     if (a.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
+                    if constexpr (SPLIT) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                     if constexpr (std::is_same<OutT, float>::value) {
                         *reinterpret_cast<float4*>(out + o) = v;
                     } else {
@@ -556,6 +558,13 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (SPLIT) {
+            if (a.amax) {  // one atomic per wave; non-negative floats order like their bit patterns
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+                if (lane == 0) atomicMax(a.amax, __float_as_uint(vmax));
+            }
         }
         return;
     }

@@ -108,6 +108,10 @@ struct infur_ctx {
     // measured tile configuration per conv shape (see pick_cfg)
     std::map<std::array<int, 13>, int> tuned;
     bool tune_warm = false;
+
+    // INFUR_DTYPE_F32_SPLIT range monitor: [0] max |activation| fed to a GEMM, [1] max |Winograd-domain input|
+    // of the last forward (bit patterns of non-negative floats, atomicMax targets); infur_split_range
+    unsigned* d_range = nullptr;
 };
 
 namespace {
@@ -611,7 +615,7 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         const double direct = 2.0 * oh * ow * (double)L.cout * L.cin * 9.0;
         {
             ProfScope ps(c, L.name + "/in", "wino_input", 0, (double)in.bytes() + (double)V.bytes(), 0.0);
-            HIPCHK(c, launch_wino_input((const float*)in.p, in.h, in.w, in.c, L.dil, mt, (float*)V.p, c->stream));
+            HIPCHK(c, launch_wino_input((const float*)in.p, in.h, in.w, in.c, L.dil, mt, (float*)V.p, c->d_range ? c->d_range + 1 : nullptr, c->stream));
         }
         ConvArgs g;
         g.in = V.p; g.wt = L.d_u; g.bias = nullptr; g.res = nullptr; g.out = M.p;
@@ -633,7 +637,8 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         pool_release(c, V);
         {
             ProfScope ps(c, L.name + "/out", "wino_output", 0, (double)M.bytes() + (double)out->bytes(), 0.0);
-            HIPCHK(c, launch_wino_output((const float*)M.p, oh, ow, L.cout, L.dil, mt, L.d_b, L.relu ? 1 : 0, (float*)out->p, c->stream));
+            HIPCHK(c, launch_wino_output((const float*)M.p, oh, ow, L.cout, L.dil, mt, L.d_b, L.relu ? 1 : 0, (float*)out->p,
+                                         L.role == 'c' ? nullptr : c->d_range, c->stream));
         }
         pool_release(c, M);
         if (c->opt.keep_activations) c->kept.push_back(*out);
@@ -649,6 +654,7 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
     if (mode == INFUR_DTYPE_F32_SPLIT) {
         a.a_scale = kSplitActScale;
         a.acc_scale = 1.0f / (a.a_scale * L.w_scale);
+        a.amax = L.role == 'c' ? nullptr : c->d_range;  // the logits feed no GEMM
     }
     int cfg = -1;
     RETIF(pick_cfg(c, a, mode, out_f32, &cfg));
@@ -677,6 +683,7 @@ int32_t run_conv_dual(infur_ctx* c, const ConvLayer& L3, const ConvLayer& D, con
     if (mode == INFUR_DTYPE_F32_SPLIT) {
         a.a_scale = kSplitActScale;
         a.acc_scale = 1.0f / (a.a_scale * L3.wcat_scale);
+        a.amax = c->d_range;
     }
     const double flops = 2.0 * oh * ow * (double)L3.cout * (L3.cin + D.cin);
     const double bytes = (double)t2.bytes() + (double)oh * ow * x.c * x.es + (double)out->bytes() + (double)L3.cout * (L3.cin + D.cin) * t2.es;
@@ -695,6 +702,7 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     if (w <= 0 || h <= 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %dx%d", w, h);
     pool_release_all(c);
     prof_reset(c);
+    if (c->d_range) HIPCHK(c, hipMemsetAsync(c->d_range, 0, 2 * sizeof(unsigned), c->stream));
     size_t ci = 0;
     const ConvLayer& stem = c->convs[ci++];
     Tensor s, x;
@@ -709,7 +717,7 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
         const int oh = conv_out(s.h, 3, 2, 1, 1), ow = conv_out(s.w, 3, 2, 1, 1);
         RETIF(talloc(c, oh, ow, 64, act_es(c), &x));
         ProfScope ps(c, "backbone.maxpool", "maxpool3x3s2", 0, (double)s.bytes() + (double)x.bytes());
-        HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, x.p, ctx_f16(c) ? 1 : 0, oh, ow, c->stream));
+        HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, x.p, ctx_f16(c) ? 1 : 0, oh, ow, c->d_range, c->stream));
     }
     pool_release(c, s);
 
@@ -839,7 +847,9 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
     bool ok = hipMalloc((void**)&c->d_pre_lut, pre.size() * 4) == hipSuccess &&
               hipMalloc((void**)&c->d_color_lut, col.size() * 4) == hipSuccess &&
               hipMemcpy(c->d_pre_lut, pre.data(), pre.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(c->d_color_lut, col.data(), col.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpy(c->d_color_lut, col.data(), col.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              (o.compute_dtype != INFUR_DTYPE_F32_SPLIT ||
+               (hipMalloc((void**)&c->d_range, 2 * sizeof(unsigned)) == hipSuccess && hipMemset(c->d_range, 0, 2 * sizeof(unsigned)) == hipSuccess));
     if (!ok) {
         infur_ctx_destroy(c);
         return INFUR_E_HIP;
@@ -860,6 +870,7 @@ void infur_ctx_destroy(infur_ctx* c) {
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     if (c->d_pre_lut) (void)hipFree(c->d_pre_lut);
     if (c->d_color_lut) (void)hipFree(c->d_color_lut);
+    if (c->d_range) (void)hipFree(c->d_range);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1429,6 +1440,21 @@ int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const ui
     infur_stream_destroy(st);
     c->err = keep;
     return rc;
+}
+
+// ---- range monitor of the split mode ----
+int32_t infur_split_range(infur_ctx* c, float* act_amax, float* wino_amax, uint32_t* saturated) {
+    if (!c) return INFUR_E_INVALID_ARG;
+    if (!c->d_range) return fail(c, INFUR_E_INVALID_ARG, "context is not in INFUR_DTYPE_F32_SPLIT mode");
+    float v[2] = {0.f, 0.f};
+    HIPCHK(c, hipMemcpyAsync(v, c->d_range, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (act_amax) *act_amax = v[0];
+    if (wino_amax) *wino_amax = v[1];
+    // beyond 65504 the hi half clamps (MODE.FP16_OVFL) and the pair stops being exact
+    const float ws = wino_mt(c) == 4 ? kSplitWinoScaleF4 : kSplitWinoScaleF2;
+    if (saturated) *saturated = (v[0] * kSplitActScale > 65504.0f || v[1] * ws > 65504.0f) ? 1u : 0u;
+    return INFUR_OK;
 }
 
 // ---- tuning database ----

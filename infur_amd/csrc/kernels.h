@@ -27,6 +27,9 @@ struct ConvArgs {
     // load time (launch_split_weights), and the accumulators are multiplied by acc_scale =
     // 1 / (a_scale * weight scale) before bias / residual / ReLU.  Powers of two: exact.
     float a_scale = 1.0f, acc_scale = 1.0f;
+    // mode 2, optional: atomicMax target (bit pattern of a non-negative float) for max |output| of this launch --
+    // the range monitor of the split mode (infur_split_range)
+    unsigned* amax = nullptr;
     // two-source 1x1 GEMM (a bottleneck's conv3 and its downsample branch as ONE launch, no residual tensor):
     // out = W[:, :Cin] * in  +  W[:, Cin:] * in2(stride2)  + bias.  in2 == nullptr: ordinary convolution.
     // Requires KH = KW = 1, pad = 0, stride = 1; wt rows are Cin + Cin2 long; OH x OW = ceil(H2/stride2) x ...
@@ -49,9 +52,10 @@ const char* conv_igemm_config_name(int cfg, int mode);
 // Winograd F(mt x mt, 3x3), mt = 2 or 4, for stride-1 3x3 convs (f32, any dilation d with pad = d);
 // (mt+2)^2 transform planes; see winograd.hip
 int wino_num_tiles(int H, int W, int d, int mt);
-hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, hipStream_t s);
+// amax (optional): atomicMax target for max |V| / max |out| (range monitor of the split mode)
+hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, unsigned* amax, hipStream_t s);
 hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int mt, const float* bias, int relu,
-                              float* out, hipStream_t s);
+                              float* out, unsigned* amax, hipStream_t s);
 hipError_t launch_wino_weights(const float* w_oihw, int O, int I, int mt, float* U, hipStream_t s);
 
 // stem: packed BGR u8 -> (LUT normalise, BGR->RGB) -> conv 7x7/2 pad 3 (3->64) + bias + ReLU,
@@ -63,7 +67,7 @@ hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt
 
 // maxpool 3x3 stride 2 pad 1, NHWC f32 / f16 (C % 4 == 0)
 hipError_t launch_maxpool3x3s2(const void* in, int H, int W, int C, void* out, int f16, int OH, int OW,
-                               hipStream_t s);
+                               unsigned* amax, hipStream_t s);
 
 // OIHW f32 -> OHWI f32 / f16 weight repack (one-off at model load)
 hipError_t launch_repack_oihw_to_ohwi(const float* src, void* dst, int f16, int O, int I, int KH, int KW,

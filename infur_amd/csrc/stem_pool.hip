@@ -140,7 +140,8 @@ hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt
 // ---------------------------------------------------------------------------------------
 template <typename T, typename V4>
 __global__ void __launch_bounds__(256)
-    maxpool3x3s2_kernel(const T* __restrict__ in, int H, int W, int C, T* __restrict__ out, int OH, int OW) {
+    maxpool3x3s2_kernel(const T* __restrict__ in, int H, int W, int C, T* __restrict__ out, int OH, int OW, unsigned* __restrict__ amax) {
+    float vmax = 0.f;  // the stem's outputs are >= 0 (ReLU): max of the pooled values = max |activation|
     const int c4n = C >> 2;
     const size_t total = (size_t)OH * OW * c4n;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -165,22 +166,28 @@ __global__ void __launch_bounds__(256)
         }
         V4 r = {(T)m0, (T)m1, (T)m2, (T)m3};
         *reinterpret_cast<V4*>(out + p * C + c4 * 4) = r;
+        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(m0), fabsf(m1)), fmaxf(fabsf(m2), fabsf(m3))));
+    }
+    if (amax) {  // range monitor of the split mode
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(vmax));
     }
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 hipError_t launch_maxpool3x3s2(const void* in, int H, int W, int C, void* out, int f16, int OH, int OW,
-                               hipStream_t s) {
+                               unsigned* amax, hipStream_t s) {
     const size_t total = (size_t)OH * OW * (C / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (f16)
         hipLaunchKernelGGL((maxpool3x3s2_kernel<_Float16, f16x4>), dim3(blocks), dim3(256), 0, s, (const _Float16*)in, H, W, C,
-                           (_Float16*)out, OH, OW);
+                           (_Float16*)out, OH, OW, amax);
     else
         hipLaunchKernelGGL((maxpool3x3s2_kernel<float, f32x4v>), dim3(blocks), dim3(256), 0, s, (const float*)in, H, W, C,
-                           (float*)out, OH, OW);
+                           (float*)out, OH, OW, amax);
     return hipGetLastError();
 }
 

@@ -90,7 +90,8 @@ __device__ __forceinline__ void g_1d(float g0, float g1, float g2, float* u) {  
 // ---- input transform: one thread = one tile x 2 channels ----
 template <int MT>
 __global__ void __launch_bounds__(256)
-    wino_input_kernel(const float* __restrict__ in, WinoGeom g, int C, int T, float* __restrict__ V) {
+    wino_input_kernel(const float* __restrict__ in, WinoGeom g, int C, int T, float* __restrict__ V, unsigned* __restrict__ amax) {
+    float vmax = 0.f;
     constexpr int AL = MT + 2;
     const int cvn = C >> 1;
     const size_t total = (size_t)T * cvn;
@@ -119,7 +120,15 @@ __global__ void __launch_bounds__(256)
         for (int a = 0; a < AL; a++) bt_1d<MT, 1>(r + a * AL, d + a * AL);  // rows: (.) B
         float* o = V + (size_t)t * C + cv * 2;
 #pragma unroll
-        for (int xi = 0; xi < AL * AL; xi++) *reinterpret_cast<f32x2*>(o + (size_t)xi * plane) = d[xi];
+        for (int xi = 0; xi < AL * AL; xi++) {
+            *reinterpret_cast<f32x2*>(o + (size_t)xi * plane) = d[xi];
+            vmax = fmaxf(vmax, fmaxf(fabsf(d[xi].x), fabsf(d[xi].y)));
+        }
+    }
+    if (amax) {  // range monitor of the split mode: max |V|, one atomic per wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(vmax));
     }
 }
 
@@ -127,7 +136,8 @@ __global__ void __launch_bounds__(256)
 template <int MT>
 __global__ void __launch_bounds__(256)
     wino_output_kernel(const float* __restrict__ M, WinoGeom g, int Cout, int T, const float* __restrict__ bias,
-                       int relu, float* __restrict__ out) {
+                       int relu, float* __restrict__ out, unsigned* __restrict__ amax) {
+    float vmax = 0.f;
     constexpr int AL = MT + 2;
     const int nvn = Cout >> 1;
     const size_t total = (size_t)T * nvn;
@@ -160,8 +170,14 @@ __global__ void __launch_bounds__(256)
                     v.y = fmaxf(v.y, 0.f);
                 }
                 *reinterpret_cast<f32x2*>(out + ((size_t)y * g.W + x) * Cout + nv * 2) = v;
+                vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
             }
         }
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(vmax));
     }
 }
 
@@ -209,26 +225,26 @@ static unsigned grid_for(size_t work) {
     return (unsigned)blocks;
 }
 
-hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, hipStream_t s) {
+hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, unsigned* amax, hipStream_t s) {
     const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
     const unsigned blocks = grid_for((size_t)T * (C / 2));
     if (mt == 2)
-        hipLaunchKernelGGL(wino_input_kernel<2>, dim3(blocks), dim3(256), 0, s, in, g, C, T, V);
+        hipLaunchKernelGGL(wino_input_kernel<2>, dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
     else
-        hipLaunchKernelGGL(wino_input_kernel<4>, dim3(blocks), dim3(256), 0, s, in, g, C, T, V);
+        hipLaunchKernelGGL(wino_input_kernel<4>, dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
     return hipGetLastError();
 }
 
 hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int mt, const float* bias, int relu,
-                              float* out, hipStream_t s) {
+                              float* out, unsigned* amax, hipStream_t s) {
     const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
     const unsigned blocks = grid_for((size_t)T * (Cout / 2));
     if (mt == 2)
-        hipLaunchKernelGGL(wino_output_kernel<2>, dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out);
+        hipLaunchKernelGGL(wino_output_kernel<2>, dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
     else
-        hipLaunchKernelGGL(wino_output_kernel<4>, dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out);
+        hipLaunchKernelGGL(wino_output_kernel<4>, dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
     return hipGetLastError();
 }
 

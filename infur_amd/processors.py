@@ -132,6 +132,12 @@ class Context:
         txt = open(path, "rb").read()
         self.check(self.L.infur_tune_import(self.h, txt, len(txt)))
 
+    def split_range(self):
+        """dtype "f32s" only: (max |activation| fed to a GEMM, max |Winograd-domain input|, saturated) of the last frame."""
+        a, w, sat = C.c_float(0), C.c_float(0), C.c_uint32(0)
+        self.check(self.L.infur_split_range(self.h, C.byref(a), C.byref(w), C.byref(sat)))
+        return a.value, w.value, bool(sat.value)
+
     def tuning_text(self) -> str:
         n = C.c_size_t(0)
         self.check(self.L.infur_tune_export(self.h, None, 0, C.byref(n)))

@@ -90,4 +90,7 @@ extern "C" {
     pub fn infur_stream_next_dims(s: *const infur_stream, frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
     pub fn infur_stream_collect(s: *mut infur_stream, rgba: *mut u8, cap: usize, scaled_bgr: *mut u8,
                                 frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
+    /// INFUR_DTYPE_F32_SPLIT: largest |activation| fed to a GEMM and largest |Winograd-domain input| of the last
+    /// forward, and whether either left the exact range of the f16 pairs
+    pub fn infur_split_range(c: *mut infur_ctx, act_amax: *mut f32, wino_amax: *mut f32, saturated: *mut u32) -> i32;
 }

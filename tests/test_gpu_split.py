@@ -149,6 +149,9 @@ def test_split_activation_range(oracle):
         FramePath(c).advance(fr, 1.0)
         lo, _ = m.lowres()
         assert np.isfinite(lo).all()
+        act, wino, saturated = c.split_range()  # the range monitor sees it
+        print(f"activations x{gain:g}: max |activation| {act:.3g}, max |Winograd input| {wino:.3g}, saturated {saturated}")
+        assert saturated == (not accurate) and act > 0 and wino > 0
         if accurate:
             tl, _ = TorchModel(blob).forward_lowres(oracle.pack_normalize(fr))
             e = rel_err(lo, tl.numpy())
