@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256)
     if (amax) {  // range monitor of the split mode: max |V|, one atomic per wave
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(vmax));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(vmax));
     }
 }
 
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256)
     if (amax) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(vmax));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(vmax));
     }
 }
 
