@@ -603,12 +603,16 @@ static hipError_t launch_cfg_g(const ConvArgs& a, hipStream_t s) {
     const int ntiles = (a.Cout + BN - 1) / BN;
     const size_t lds = (size_t)lds_bytes(BM, BN, WM, WN, NBUF);
     auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT, G1, RESPF, DUAL>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    // > 64 KB of dynamic LDS needs the attribute once per kernel AND per device (a process may hold contexts on
+    // several GPUs); a context is driven from one thread, two contexts racing here only repeat the call
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63, attr_done[63] = false;
+    if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL(k, dim3(mtiles * ntiles * (a.batch > 1 ? a.batch : 1)), dim3(WM * WN * 64), lds, s, a, mtiles, ntiles);
     return hipGetLastError();

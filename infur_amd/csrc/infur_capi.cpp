@@ -779,6 +779,13 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
 // =====================================================================================
 // C ABI
 // =====================================================================================
+// Every entry point runs on its context's device: a process may hold contexts on several GPUs, and
+// hipMalloc / kernel launches follow the calling thread's current device, not the stream's.
+static inline void enter(const infur_ctx* c) {
+    int cur = -1;
+    if (c && (hipGetDevice(&cur) != hipSuccess || cur != c->device)) (void)hipSetDevice(c->device);
+}
+
 extern "C" {
 
 uint32_t infur_abi_version(void) { return INFUR_ABI_VERSION; }
@@ -878,6 +885,7 @@ void infur_ctx_destroy(infur_ctx* c) {
 const char* infur_last_error(const infur_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int32_t infur_ctx_synchronize(infur_ctx* c) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return INFUR_OK;
@@ -908,6 +916,7 @@ int32_t infur_scale_out_dims(uint32_t w, uint32_t h, float factor, uint32_t* ow,
 
 int32_t infur_scale_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                         void* d_out, size_t cap, uint32_t* ow, uint32_t* oh) {
+    enter(c);
     if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
     if (mode > INFUR_SCALE_BILINEAR) return fail(c, INFUR_E_INVALID_ARG, "unknown scale mode %u", mode);
     int32_t rc = infur_scale_validate(factor);
@@ -929,6 +938,7 @@ int32_t infur_scale_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h,
 
 int32_t infur_scale(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                     uint8_t* out, size_t cap, uint32_t* ow, uint32_t* oh) {
+    enter(c);
     if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
     int32_t rc = infur_scale_validate(factor);
     if (rc) return fail(c, rc, "%s", infur_status_string(rc));
@@ -949,6 +959,7 @@ int32_t infur_scale(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, fl
 
 // ---- Model ----
 int32_t infur_model_unload(infur_ctx* c) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     model_free(c);
@@ -956,11 +967,13 @@ int32_t infur_model_unload(infur_ctx* c) {
 }
 
 int32_t infur_model_load_blob_dev(infur_ctx* c, const void* d_blob, size_t len) {
+    enter(c);
     if (!c || !d_blob) return INFUR_E_INVALID_ARG;
     return model_load_dev(c, d_blob, len);
 }
 
 int32_t infur_model_load_blob(infur_ctx* c, const void* blob, size_t len) {
+    enter(c);
     if (!c || !blob) return INFUR_E_INVALID_ARG;
     if (len < kBlobHdr || memcmp(blob, "INFURW01", 8) != 0)
         return fail(c, INFUR_E_MODEL_FORMAT, "bad magic: not an INFURW01 weight blob");
@@ -974,6 +987,7 @@ int32_t infur_model_load_blob(infur_ctx* c, const void* blob, size_t len) {
 }
 
 int32_t infur_model_load(infur_ctx* c, const char* path) {
+    enter(c);
     if (!c || !path) return INFUR_E_INVALID_ARG;
     if (path[0] == 0) return infur_model_unload(c);  // ModelCmd::Load("") unloads, predict_onnx.rs:310-312
     FILE* f = fopen(path, "rb");
@@ -1026,6 +1040,7 @@ int32_t infur_onnx_to_blob(const void* onnx, size_t len, void** blob, size_t* bl
 void infur_buffer_free(void* p) { free(p); }
 
 int32_t infur_model_info_get(const infur_ctx* c, infur_model_info* info) {
+    enter(c);
     if (!c || !info) return INFUR_E_INVALID_ARG;
     if (!c->loaded) return INFUR_E_MODEL_NOT_LOADED;
     *info = c->info;
@@ -1045,6 +1060,7 @@ int32_t infur_model_lowres_dims(uint32_t h, uint32_t w, uint32_t* lh, uint32_t* 
 
 int32_t infur_model_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, void* d_out, void* d_aux,
                                 uint32_t* n_outputs) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     if (n_outputs) *n_outputs = 0;
     if (!c->loaded) return INFUR_OK;  // no session: out untouched, Ok(()) (predict_onnx.rs:318,333)
@@ -1068,6 +1084,7 @@ int32_t infur_model_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uin
 
 int32_t infur_model_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float* out, float* aux,
                             uint32_t* n_outputs) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     if (n_outputs) *n_outputs = 0;
     if (!c->loaded) return INFUR_OK;
@@ -1086,6 +1103,7 @@ int32_t infur_model_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32
 }
 
 int32_t infur_model_read_lowres(infur_ctx* c, float* out_low, float* aux_low, uint32_t* lh, uint32_t* lw) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     if (!c->loaded || !c->out_low.p) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no forward pass has run");
     const Tensor& t = c->out_low;
@@ -1107,6 +1125,7 @@ int32_t infur_model_read_lowres(infur_ctx* c, float* out_low, float* aux_low, ui
 
 int32_t infur_debug_read_activation(infur_ctx* c, uint32_t index, float* host, size_t cap, uint32_t* ch, uint32_t* h,
                                     uint32_t* w) {
+    enter(c);
     if (!c || !host) return INFUR_E_INVALID_ARG;
     if (!c->opt.keep_activations) return fail(c, INFUR_E_INVALID_ARG, "context was created without keep_activations");
     if (index >= c->kept.size()) return fail(c, INFUR_E_INVALID_ARG, "activation %u of %zu", index, c->kept.size());
@@ -1124,6 +1143,7 @@ int32_t infur_debug_read_activation(infur_ctx* c, uint32_t index, float* host, s
 
 // ---- pre-proc alone ----
 int32_t infur_pack_normalize_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, void* d_chw) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     if ((size_t)w * h == 0) return INFUR_OK;
     if (!d_bgr || !d_chw) return INFUR_E_INVALID_ARG;
@@ -1133,6 +1153,7 @@ int32_t infur_pack_normalize_dev(infur_ctx* c, const void* d_bgr, uint32_t w, ui
 }
 
 int32_t infur_pack_normalize(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float* chw) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     const size_t npix = (size_t)w * h;
     if (npix == 0) return INFUR_OK;
@@ -1148,6 +1169,7 @@ int32_t infur_pack_normalize(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint3
 
 // ---- ColorCode ----
 int32_t infur_colorcode_dev(infur_ctx* c, const void* d_khw, uint32_t k, uint32_t h, uint32_t w, void* d_rgba) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     if ((size_t)h * w == 0) return INFUR_OK;  // empty image: nothing to write (decode_predict.rs:68 zips 0 pixels)
     if (!d_rgba || (k > 0 && !d_khw)) return INFUR_E_INVALID_ARG;
@@ -1157,6 +1179,7 @@ int32_t infur_colorcode_dev(infur_ctx* c, const void* d_khw, uint32_t k, uint32_
 }
 
 int32_t infur_colorcode(infur_ctx* c, const float* khw, uint32_t k, uint32_t h, uint32_t w, uint8_t* rgba) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     const size_t hw = (size_t)h * w;
     if (hw == 0) return INFUR_OK;
@@ -1172,6 +1195,7 @@ int32_t infur_colorcode(infur_ctx* c, const float* khw, uint32_t k, uint32_t h, 
 
 // ---- display conversion ----
 int32_t infur_bgr_to_rgba_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, void* d_rgba) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     if ((size_t)w * h == 0) return INFUR_OK;
     if (!d_bgr || !d_rgba) return INFUR_E_INVALID_ARG;
@@ -1181,6 +1205,7 @@ int32_t infur_bgr_to_rgba_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint3
 }
 
 int32_t infur_bgr_to_rgba(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* rgba) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     const size_t npix = (size_t)w * h;
     if (npix == 0) return INFUR_OK;
@@ -1197,6 +1222,7 @@ int32_t infur_bgr_to_rgba(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t
 // ---- fused frame path ----
 int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                                 void* d_rgba, size_t cap, void* d_scaled, uint32_t* ow, uint32_t* oh) {
+    enter(c);
     if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
     if (mode > INFUR_SCALE_BILINEAR) return fail(c, INFUR_E_INVALID_ARG, "unknown scale mode %u", mode);
     int32_t rc = infur_scale_validate(factor);
@@ -1235,6 +1261,7 @@ int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uin
 
 int32_t infur_frame_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                             uint8_t* rgba, size_t cap, uint8_t* scaled, uint32_t* ow, uint32_t* oh) {
+    enter(c);
     if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
     int32_t rc = infur_scale_validate(factor);
     if (rc) return fail(c, rc, "%s", infur_status_string(rc));
@@ -1303,6 +1330,7 @@ int32_t slot_reserve(infur_ctx* c, infur_stream::Slot& sl, size_t in_bytes, size
 extern "C" {
 
 int32_t infur_stream_create(infur_ctx* c, uint32_t depth, infur_stream** out) {
+    enter(c);
     if (!c || !out || depth == 0 || depth > 64) return INFUR_E_INVALID_ARG;
     *out = nullptr;
     infur_stream* st = new infur_stream();
@@ -1323,6 +1351,7 @@ int32_t infur_stream_create(infur_ctx* c, uint32_t depth, infur_stream** out) {
 }
 
 void infur_stream_destroy(infur_stream* st) {
+    if (st) enter(st->ctx);
     if (!st) return;
     if (st->ctx && st->ctx->stream) (void)hipStreamSynchronize(st->ctx->stream);
     if (st->s_h2d) (void)hipStreamSynchronize(st->s_h2d);
@@ -1344,6 +1373,7 @@ uint32_t infur_stream_pending(const infur_stream* st) { return st ? (uint32_t)(s
 
 int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                             uint64_t frame_id) {
+    if (st) enter(st->ctx);
     if (!st || !bgr) return INFUR_E_INVALID_ARG;
     infur_ctx* c = st->ctx;
     int32_t rc = infur_scale_validate(factor);
@@ -1381,6 +1411,7 @@ int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, ui
 }
 
 int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint32_t* ow, uint32_t* oh) {
+    if (st) enter(st->ctx);
     if (!st || st->head == st->tail) return INFUR_E_INVALID_ARG;
     const infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
     if (frame_id) *frame_id = sl.id;
@@ -1391,6 +1422,7 @@ int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint3
 
 int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t cap, uint8_t* scaled, uint64_t* frame_id,
                              uint32_t* ow, uint32_t* oh) {
+    if (st) enter(st->ctx);
     if (!st) return INFUR_E_INVALID_ARG;
     infur_ctx* c = st->ctx;
     if (st->head == st->tail) return fail(c, INFUR_E_INVALID_ARG, "no frame is pending");
@@ -1412,6 +1444,7 @@ int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t cap, uint8_
 int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const uint32_t* ws, const uint32_t* hs, uint32_t n,
                             float factor, uint32_t mode, uint8_t* const* rgba, const size_t* caps, uint32_t* ows,
                             uint32_t* ohs) {
+    enter(c);
     if (!c || (n && (!frames || !ws || !hs || !rgba || !caps))) return INFUR_E_INVALID_ARG;
     if (n == 0) return INFUR_OK;
     infur_stream* st = nullptr;
@@ -1444,6 +1477,7 @@ int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const ui
 
 // ---- range monitor of the split mode ----
 int32_t infur_split_range(infur_ctx* c, float* act_amax, float* wino_amax, uint32_t* saturated) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     if (!c->d_range) return fail(c, INFUR_E_INVALID_ARG, "context is not in INFUR_DTYPE_F32_SPLIT mode");
     float v[2] = {0.f, 0.f};
@@ -1459,6 +1493,7 @@ int32_t infur_split_range(infur_ctx* c, float* act_amax, float* wino_amax, uint3
 
 // ---- tuning database ----
 int32_t infur_tune_export(infur_ctx* c, char* buf, size_t cap, size_t* len) {
+    enter(c);
     if (!c || !len) return INFUR_E_INVALID_ARG;
     std::string out;
     char line[256];
@@ -1476,6 +1511,7 @@ int32_t infur_tune_export(infur_ctx* c, char* buf, size_t cap, size_t* len) {
 }
 
 int32_t infur_tune_import(infur_ctx* c, const char* text, size_t len) {
+    enter(c);
     if (!c || (!text && len)) return INFUR_E_INVALID_ARG;
     std::string t(text ? text : "", len);
     size_t pos = 0;
@@ -1501,12 +1537,14 @@ int32_t infur_tune_import(infur_ctx* c, const char* text, size_t len) {
 
 // ---- profiling ----
 int32_t infur_profile_enable(infur_ctx* c, uint32_t on) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     c->opt.profile = on ? 1 : 0;
     return INFUR_OK;
 }
 
 int32_t infur_profile_count(infur_ctx* c, uint32_t* n) {
+    enter(c);
     if (!c || !n) return INFUR_E_INVALID_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *n = (uint32_t)c->prof.size();
@@ -1514,6 +1552,7 @@ int32_t infur_profile_count(infur_ctx* c, uint32_t* n) {
 }
 
 int32_t infur_profile_get(infur_ctx* c, uint32_t i, infur_kernel_record* rec) {
+    enter(c);
     if (!c || !rec || i >= c->prof.size()) return INFUR_E_INVALID_ARG;
     const ProfRec& r = c->prof[i];
     memset(rec, 0, sizeof *rec);
@@ -1530,23 +1569,27 @@ int32_t infur_profile_get(infur_ctx* c, uint32_t i, infur_kernel_record* rec) {
 
 // ---- device memory helpers ----
 int32_t infur_dev_alloc(infur_ctx* c, size_t bytes, void** d) {
+    enter(c);
     if (!c || !d) return INFUR_E_INVALID_ARG;
     HIPCHK(c, hipMalloc(d, bytes ? bytes : 1));
     return INFUR_OK;
 }
 int32_t infur_dev_free(infur_ctx* c, void* d) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(d));
     return INFUR_OK;
 }
 int32_t infur_memcpy_h2d(infur_ctx* c, void* d, const void* s, size_t n) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return INFUR_OK;
 }
 int32_t infur_memcpy_d2h(infur_ctx* c, void* d, const void* s, size_t n) {
+    enter(c);
     if (!c) return INFUR_E_INVALID_ARG;
     HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
