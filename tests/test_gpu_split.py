@@ -204,3 +204,20 @@ def test_split_resnet101_and_stream(oracle):
         assert (rgba == got).all()  # the ring and the batch call run the same path
     sp.close()
     c.close()
+
+
+def test_split_range_only_in_split_mode(blob50):
+    from infur_amd.processors import InfurError
+
+    c = Context(device=0, dtype="f32")
+    Model(c).control(ModelCmd.LoadBlob(blob50))
+    FramePath(c).advance(W.synth_frame(48, 64), 1.0)
+    with pytest.raises(InfurError):
+        c.split_range()
+    c.close()
+    c = Context(device=0, dtype="f32s")
+    Model(c).control(ModelCmd.LoadBlob(blob50))
+    FramePath(c).advance(W.synth_frame(48, 64), 1.0)
+    act, wino, saturated = c.split_range()
+    assert 0 < act < 1e3 and 0 < wino < 1e5 and not saturated
+    c.close()
