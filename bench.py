@@ -6,9 +6,10 @@
 A "step" is one pass of the hot path (packed BGR frame -> [scale] -> fused pre-proc + stem ->
 FCN-ResNet50 incl. aux head -> bilinear up-sample + argmax + shade -> RGBA mask) over one batch
 of ``--frames-per-step`` distinct synthetic frames per GPU, inputs and outputs resident in HBM.
-N > 1 is launched by torch.distributed.run, one rank per GPU: the weight blob is broadcast
-once over RCCL (timed separately, outside the region), frames are sharded with no data-path
-collective ("weak" scaling: per-GPU work is fixed).  Rank 0 prints ONE JSON line.
+N > 1 runs one rank per GPU under torch.distributed.run -- started by the driver, or by this script
+itself when it finds no launcher around it (`python bench.py --gpus N`): the weight blob is
+broadcast once over RCCL (timed separately, outside the region), frames are sharded with no
+data-path collective ("weak" scaling: per-GPU work is fixed).  Rank 0 prints ONE JSON line.
 
 The CPU oracle (oracle/) is used here only for the ``cpu_baseline`` leg and a one-frame
 parity spot check; it is never part of the measured path.
@@ -41,9 +42,12 @@ def parse():
     ap.add_argument("--no-aux", action="store_true", help="skip the aux head (the ONNX graph always evaluates it)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU baseline budget")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="CPU baseline budget")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--no-split", action="store_true", help="skip the f32_split_mode side measurement")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side measurements of BASELINE configs[2] (1080p stream at scale 0.5, PCIe inclusive) and "
+                         "configs[4] (4K FCN-ResNet101 f16)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s"],
                     help="conv-stack arithmetic: f32 (BASELINE configs[1], the default and the parity mode) or f16 "
                          "operands with f32 accumulation (configs[4]'s mode)")
@@ -51,57 +55,196 @@ def parse():
                     help="f32 stride-1 3x3 convs with Cin >= this run as Winograd F(2x2,3x3); 0 = library default, -1 = never")
     ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4], help="Winograd output tile (0 = default)")
     ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="backbone: FCN-ResNet50 (default) / 101")
+    ap.add_argument("--cpu-probe", default=None, help=argparse.SUPPRESS)  # internal: child process of cpu_baseline
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise the "
                          "multi-process path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly as the
+    driver's own multi-GPU form does (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), and hand
+    its exit code back.  With fewer visible GPUs than ranks the ranks share devices and the collective runs over
+    gloo (RCCL cannot put two ranks on one device); the JSON line says so (`config.oversubscribed`)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    argv = list(sys.argv[1:])
+    if torch.cuda.device_count() < a.gpus and a.backend == "nccl":
+        sys.stderr.write(f"bench.py: {torch.cuda.device_count()} GPU(s) visible for {a.gpus} ranks: ranks share devices, "
+                         "collective over gloo\n")
+        argv += ["--backend", "gloo"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model_string():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(blob, frame, budget_s):
-    """The oracle's whole path on the host cores: pre-proc (C) + FCN-ResNet50 (torch-CPU /
-    oneDNN) + up-sample + ColorCode (C).  Bounded sample: one whole 1080p frame per thread
-    count.  oneDNN's best thread count on a many-core host is far below the core count (256
-    threads is ~100x slower than 16 on the GPU box), so a short sweep picks the fastest; the
-    reference's own setting (ONNX Runtime pinned to 3 intra-op threads, predict_onnx.rs:292)
-    is timed too and reported beside it."""
+    """The oracle's whole path on the host cores: pre-proc (C) + FCN-ResNet50 (torch-CPU / oneDNN) + up-sample +
+    ColorCode (C).  Bounded sample of the bench workload: per thread count one un-timed warm-up frame (oneDNN
+    creates its primitives on first use) and then two timed whole frames, at the reference's own setting (ONNX
+    Runtime pinned to 3 intra-op threads, predict_onnx.rs:292), at 16 and at 32 threads.  SURVEY 8d also asks for
+    ALL host cores: oneDNN collapses far above its best thread count, so that sample is bounded by first timing a
+    1/64-area probe frame and running the whole frame only if the scaled estimate fits the remaining budget;
+    otherwise the probe-scaled estimate is reported and labelled as such.  `value` is the best measured rate."""
+    import numpy as np
     import torch
 
     from oracle.infur_oracle import COracle, TorchModel
 
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     co = COracle(threads=min(cores, 16))
     tm = TorchModel(blob)
     h, w = frame.shape[:2]
 
-    def one_frame():
+    def one_frame(fr):
+        fh, fw = fr.shape[:2]
         t0 = time.perf_counter()
-        chw = co.pack_normalize(frame)
+        chw = co.pack_normalize(fr)
         lo, _ = tm.forward_lowres(chw)
-        full = co.upsample_bilinear(lo.numpy(), h, w)
+        full = co.upsample_bilinear(lo.numpy(), fh, fw)
         co.colorcode(full)
         return time.perf_counter() - t0
 
-    results, spent = {}, 0.0
-    for th in (16, 32, 3):
-        if th > cores or spent > budget_s:
+    t_start = time.perf_counter()
+    spent = lambda: time.perf_counter() - t_start  # noqa: E731
+    results, samples = {}, {}
+    for th in (16, 3, 32):
+        if th > cores or spent() > budget_s:
             continue
         torch.set_num_threads(th)
-        results[th] = one_frame()
-        spent += results[th]
+        one_frame(frame)  # warm-up, not timed
+        ts = [one_frame(frame)]
+        if spent() < budget_s:
+            ts.append(one_frame(frame))
+        results[th] = min(ts)
+        samples[th] = len(ts)
+    all_cores = None
+    if cores not in results:
+        # SURVEY 8d's all-cores sample, in a child process under a hard time limit: oneDNN at 256 threads on this
+        # class of host needs tens of seconds for a 240x135 frame, so the sample must not be able to stall the bench
+        import subprocess
+
+        ph, pw = max(h // 8, 32), max(w // 8, 32)
+        limit = 20.0
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", f"{cores},{pw},{ph}"],
+                               capture_output=True, text=True, timeout=limit)
+            tp = float(r.stdout.strip().splitlines()[-1])
+            est = tp * (h * w) / float(ph * pw)
+            all_cores = {"threads": cores, "frames_per_s": 1.0 / est,
+                         "kind": f"extrapolated by pixel count from one {pw}x{ph} probe frame ({tp * 1e3:.0f} ms at {cores} threads, "
+                                 "after one warm-up frame)"}
+        except subprocess.TimeoutExpired:
+            all_cores = {"threads": cores, "frames_per_s": None,
+                         "kind": f"a {pw}x{ph} probe frame (1/64 of the pixels) + its warm-up did not finish within {limit:.0f} s at "
+                                 f"{cores} threads: < {1.0 / (limit / 2 * 64):.5f} frames/s 1080p-equivalent; oneDNN collapses far "
+                                 "above its best thread count on this host"}
+        except (ValueError, IndexError, OSError):
+            all_cores = {"threads": cores, "frames_per_s": None, "kind": "probe failed"}
     best = min(results, key=results.get)
-    return {
+    out = {
         "value": 1.0 / results[best], "unit": "frames/s", "cores": best, "kind": "port",
-        "sample": f"one whole {w}x{h} frame through the oracle path (C pre-proc, torch-CPU oneDNN FCN-ResNet50 incl. aux "
-                  f"head, C up-sample + ColorCode) per thread count {sorted(results)}; {spent:.1f} s of CPU wall time; "
-                  f"host has {cores} logical cores",
+        "sample": f"whole {w}x{h} frames through the oracle path (C pre-proc, torch-CPU oneDNN FCN-ResNet50 incl. aux head, C "
+                  f"up-sample + ColorCode): per thread count 1 warm-up + best of {dict(sorted(samples.items()))} timed frames; "
+                  f"{spent():.1f} s of CPU wall time",
+        "host_cpu": cpu_model_string(), "host_logical_cores": cores, "os_cpu_count": os.cpu_count(),
         "frames_per_s_by_threads": {str(k): 1.0 / v for k, v in sorted(results.items())},
-        "reference_note": "the reference pins ONNX Runtime to 3 intra-op threads (predict_onnx.rs:292); the reference "
-                          "itself cannot run here (no cargo / onnxruntime / model file)",
+        "all_cores": all_cores,
+        "reference_note": "the reference pins ONNX Runtime to 3 intra-op threads (predict_onnx.rs:292); the reference itself "
+                          "cannot run here (no cargo; onnxruntime / the model file are picked up when present, see "
+                          "`reference_runtime`)",
     }
+    ort = ort_baseline(frame)
+    if ort is not None:
+        out["reference_runtime"] = ort
+        if "frames_per_s" in ort:
+            out.update(value=ort["frames_per_s"], cores=3, kind="reference-runtime")
+    return out
+
+
+def ort_baseline(frame):
+    """Opportunistic: when `onnxruntime` imports and INFUR_ONNX_MODEL names the zoo's
+    fcn-resnet50-12.onnx, time the reference's own runtime configured as the reference configures it
+    (predict_onnx.rs:289-293: 3 intra-op threads, extended graph optimisations) on the bench frame."""
+    path = os.environ.get("INFUR_ONNX_MODEL")
+    if not path:
+        return None
+    try:
+        import numpy as np
+        import onnxruntime as ort
+    except ImportError:
+        return {"skipped": "INFUR_ONNX_MODEL is set but onnxruntime does not import"}
+    if not os.path.exists(path):
+        return {"skipped": f"{path} does not exist"}
+    so = ort.SessionOptions()
+    so.intra_op_num_threads = 3
+    so.graph_optimization_level = ort.GraphOptimizationLevel.ORT_ENABLE_EXTENDED
+    sess = ort.InferenceSession(path, so, providers=["CPUExecutionProvider"])
+    mean = np.array([0.485, 0.456, 0.406], np.float32)[:, None, None]
+    std1 = (np.float32(1.0) / np.array([0.229, 0.224, 0.225], np.float32))[:, None, None]
+    x = (np.ascontiguousarray(frame[..., ::-1].transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0) - mean) * std1
+    name = sess.get_inputs()[0].name
+    sess.run(None, {name: x[None]})  # warm-up
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        sess.run(None, {name: x[None]})
+        ts.append(time.perf_counter() - t0)
+    return {"frames_per_s": 1.0 / min(ts), "threads": 3, "model": os.path.basename(path), "onnxruntime": ort.__version__,
+            "note": "session.run only (the reference's pre-proc and ColorCode run outside it)"}
+
+
+def cpu_probe(spec):
+    """Child of cpu_baseline: `threads,w,h` -> seconds for one probe frame through the torch-CPU network (after one
+    warm-up frame), printed on stdout."""
+    import torch
+
+    from infur_amd import weights as W
+    from oracle.infur_oracle import COracle, TorchModel
+
+    th, w, h = (int(x) for x in spec.split(","))
+    torch.set_num_threads(th)
+    co = COracle(threads=min(th, 16))
+    tm = TorchModel(W.synth_blob())
+    fr = W.synth_frame(h, w)
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        lo, _ = tm.forward_lowres(co.pack_normalize(fr))
+        co.colorcode(co.upsample_bilinear(lo.numpy(), h, w))
+        ts.append(time.perf_counter() - t0)
+    print(ts[-1], flush=True)
 
 
 def main():
     a = parse()
+    if a.cpu_probe:
+        return cpu_probe(a.cpu_probe)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
+    import hashlib
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -115,8 +258,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
     ndev = torch.cuda.device_count()
     dev = local_rank if a.backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev)
@@ -137,7 +278,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nbytes = idist.load_model_everywhere(ctx, blob, coll_device=coll_dev)
+    nbytes, bcast_ms = idist.load_model_everywhere(ctx, blob, coll_device=coll_dev)
     torch.cuda.synchronize()
     load_ms = (time.perf_counter() - t0) * 1e3
 
@@ -179,6 +320,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # every rank decodes the SAME frame once more (outside the timed region): replicas must agree bit for bit
+    agree = None
+    if world > 1:
+        f0 = torch.from_numpy(W.synth_frame(H, Wd, index=0)).cuda()
+        fp.advance_dev(f0.data_ptr(), Wd, H, a.scale, d_masks[0].data_ptr(), d_masks[0].numel())
+        ctx.synchronize()
+        sha = hashlib.sha256(d_masks[0].cpu().numpy().tobytes()).hexdigest()
+        shas = [None] * world
+        dist.all_gather_object(shas, sha)
+        agree = len(set(shas)) == 1
+
     frames_total = world * B * a.steps
     fps = frames_total / elapsed
     out = {
@@ -191,7 +343,11 @@ def main():
                         f"scale={a.scale}" + (" [BASELINE configs[1]]" if (Wd, H, a.scale, a.dtype, a.depth) == (1920, 1080, 1.0, "f32", 50) else ""),
             "frames_per_step_per_gpu": B, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if world > 1 else None,
             "weights": f"synthetic seed {W.DEFAULT_SEED:#x}, {nbytes / 1e6:.1f} MB blob",
-            "weights_load_ms": round(load_ms, 2), "ms_per_frame_per_gpu": elapsed / (a.steps * B) * 1e3,
+            "weights_load_ms": round(load_ms, 2), "weights_bcast_ms": round(bcast_ms, 3),
+            "weights_note": "weights_load_ms = broadcast + per-rank repack into kernel layouts; weights_bcast_ms = the "
+                            "collective alone (0 at N = 1); both outside the timed region",
+            "ranks_agree_on_frame0_mask": agree, "oversubscribed": world > max(ndev, 1),
+            "ms_per_frame_per_gpu": elapsed / (a.steps * B) * 1e3,
         },
     }
 
@@ -288,6 +444,10 @@ def main():
 
         if world == 1 and a.dtype == "f32" and not a.no_split:
             out["f32_split_mode"] = split_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H)
+        default_workload = (Wd, H, a.scale, a.dtype, a.depth) == (1920, 1080, 1.0, "f32", 50)
+        if world == 1 and default_workload and not a.no_side:
+            out["configs2_stream_scale05"] = stream_scale05_rate(a, dev, blob, frames_np)
+            out["configs4_r101_f16_4k"] = r101_f16_4k_rate(a, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, frames_np[0], a.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -327,6 +487,89 @@ def split_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H):
             "parity": "logits within 3e-5 of the f32 oracle enforced in tests/test_gpu_split.py (measured 2.5e-6 .. 4e-6, the "
                       "native f32 MFMA mode measures 3e-6 .. 4e-6); class maps identical outside a 3e-5 band",
             "run": "python bench.py --dtype f32s"}
+
+
+def stream_scale05_rate(a, dev, blob, frames_np):
+    """BASELINE configs[2]: the 1080p stream at scale 0.5 -- frames come from HOST memory through the depth-3
+    infur_stream ring (H2D, scale + forward + decode, D2H on three HIP streams), i.e. PCIe inclusive, native f32.
+    Reported next to the headline; never `value`.  roofline: direct-conv FLOPs of a 960x540 frame x frames/s
+    against the f32 MFMA peak (Winograd layers make > 1 possible, as for the headline)."""
+    from infur_amd import weights as W
+    from infur_amd.app import StreamPath
+    from infur_amd.processors import Context, FramePath, Model, ModelCmd
+
+    ctx = Context(device=dev, compute_aux=not a.no_aux)
+    Model(ctx).control(ModelCmd.LoadBlob(blob))
+    H, Wd = frames_np[0].shape[:2]
+    sp = StreamPath(ctx, depth=3)
+    n = 48
+    frames = [(i, frames_np[i % len(frames_np)]) for i in range(n)]
+    list(sp.run(frames[:6], 0.5))  # warm-up: ring allocation, tile configurations
+    t0 = time.perf_counter()
+    got = list(sp.run(frames, 0.5))
+    dt = time.perf_counter() - t0
+    sp.close()
+    # the same per-frame work with the frame already in HBM
+    import torch
+
+    fp = FramePath(ctx)
+    oh, ow = got[0][1].shape[:2]
+    d_in = torch.from_numpy(frames_np[0]).cuda()
+    d_out = torch.empty((oh, ow, 4), dtype=torch.uint8, device="cuda")
+    for _ in range(4):
+        fp.advance_dev(d_in.data_ptr(), Wd, H, 0.5, d_out.data_ptr(), d_out.numel())
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(32):
+        fp.advance_dev(d_in.data_ptr(), Wd, H, 0.5, d_out.data_ptr(), d_out.numel())
+    ctx.synchronize()
+    dt_dev = time.perf_counter() - t1
+    ctx.close()
+    gflop = W.conv_flops(oh, ow, depth=50, aux=not a.no_aux)["total"] / 1e9
+    fps = n / dt
+    return {"value": fps, "unit": "frames/s", "dtype": "f32", "frames": n, "realtime_30fps_streams": fps / 30.0,
+            "workload": f"{Wd}x{H} bgr24 frames from host memory -> scale 0.5 (nearest) -> {ow}x{oh} FCN-ResNet50 -> mask to host; "
+                        "infur_stream depth 3, PCIe inclusive",
+            "hbm_resident_frames_per_s": 32 / dt_dev, "conv_gflop_per_frame": gflop,
+            "roofline": {"bound": "mfma", "achieved": gflop * (32 / dt_dev) / 1e3, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gflop * (32 / dt_dev) / 1e3 / PEAK_F32_MFMA_TFLOPS,
+                         "note": "whole-frame algorithmic (direct-conv) FLOPs x HBM-resident frames/s; 11 convs run as Winograd F(4x4)"}}
+
+
+def r101_f16_4k_rate(a, dev):
+    """BASELINE configs[4]: one 3840x2160 frame through FCN-ResNet101 on the f16 matrix cores (f16 operands, f32
+    accumulation), scale 1.0, frame resident in HBM.  roofline: 14,278 GFLOP per frame x frames/s against the dense
+    f16 MFMA peak (2.5 PFLOP/s)."""
+    import torch
+
+    from infur_amd import weights as W
+    from infur_amd.processors import Context, FramePath, Model, ModelCmd
+
+    H, Wd = 2160, 3840
+    ctx = Context(device=dev, compute_aux=not a.no_aux, dtype="f16")
+    Model(ctx).control(ModelCmd.LoadBlob(W.synth_blob(depth=101)))
+    fp = FramePath(ctx)
+    d_in = torch.from_numpy(W.synth_frame(H, Wd, index=0)).cuda()
+    d_out = torch.empty((H, Wd, 4), dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        fp.advance_dev(d_in.data_ptr(), Wd, H, 1.0, d_out.data_ptr(), d_out.numel())
+    ctx.synchronize()
+    n = 8
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fp.advance_dev(d_in.data_ptr(), Wd, H, 1.0, d_out.data_ptr(), d_out.numel())
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    gflop = W.conv_flops(H, Wd, depth=101, aux=not a.no_aux)["total"] / 1e9
+    fps = n / dt
+    return {"value": fps, "unit": "frames/s", "dtype": "f16", "ms_per_frame": dt / n * 1e3, "frames": n,
+            "workload": f"{Wd}x{H} frame, FCN-ResNet101 f16 operands / f32 accumulation, scale 1.0, HBM resident",
+            "conv_gflop_per_frame": gflop,
+            "roofline": {"bound": "mfma", "achieved": gflop * fps / 1e3, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gflop * fps / 1e3 / PEAK_F16_MFMA_TFLOPS},
+            "parity": "per-layer and whole-frame logits vs the f32 oracle at 5e-3 (tests/test_gpu_f16_r101.py); a "
+                      "reduced-precision mode by definition, never the headline"}
 
 
 def idims(ctx, w, h, factor):

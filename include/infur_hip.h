@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define INFUR_ABI_VERSION 1
+#define INFUR_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -46,7 +46,7 @@ enum {
     INFUR_E_MODEL_NOT_LOADED = 5, /* advance without a model where one is required */
     INFUR_E_MODEL_FORMAT = 6,     /* ModelCmdError / ModelInputFormatError, predict_onnx.rs:41-54 */
     INFUR_E_HIP = 7,              /* HIP runtime error (ModelProcError::RuntimeError analogue) */
-    INFUR_E_RCCL = 8,             /* reserved: collective error in the multi-GPU host layer */
+    INFUR_E_RCCL = 8,             /* RCCL error in infur_group_* / infur_weights_broadcast */
     INFUR_E_INVALID_ARG = 9,
     INFUR_E_IO = 10,              /* model file could not be read */
     INFUR_E_CAPACITY = 11         /* caller's output buffer is too small */
@@ -94,7 +94,7 @@ typedef struct infur_model_info {
     char input_name[32];    /* "input" */
     char input0_dtype[16];  /* "Float" */
     char output_names[2][32]; /* "out", "aux" */
-    uint32_t n_outputs;
+    uint32_t n_outputs;     /* 2, or 1 when the file has no aux head or options.compute_aux == 0 */
     uint32_t num_classes;
     uint32_t depth;         /* 50 | 101 */
     uint32_t n_convs;
@@ -159,11 +159,20 @@ int32_t infur_model_info_get(const infur_ctx* ctx, infur_model_info* info);
 /* Model::advance (predict_onnx.rs:317-334): pre-proc (:97-140) + forward (:138) + batch
  * strip (:326-330).  out / aux: [num_classes, h, w] f32 planar, either may be NULL.
  * With no model loaded this is a no-op returning INFUR_OK (predict_onnx.rs:318,333) and
- * *n_outputs (optional) is set to 0; otherwise to 2. */
+ * *n_outputs (optional) is set to 0; otherwise to infur_model_info.n_outputs (the length of the
+ * reference's output Vec).  Passing `aux` for a one-output model is INFUR_E_INVALID_ARG, reported
+ * before any work is done.
+ * Limits: a single activation tensor must stay below 2 GiB (32-bit buffer offsets in the conv
+ * kernel; INFUR_E_HIP otherwise) -- far above every BASELINE config (4K f32: 0.53 GiB). */
 int32_t infur_model_advance(infur_ctx* ctx, const uint8_t* bgr, uint32_t w, uint32_t h,
                             float* out, float* aux, uint32_t* n_outputs);
 int32_t infur_model_advance_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t h,
                                 void* d_out, void* d_aux, uint32_t* n_outputs);
+/* Optional: run one throw-away frame of w x h so that the first real advance at that size finds its activation
+ * arena allocated and every conv shape's tile configuration measured (options.no_autotune == 0 times the
+ * candidates on first use: a few hundred ms).  A GUI calls this when the scale slider settles
+ * (processing.rs:220-226 marks the processor dirty at that moment).  INFUR_E_MODEL_NOT_LOADED without a model. */
+int32_t infur_model_warmup(infur_ctx* ctx, uint32_t w, uint32_t h);
 /* output-stride-8 logits of the last advance, [num_classes, lh, lw] f32 planar (host) */
 int32_t infur_model_lowres_dims(uint32_t h, uint32_t w, uint32_t* lh, uint32_t* lw);
 int32_t infur_model_read_lowres(infur_ctx* ctx, float* out_low, float* aux_low, uint32_t* lh,
@@ -215,6 +224,9 @@ int32_t infur_frame_advance_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, u
  * (ff-video/src/decoder.rs:53-64,156-165). */
 typedef struct infur_stream infur_stream;
 int32_t infur_stream_create(infur_ctx* ctx, uint32_t depth, infur_stream** out);
+/* Lifetime: a stream belongs to its context.  infur_ctx_destroy releases the resources of the streams still
+ * alive and leaves them as empty handles (every call on them then returns INFUR_E_INVALID_ARG); such a handle
+ * must still be passed to infur_stream_destroy.  Either destroy order is therefore safe. */
 void infur_stream_destroy(infur_stream* st);
 /* INFUR_OK, or an error of infur_frame_advance; frame_id is returned by collect */
 int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor,
@@ -236,6 +248,41 @@ int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t rgba_capaci
 int32_t infur_batch_advance(infur_ctx* ctx, const uint8_t* const* frames, const uint32_t* ws,
                             const uint32_t* hs, uint32_t n, float factor, uint32_t scale_mode,
                             uint8_t* const* rgba, const size_t* caps, uint32_t* ows, uint32_t* ohs);
+
+/* ---- several GPUs from ONE host process (BASELINE configs[3]; north_star: "a frame-batch mode shards independent
+ * frames across the 8 GPUs of one node with RCCL broadcast of weights over xGMI and no cross-GPU dependence") ----
+ * The reference runs all processors on one `Proc` thread of one process (infur/src/main.rs:38-40,110-112); a Rust
+ * host reaches N GPUs through a GROUP: n contexts (normally one per device; several on one device are allowed),
+ * one persistent worker thread per context, and -- when the contexts span >= 2 devices -- one RCCL communicator
+ * over those devices (ncclCommInitAll).  Frames are independent (app.rs:107-153), so the only collective is the
+ * one-off replication of the weights.  A group and its contexts are used from one thread at a time. */
+typedef struct infur_group infur_group;
+int32_t infur_group_create(infur_ctx* const* ctxs, uint32_t n_ctx, infur_group** out);
+void infur_group_destroy(infur_group* g); /* the contexts stay alive and remain the caller's */
+const char* infur_group_last_error(const infur_group* g);
+uint32_t infur_group_size(const infur_group* g);
+/* 1 when the group holds an RCCL communicator (its contexts span >= 2 devices, or INFUR_FORCE_RCCL=1 in the
+ * environment: then a single-device group routes its copies through a one-rank communicator -- a test hook) */
+uint32_t infur_group_uses_rccl(const infur_group* g);
+/* Replicates the model loaded in context `root` (index into the group) to every other context: ONE
+ * ncclBroadcast of the repacked weight arena (141 MB for FCN-ResNet50 f32) over xGMI, no
+ * per-GPU re-upload or repack; contexts sharing a device with an already served one get a device-to-device copy.
+ * All contexts must have been created with the same compute_dtype / winograd options (the arena layout depends
+ * on them).  INFUR_E_MODEL_NOT_LOADED if `root` has no model; INFUR_E_RCCL on a collective error. */
+int32_t infur_group_weights_broadcast(infur_group* g, uint32_t root);
+/* infur_batch_advance over the whole group: frames [0, n) are split into contiguous slices, slice r (sizes differ
+ * by at most one) runs on context r's worker thread through that context's depth-3 ring; masks land in rgba[i]
+ * in frame order.  No data-path collective.  Returns the first failing context's status. */
+int32_t infur_group_batch_advance(infur_group* g, const uint8_t* const* frames, const uint32_t* ws,
+                                  const uint32_t* hs, uint32_t n, float factor, uint32_t scale_mode,
+                                  uint8_t* const* rgba, const size_t* caps, uint32_t* ows, uint32_t* ohs);
+/* One-shot forms (SURVEY section 8b's names): build a temporary group around the call.  ctxs[0] is the root.  Use a
+ * persistent infur_group when calling repeatedly: communicator and thread set-up then happen once. */
+int32_t infur_weights_broadcast(infur_ctx* const* ctxs, uint32_t n_ctx);
+int32_t infur_batch_advance_multi(infur_ctx* const* ctxs, uint32_t n_ctx, const uint8_t* const* frames,
+                                  const uint32_t* ws, const uint32_t* hs, uint32_t n, float factor,
+                                  uint32_t scale_mode, uint8_t* const* rgba, const size_t* caps,
+                                  uint32_t* ows, uint32_t* ohs);
 
 /* ---- INFUR_DTYPE_F32_SPLIT range monitor ----
  * The split mode carries every GEMM operand as an f16 pair of x * 2^k with static k: exact to

@@ -140,11 +140,12 @@ public:
         return r;
     }
 
-    /// predict_onnx.rs:317-334: with no model `out` is left untouched and Ok is returned
+    /// predict_onnx.rs:317-334: with no model `out` is left untouched and Ok is returned.  `out` receives as many
+    /// tensors as the model has outputs (2, or 1 without the aux head / with compute_aux = false).
     Status advance(const BgrImage& img, std::vector<Tensor3>& out) {
         infur_model_info mi;
         if (infur_model_info_get(c_.get(), &mi) != INFUR_OK) return INFUR_OK;
-        std::vector<Tensor3> t(2);
+        std::vector<Tensor3> t(mi.n_outputs);
         for (auto& x : t) {
             x.k = mi.num_classes;
             x.h = img.height;
@@ -153,7 +154,7 @@ public:
         }
         uint32_t n = 0;
         Status s = infur_model_advance(c_.get(), img.data.data(), img.width, img.height, t[0].data.data(),
-                                       t[1].data.data(), &n);
+                                       t.size() > 1 ? t[1].data.data() : nullptr, &n);
         if (s != INFUR_OK) return s;
         out.clear();
         for (auto& x : t) out.push_back(std::move(x));
@@ -183,6 +184,53 @@ public:
 
 private:
     Context& c_;
+};
+
+/// infur_group: n contexts (one per GPU) of one process -- RCCL weight broadcast + frame-batch sharding
+/// (BASELINE configs[3]).  The contexts must outlive the group.
+class Group {
+public:
+    explicit Group(const std::vector<Context*>& ctxs) {
+        std::vector<infur_ctx*> raw;
+        for (Context* c : ctxs) raw.push_back(c->get());
+        status_ = infur_group_create(raw.data(), (uint32_t)raw.size(), &g_);
+    }
+    ~Group() { infur_group_destroy(g_); }
+    Group(const Group&) = delete;
+    Group& operator=(const Group&) = delete;
+    bool ok() const { return status_ == INFUR_OK; }
+    infur_group* get() const { return g_; }
+    std::string last_error() const { return infur_group_last_error(g_); }
+    Status weights_broadcast(uint32_t root = 0) { return infur_group_weights_broadcast(g_, root); }
+    /// masks[i] is resized to the mask of frames[i] (scale `factor` applied first, as app.rs:107-153 does per frame)
+    Status batch_advance(const std::vector<BgrImage>& frames, float factor, std::vector<ColorImage>& masks,
+                         uint32_t scale_mode = INFUR_SCALE_NEAREST) {
+        const size_t n = frames.size();
+        masks.resize(n);
+        std::vector<const uint8_t*> in(n);
+        std::vector<uint8_t*> out(n);
+        std::vector<uint32_t> ws(n), hs(n);
+        std::vector<size_t> caps(n);
+        for (size_t i = 0; i < n; i++) {
+            uint32_t ow = 0, oh = 0;
+            Status s = infur_scale_out_dims(frames[i].width, frames[i].height, factor, &ow, &oh);
+            if (s != INFUR_OK) return s;
+            masks[i].width = ow;
+            masks[i].height = oh;
+            masks[i].rgba.resize((size_t)ow * oh * 4);
+            in[i] = frames[i].data.data();
+            out[i] = masks[i].rgba.data();
+            ws[i] = frames[i].width;
+            hs[i] = frames[i].height;
+            caps[i] = masks[i].rgba.size();
+        }
+        return infur_group_batch_advance(g_, in.data(), ws.data(), hs.data(), (uint32_t)n, factor, scale_mode, out.data(),
+                                         caps.data(), nullptr, nullptr);
+    }
+
+private:
+    infur_group* g_ = nullptr;
+    Status status_ = INFUR_OK;
 };
 
 }  // namespace infur

@@ -11,6 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinfur_hip.so")
 
+ABI_VERSION = 2  # INFUR_ABI_VERSION of include/infur_hip.h
+
 # status codes (include/infur_hip.h)
 OK = 0
 E_INVALID_SCALE = 1
@@ -101,6 +103,7 @@ SIGNATURES = {
     "infur_model_info_get": (C.c_int32, [_vp, C.POINTER(ModelInfoC)]),
     "infur_model_advance": (C.c_int32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32p]),
     "infur_model_advance_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32p]),
+    "infur_model_warmup": (C.c_int32, [_vp, _u32, _u32]),
     "infur_model_lowres_dims": (C.c_int32, [_u32, _u32, _u32p, _u32p]),
     "infur_model_read_lowres": (C.c_int32, [_vp, _vp, _vp, _u32p, _u32p]),
     "infur_debug_read_activation": (C.c_int32, [_vp, _u32, _vp, _sz, _u32p, _u32p, _u32p]),
@@ -120,6 +123,17 @@ SIGNATURES = {
     "infur_stream_collect": (C.c_int32, [_vp, _vp, _sz, _vp, C.POINTER(C.c_uint64), _u32p, _u32p]),
     "infur_batch_advance": (C.c_int32, [_vp, C.POINTER(_vp), _u32p, _u32p, _u32, _f, _u32, C.POINTER(_vp),
                                         C.POINTER(_sz), _u32p, _u32p]),
+    "infur_group_create": (C.c_int32, [C.POINTER(_vp), _u32, C.POINTER(_vp)]),
+    "infur_group_destroy": (None, [_vp]),
+    "infur_group_last_error": (C.c_char_p, [_vp]),
+    "infur_group_size": (C.c_uint32, [_vp]),
+    "infur_group_uses_rccl": (C.c_uint32, [_vp]),
+    "infur_group_weights_broadcast": (C.c_int32, [_vp, _u32]),
+    "infur_group_batch_advance": (C.c_int32, [_vp, C.POINTER(_vp), _u32p, _u32p, _u32, _f, _u32, C.POINTER(_vp),
+                                              C.POINTER(_sz), _u32p, _u32p]),
+    "infur_weights_broadcast": (C.c_int32, [C.POINTER(_vp), _u32]),
+    "infur_batch_advance_multi": (C.c_int32, [C.POINTER(_vp), _u32, C.POINTER(_vp), _u32p, _u32p, _u32, _f, _u32,
+                                              C.POINTER(_vp), C.POINTER(_sz), _u32p, _u32p]),
     "infur_split_range": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _u32p]),
     "infur_tune_export": (C.c_int32, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "infur_tune_import": (C.c_int32, [_vp, C.c_char_p, _sz]),
@@ -150,8 +164,9 @@ def load() -> C.CDLL:
     # /opt/rocm's).  Two runtimes in one process cannot both own the GPU, so when torch is
     # installed it is imported FIRST: the loader then binds libinfur_hip.so's libamdhip64.so.7
     # dependency to the copy torch already mapped and the process has a single runtime
-    # (needed for torch.distributed/RCCL next to our kernels).  Without torch the system
-    # runtime from the library's RUNPATH is used.
+    # (needed for torch.distributed/RCCL next to our kernels).  The same holds for librccl.so.1,
+    # which libinfur_hip.so links for infur_group_* (torch bundles its own copy under that soname).
+    # Without torch the system libraries from the library's RUNPATH are used.
     try:
         import torch  # noqa: F401
     except ImportError:
@@ -161,7 +176,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.infur_abi_version() != 1:
+    if lib.infur_abi_version() != ABI_VERSION:
         raise ImportError("libinfur_hip.so ABI version mismatch")
     _lib = lib
     return lib

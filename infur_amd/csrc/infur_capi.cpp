@@ -20,99 +20,17 @@
 #include <cstdlib>
 #include <array>
 #include <cstring>
+#include <exception>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
+#include "infur_ctx.h"
 #include "kernels.h"
 #include "onnx_reader.h"
 
 using namespace infur;
-
-namespace {
-
-struct Buf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    bool used = false;
-};
-
-struct Tensor {  // NHWC activation (f32 or f16) living in the pool
-    void* p = nullptr;
-    int h = 0, w = 0, c = 0;
-    int slot = -1;
-    int es = 4;  // element size: 4 = f32, 2 = f16
-    size_t elems() const { return (size_t)h * w * c; }
-    size_t bytes() const { return elems() * (size_t)es; }
-};
-
-struct ConvLayer {
-    std::string name;
-    int cout = 0, cin = 0, k = 0, stride = 1, pad = 0, dil = 1;
-    bool relu = false;
-    char role = 0;        // s stem, 1 2 3 block convs, d downsample, h head3x3, c classifier
-    void* d_w = nullptr;   // repacked weights (context dtype; the stem's stay f32)
-    float* d_b = nullptr;  // bias, always f32
-    float* d_u = nullptr;  // Winograd-domain weights U[16][cout][cin] (f32 stride-1 3x3 convs only)
-    // INFUR_DTYPE_F32_SPLIT: d_w / d_u hold f16 (hi, lo) pairs of w * w_scale / u * u_scale (powers of two)
-    float w_scale = 1.0f, u_scale = 1.0f;
-    // conv3 of a stage's first block: its weights and the downsample branch's side by side ([cout][cin + ds.cin],
-    // context dtype), the two biases summed -- the two-source GEMM of run_conv_dual
-    void* d_wcat = nullptr;
-    float* d_bcat = nullptr;
-    float wcat_scale = 1.0f;
-};
-
-struct ProfRec {
-    std::string name;
-    const char* kernel;
-    double flops, bytes, algo_flops;
-    hipEvent_t e0, e1;
-};
-
-}  // namespace
-
-struct infur_ctx {
-    infur_options opt{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::string err;
-
-    // lookup tables
-    float* d_pre_lut = nullptr;     // [3][256] f32, RGB order
-    uint32_t* d_color_lut = nullptr;  // [20][256] premultiplied RGBA
-
-    // model
-    bool loaded = false;
-    infur_model_info info{};
-    int depth = 0, num_classes = 0;
-    bool has_aux = false;
-    std::vector<ConvLayer> convs;
-    void* d_weights = nullptr;  // single allocation holding every repacked tensor
-    size_t weight_bytes = 0;
-
-    // activation pool + results of the last forward
-    std::vector<Buf> pool;
-    Tensor out_low, aux_low;  // NHWC [lh][lw][K]
-    int last_h = 0, last_w = 0;
-    std::vector<Tensor> kept;  // keep_activations: output of every conv
-
-    // staging for the host-pointer entry points
-    Buf st_in, st_scaled, st_rgba, st_f32a, st_f32b;
-
-    // profiling
-    std::vector<ProfRec> prof;
-    std::vector<hipEvent_t> ev_free;
-
-    // measured tile configuration per conv shape (see pick_cfg)
-    std::map<std::array<int, 13>, int> tuned;
-    bool tune_warm = false;
-
-    // INFUR_DTYPE_F32_SPLIT range monitor: [0] max |activation| fed to a GEMM, [1] max |Winograd-domain input|
-    // of the last forward (bit patterns of non-negative floats, atomicMax targets); infur_split_range
-    unsigned* d_range = nullptr;
-};
 
 namespace {
 
@@ -167,6 +85,7 @@ int32_t pool_acquire(infur_ctx* c, size_t bytes, int* slot) {
         best = (int)c->pool.size() - 1;
     }
     c->pool[best].used = true;
+    c->pool[best].last_use = c->frame_no;
     *slot = best;
     return INFUR_OK;
 }
@@ -188,6 +107,23 @@ void pool_free(infur_ctx* c) {
     for (auto& b : c->pool)
         if (b.p) (void)hipFree(b.p);
     c->pool.clear();
+}
+
+// A long-lived context that has seen several frame sizes (the GUI's scale slider) would otherwise keep the
+// largest arena forever: once kPoolTrimAfter consecutive frames had the same size, buffers no frame of that
+// run has used are returned to the device.  hipFree synchronises, so nothing in flight can still touch them.
+constexpr uint32_t kPoolTrimAfter = 4;
+void pool_trim(infur_ctx* c) {
+    size_t kept = 0;
+    for (auto& b : c->pool) {
+        if (!b.used && b.p && b.last_use + kPoolTrimAfter <= c->frame_no) {
+            (void)hipFree(b.p);
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+        if (b.p) c->pool[kept++] = b;
+    }
+    c->pool.resize(kept);
 }
 
 int32_t talloc(infur_ctx* c, int h, int w, int ch, int es, Tensor* t) {
@@ -446,7 +382,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     if (ncls <= 0 || ncls > 256) return fail(c, INFUR_E_MODEL_FORMAT, "unsupported class count %d", ncls);
     std::vector<ConvLayer> g = build_graph(depth, ncls, aux);
     if (n != g.size()) return fail(c, INFUR_E_MODEL_FORMAT, "blob has %u convs, graph needs %zu", n, g.size());
-    if (kBlobHdr + (size_t)n * kBlobEntry > len) return fail(c, INFUR_E_MODEL_FORMAT, "truncated conv table");
+    if ((len - kBlobHdr) / kBlobEntry < n) return fail(c, INFUR_E_MODEL_FORMAT, "truncated conv table");
     std::vector<uint8_t> table((size_t)n * kBlobEntry);
     HIPCHK(c, hipMemcpyAsync(table.data(), (const uint8_t*)d_blob + kBlobHdr, table.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -468,7 +404,9 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         if ((int)d[0] != L.cout || (int)d[1] != L.cin || (int)d[2] != L.k || (int)d[3] != L.k)
             return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' has shape [%u,%u,%u,%u], expected [%d,%d,%d,%d]", name, d[0], d[1], d[2], d[3], L.cout, L.cin, L.k, L.k);
         const size_t wn = (size_t)L.cout * L.cin * L.k * L.k * 4, bn = (size_t)L.cout * 4;
-        if (ents[i].w_off % 4 || ents[i].b_off % 4 || ents[i].w_off + wn > len || ents[i].b_off + bn > len)
+        // offsets come from the (untrusted) file: compare without forming off + n, which can wrap
+        auto in_range = [len](uint64_t off, size_t n) { return off <= len && n <= len - off; };
+        if (ents[i].w_off % 4 || ents[i].b_off % 4 || !in_range(ents[i].w_off, wn) || !in_range(ents[i].b_off, bn))
             return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' data out of range", name);
         total += align_up(wn, 256) + align_up(bn, 256);  // upper bound (f16 weights take half)
         if (wino_eligible(c, L)) total += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
@@ -476,15 +414,21 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
             total += align_up((size_t)L.cout * (L.cin + g[i + 1].cin) * 4, 256) + align_up(bn, 256);
     }
 
-    model_free(c);
-    HIPCHK(c, hipMalloc(&c->d_weights, total));
+    // The new weight set is built beside the loaded one and swapped in only when everything succeeded: a failed
+    // (re)load leaves the previous model in place, as Model::control does on any load error (predict_onnx.rs:288-309).
+    struct DevMem {
+        void* p = nullptr;
+        ~DevMem() { if (p) (void)hipFree(p); }
+    } arena;
+    HIPCHK(c, hipMalloc(&arena.p, total));
+    void* const d_weights = arena.p;
     size_t off = 0;
     for (uint32_t i = 0; i < n; i++) {
         ConvLayer& L = g[i];
         const size_t wn = (size_t)L.cout * L.cin * L.k * L.k * 4, bn = (size_t)L.cout * 4;
-        L.d_w = (float*)((uint8_t*)c->d_weights + off);
+        L.d_w = (float*)((uint8_t*)d_weights + off);
         off += align_up(wn, 256);
-        L.d_b = (float*)((uint8_t*)c->d_weights + off);
+        L.d_b = (float*)((uint8_t*)d_weights + off);
         off += align_up(bn, 256);
         const float* src_w = (const float*)((const uint8_t*)d_blob + ents[i].w_off);
         if (L.role == 's')
@@ -495,7 +439,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
             HIPCHK(c, launch_repack_oihw_to_ohwi(src_w, L.d_w, ctx_f16(c) ? 1 : 0, L.cout, L.cin, L.k, L.k, c->stream));
         HIPCHK(c, hipMemcpyAsync(L.d_b, (const uint8_t*)d_blob + ents[i].b_off, bn, hipMemcpyDeviceToDevice, c->stream));
         if (wino_eligible(c, L)) {
-            L.d_u = (float*)((uint8_t*)c->d_weights + off);
+            L.d_u = (float*)((uint8_t*)d_weights + off);
             off += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
             HIPCHK(c, launch_wino_weights(src_w, L.cout, L.cin, wino_mt(c), L.d_u, c->stream));
         }
@@ -506,15 +450,18 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         const ConvLayer& D = g[i + 1];
         if (L.role != '3' || D.role != 'd') continue;
         const size_t es = ctx_f16(c) ? 2 : 4;
-        L.d_wcat = (uint8_t*)c->d_weights + off;
+        L.d_wcat = (uint8_t*)d_weights + off;
         off += align_up((size_t)L.cout * (L.cin + D.cin) * 4, 256);
-        L.d_bcat = (float*)((uint8_t*)c->d_weights + off);
+        L.d_bcat = (float*)((uint8_t*)d_weights + off);
         off += align_up((size_t)L.cout * 4, 256);
         HIPCHK(c, launch_concat_rows(L.d_w, (size_t)L.cin * es, D.d_w, (size_t)D.cin * es, L.d_wcat, L.cout, c->stream));
         HIPCHK(c, launch_add_f32(L.d_b, D.d_b, L.d_bcat, L.cout, c->stream));
     }
     if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT) RETIF(split_weights(c, g));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    model_free(c);  // the old model goes only now
+    c->d_weights = d_weights;
+    arena.p = nullptr;
     c->convs.swap(g);
     c->depth = depth;
     c->num_classes = ncls;
@@ -527,8 +474,9 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     snprintf(mi.input_name, sizeof mi.input_name, "input");
     snprintf(mi.input0_dtype, sizeof mi.input0_dtype, "Float");  // the model's declared input type (predict_onnx.rs:90)
     snprintf(mi.output_names[0], 32, "out");
-    snprintf(mi.output_names[1], 32, "aux");
-    mi.n_outputs = 2;
+    // the aux output exists when the file has the head AND this context evaluates it (options.compute_aux)
+    mi.n_outputs = 1 + ((aux && c->opt.compute_aux) ? 1 : 0);
+    if (mi.n_outputs == 2) snprintf(mi.output_names[1], 32, "aux");
     mi.num_classes = (uint32_t)ncls;
     mi.depth = (uint32_t)depth;
     mi.n_convs = n;
@@ -702,6 +650,9 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     if (w <= 0 || h <= 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %dx%d", w, h);
     pool_release_all(c);
     prof_reset(c);
+    c->frame_no++;
+    c->same_size = (h == c->last_h && w == c->last_w) ? c->same_size + 1 : 0;
+    if (c->same_size == kPoolTrimAfter) pool_trim(c);  // no tensor is live here: slots may be renumbered
     if (c->d_range) HIPCHK(c, hipMemsetAsync(c->d_range, 0, 2 * sizeof(unsigned), c->stream));
     size_t ci = 0;
     const ConvLayer& stem = c->convs[ci++];
@@ -781,6 +732,8 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
 // =====================================================================================
 // Every entry point runs on its context's device: a process may hold contexts on several GPUs, and
 // hipMalloc / kernel launches follow the calling thread's current device, not the stream's.
+static void stream_orphan(infur_stream* st);  // releases a stream's resources and detaches it from its context
+
 static inline void enter(const infur_ctx* c) {
     int cur = -1;
     if (c && (hipGetDevice(&cur) != hipSuccess || cur != c->device)) (void)hipSetDevice(c->device);
@@ -823,52 +776,60 @@ void infur_options_default(infur_options* o) {
 }
 
 int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
-    if (!out) return INFUR_E_INVALID_ARG;
-    *out = nullptr;
-    infur_options o;
-    infur_options_default(&o);
-    if (opts) {
-        if (opts->struct_size != sizeof(infur_options)) return INFUR_E_INVALID_ARG;
-        o = *opts;
-    }
-    if (o.compute_dtype > INFUR_DTYPE_F32_SPLIT) return INFUR_E_INVALID_ARG;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || o.device < 0 || o.device >= n) return INFUR_E_HIP;
-    if (hipSetDevice(o.device) != hipSuccess) return INFUR_E_HIP;
-    infur_ctx* c = new infur_ctx();
-    c->opt = o;
-    c->device = o.device;
-    if (o.stream) {
-        c->stream = (hipStream_t)o.stream;
-    } else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete c;
+    try {
+        if (!out) return INFUR_E_INVALID_ARG;
+        *out = nullptr;
+        infur_options o;
+        infur_options_default(&o);
+        if (opts) {
+            if (opts->struct_size != sizeof(infur_options)) return INFUR_E_INVALID_ARG;
+            o = *opts;
+        }
+        if (o.compute_dtype > INFUR_DTYPE_F32_SPLIT) return INFUR_E_INVALID_ARG;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || o.device < 0 || o.device >= n) return INFUR_E_HIP;
+        if (hipSetDevice(o.device) != hipSuccess) return INFUR_E_HIP;
+        infur_ctx* c = new infur_ctx();
+        c->opt = o;
+        c->device = o.device;
+        if (o.stream) {
+            c->stream = (hipStream_t)o.stream;
+        } else {
+            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+                delete c;
+                return INFUR_E_HIP;
+            }
+            c->own_stream = true;
+        }
+        std::vector<float> pre(768);
+        std::vector<uint32_t> col(20 * 256);
+        build_pre_lut(pre.data());
+        build_color_lut(col.data());
+        bool ok = hipMalloc((void**)&c->d_pre_lut, pre.size() * 4) == hipSuccess &&
+                  hipMalloc((void**)&c->d_color_lut, col.size() * 4) == hipSuccess &&
+                  hipMemcpy(c->d_pre_lut, pre.data(), pre.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(c->d_color_lut, col.data(), col.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  (o.compute_dtype != INFUR_DTYPE_F32_SPLIT ||
+                   (hipMalloc((void**)&c->d_range, 2 * sizeof(unsigned)) == hipSuccess && hipMemset(c->d_range, 0, 2 * sizeof(unsigned)) == hipSuccess));
+        if (!ok) {
+            infur_ctx_destroy(c);
             return INFUR_E_HIP;
         }
-        c->own_stream = true;
+        *out = c;
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(nullptr, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    std::vector<float> pre(768);
-    std::vector<uint32_t> col(20 * 256);
-    build_pre_lut(pre.data());
-    build_color_lut(col.data());
-    bool ok = hipMalloc((void**)&c->d_pre_lut, pre.size() * 4) == hipSuccess &&
-              hipMalloc((void**)&c->d_color_lut, col.size() * 4) == hipSuccess &&
-              hipMemcpy(c->d_pre_lut, pre.data(), pre.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(c->d_color_lut, col.data(), col.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              (o.compute_dtype != INFUR_DTYPE_F32_SPLIT ||
-               (hipMalloc((void**)&c->d_range, 2 * sizeof(unsigned)) == hipSuccess && hipMemset(c->d_range, 0, 2 * sizeof(unsigned)) == hipSuccess));
-    if (!ok) {
-        infur_ctx_destroy(c);
-        return INFUR_E_HIP;
-    }
-    *out = c;
-    return INFUR_OK;
 }
 
 void infur_ctx_destroy(infur_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    // streams that outlive their context become empty shells: infur_stream_destroy on them only frees the handle
+    while (!c->streams.empty()) stream_orphan(c->streams.back());
     model_free(c);
     pool_free(c);
     for (Buf* b : {&c->st_in, &c->st_scaled, &c->st_rgba, &c->st_f32a, &c->st_f32b})
@@ -916,45 +877,57 @@ int32_t infur_scale_out_dims(uint32_t w, uint32_t h, float factor, uint32_t* ow,
 
 int32_t infur_scale_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                         void* d_out, size_t cap, uint32_t* ow, uint32_t* oh) {
-    enter(c);
-    if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
-    if (mode > INFUR_SCALE_BILINEAR) return fail(c, INFUR_E_INVALID_ARG, "unknown scale mode %u", mode);
-    int32_t rc = infur_scale_validate(factor);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    rc = infur_scale_out_dims(w, h, factor, ow, oh);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    const size_t need = (size_t)*ow * *oh * 3;
-    if (need == 0) return INFUR_OK;
-    if (!d_bgr || !d_out) return INFUR_E_INVALID_ARG;
-    if (cap < need) return fail(c, INFUR_E_CAPACITY, "scaled frame needs %zu bytes, buffer has %zu", need, cap);
-    if (factor == 1.0f) {
-        HIPCHK(c, hipMemcpyAsync(d_out, d_bgr, need, hipMemcpyDeviceToDevice, c->stream));
-    } else {
-        ProfScope ps(c, "scale", mode ? "scale_bilinear" : "scale_nearest", 0, (double)w * h * 3 + (double)need);
-        HIPCHK(c, launch_scale_bgr((const uint8_t*)d_bgr, (int)w, (int)h, (uint8_t*)d_out, (int)*ow, (int)*oh, (int)mode, c->stream));
+    try {
+        enter(c);
+        if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
+        if (mode > INFUR_SCALE_BILINEAR) return fail(c, INFUR_E_INVALID_ARG, "unknown scale mode %u", mode);
+        int32_t rc = infur_scale_validate(factor);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        rc = infur_scale_out_dims(w, h, factor, ow, oh);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        const size_t need = (size_t)*ow * *oh * 3;
+        if (need == 0) return INFUR_OK;
+        if (!d_bgr || !d_out) return INFUR_E_INVALID_ARG;
+        if (cap < need) return fail(c, INFUR_E_CAPACITY, "scaled frame needs %zu bytes, buffer has %zu", need, cap);
+        if (factor == 1.0f) {
+            HIPCHK(c, hipMemcpyAsync(d_out, d_bgr, need, hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            ProfScope ps(c, "scale", mode ? "scale_bilinear" : "scale_nearest", 0, (double)w * h * 3 + (double)need);
+            HIPCHK(c, launch_scale_bgr((const uint8_t*)d_bgr, (int)w, (int)h, (uint8_t*)d_out, (int)*ow, (int)*oh, (int)mode, c->stream));
+        }
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    return INFUR_OK;
 }
 
 int32_t infur_scale(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                     uint8_t* out, size_t cap, uint32_t* ow, uint32_t* oh) {
-    enter(c);
-    if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
-    int32_t rc = infur_scale_validate(factor);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    rc = infur_scale_out_dims(w, h, factor, ow, oh);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    const size_t in_bytes = (size_t)w * h * 3, need = (size_t)*ow * *oh * 3;
-    if (need == 0) return INFUR_OK;
-    if (!bgr || !out) return INFUR_E_INVALID_ARG;
-    if (cap < need) return fail(c, INFUR_E_CAPACITY, "scaled frame needs %zu bytes, buffer has %zu", need, cap);
-    RETIF(ensure(c, c->st_in, in_bytes));
-    RETIF(ensure(c, c->st_scaled, need));
-    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
-    RETIF(infur_scale_dev(c, c->st_in.p, w, h, factor, mode, c->st_scaled.p, c->st_scaled.bytes, ow, oh));
-    HIPCHK(c, hipMemcpyAsync(out, c->st_scaled.p, need, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return INFUR_OK;
+    try {
+        enter(c);
+        if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
+        int32_t rc = infur_scale_validate(factor);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        rc = infur_scale_out_dims(w, h, factor, ow, oh);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        const size_t in_bytes = (size_t)w * h * 3, need = (size_t)*ow * *oh * 3;
+        if (need == 0) return INFUR_OK;
+        if (!bgr || !out) return INFUR_E_INVALID_ARG;
+        if (cap < need) return fail(c, INFUR_E_CAPACITY, "scaled frame needs %zu bytes, buffer has %zu", need, cap);
+        RETIF(ensure(c, c->st_in, in_bytes));
+        RETIF(ensure(c, c->st_scaled, need));
+        HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
+        RETIF(infur_scale_dev(c, c->st_in.p, w, h, factor, mode, c->st_scaled.p, c->st_scaled.bytes, ow, oh));
+        HIPCHK(c, hipMemcpyAsync(out, c->st_scaled.p, need, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 // ---- Model ----
@@ -967,74 +940,98 @@ int32_t infur_model_unload(infur_ctx* c) {
 }
 
 int32_t infur_model_load_blob_dev(infur_ctx* c, const void* d_blob, size_t len) {
-    enter(c);
-    if (!c || !d_blob) return INFUR_E_INVALID_ARG;
-    return model_load_dev(c, d_blob, len);
+    try {
+        enter(c);
+        if (!c || !d_blob) return INFUR_E_INVALID_ARG;
+        return model_load_dev(c, d_blob, len);
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 int32_t infur_model_load_blob(infur_ctx* c, const void* blob, size_t len) {
-    enter(c);
-    if (!c || !blob) return INFUR_E_INVALID_ARG;
-    if (len < kBlobHdr || memcmp(blob, "INFURW01", 8) != 0)
-        return fail(c, INFUR_E_MODEL_FORMAT, "bad magic: not an INFURW01 weight blob");
-    void* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, len));
-    hipError_t e = hipMemcpyAsync(d, blob, len, hipMemcpyHostToDevice, c->stream);
-    int32_t rc = e == hipSuccess ? model_load_dev(c, d, len) : fail(c, INFUR_E_HIP, "weight upload failed: %s", hipGetErrorString(e));
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    return rc;
+    try {
+        enter(c);
+        if (!c || !blob) return INFUR_E_INVALID_ARG;
+        if (len < kBlobHdr || memcmp(blob, "INFURW01", 8) != 0)
+            return fail(c, INFUR_E_MODEL_FORMAT, "bad magic: not an INFURW01 weight blob");
+        void* d = nullptr;
+        HIPCHK(c, hipMalloc(&d, len));
+        hipError_t e = hipMemcpyAsync(d, blob, len, hipMemcpyHostToDevice, c->stream);
+        int32_t rc = e == hipSuccess ? model_load_dev(c, d, len) : fail(c, INFUR_E_HIP, "weight upload failed: %s", hipGetErrorString(e));
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(d);
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 int32_t infur_model_load(infur_ctx* c, const char* path) {
-    enter(c);
-    if (!c || !path) return INFUR_E_INVALID_ARG;
-    if (path[0] == 0) return infur_model_unload(c);  // ModelCmd::Load("") unloads, predict_onnx.rs:310-312
-    FILE* f = fopen(path, "rb");
-    if (!f) return fail(c, INFUR_E_IO, "couldn't open model file '%s'", path);
-    fseek(f, 0, SEEK_END);
-    long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> buf(n > 0 ? (size_t)n : 0);
-    const size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
-    fclose(f);
-    if (got != buf.size()) return fail(c, INFUR_E_IO, "short read on '%s'", path);
-    if (buf.empty()) return fail(c, INFUR_E_MODEL_FORMAT, "model file '%s' is empty", path);
-    if (buf.size() >= 8 && memcmp(buf.data(), "INFURW01", 8) == 0) return infur_model_load_blob(c, buf.data(), buf.size());
-    if (looks_like_onnx(buf.data(), buf.size())) {
-        std::vector<uint8_t> blob;
-        OnnxInfo oi;
-        std::string err;
-        if (onnx_to_blob(buf.data(), buf.size(), blob, oi, err) != 0)
-            return fail(c, INFUR_E_MODEL_FORMAT, "couldn't infer image input / load '%s': %s", path, err.c_str());
-        int32_t rc = infur_model_load_blob(c, blob.data(), blob.size());
-        if (rc == INFUR_OK) {  // report the file's own tensor names (predict_onnx.rs:89-92)
-            snprintf(c->info.input_name, sizeof c->info.input_name, "%s", oi.input_name.c_str());
-            for (size_t i = 0; i < oi.output_names.size() && i < 2; i++)
-                snprintf(c->info.output_names[i], 32, "%s", oi.output_names[i].c_str());
+    try {
+        enter(c);
+        if (!c || !path) return INFUR_E_INVALID_ARG;
+        if (path[0] == 0) return infur_model_unload(c);  // ModelCmd::Load("") unloads, predict_onnx.rs:310-312
+        FILE* f = fopen(path, "rb");
+        if (!f) return fail(c, INFUR_E_IO, "couldn't open model file '%s'", path);
+        fseek(f, 0, SEEK_END);
+        long n = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> buf(n > 0 ? (size_t)n : 0);
+        const size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+        fclose(f);
+        if (got != buf.size()) return fail(c, INFUR_E_IO, "short read on '%s'", path);
+        if (buf.empty()) return fail(c, INFUR_E_MODEL_FORMAT, "model file '%s' is empty", path);
+        if (buf.size() >= 8 && memcmp(buf.data(), "INFURW01", 8) == 0) return infur_model_load_blob(c, buf.data(), buf.size());
+        if (looks_like_onnx(buf.data(), buf.size())) {
+            std::vector<uint8_t> blob;
+            OnnxInfo oi;
+            std::string err;
+            if (onnx_to_blob(buf.data(), buf.size(), blob, oi, err) != 0)
+                return fail(c, INFUR_E_MODEL_FORMAT, "couldn't infer image input / load '%s': %s", path, err.c_str());
+            int32_t rc = infur_model_load_blob(c, blob.data(), blob.size());
+            if (rc == INFUR_OK) {  // report the file's own tensor names (predict_onnx.rs:89-92)
+                snprintf(c->info.input_name, sizeof c->info.input_name, "%s", oi.input_name.c_str());
+                for (size_t i = 0; i < oi.output_names.size() && i < c->info.n_outputs; i++)
+                    snprintf(c->info.output_names[i], 32, "%s", oi.output_names[i].c_str());
+            }
+            return rc;
         }
-        return rc;
+        return fail(c, INFUR_E_MODEL_FORMAT, "'%s' is neither an INFURW01 blob nor an ONNX model", path);
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    return fail(c, INFUR_E_MODEL_FORMAT, "'%s' is neither an INFURW01 blob nor an ONNX model", path);
 }
 
 int32_t infur_onnx_to_blob(const void* onnx, size_t len, void** blob, size_t* blob_len, char* err, size_t errcap) {
-    if (!onnx || !blob || !blob_len) return INFUR_E_INVALID_ARG;
-    *blob = nullptr;
-    *blob_len = 0;
-    std::vector<uint8_t> out;
-    OnnxInfo oi;
-    std::string e;
-    if (onnx_to_blob((const uint8_t*)onnx, len, out, oi, e) != 0) {
-        if (err && errcap) snprintf(err, errcap, "%s", e.c_str());
-        return INFUR_E_MODEL_FORMAT;
+    try {
+        if (!onnx || !blob || !blob_len) return INFUR_E_INVALID_ARG;
+        *blob = nullptr;
+        *blob_len = 0;
+        std::vector<uint8_t> out;
+        OnnxInfo oi;
+        std::string e;
+        if (onnx_to_blob((const uint8_t*)onnx, len, out, oi, e) != 0) {
+            if (err && errcap) snprintf(err, errcap, "%s", e.c_str());
+            return INFUR_E_MODEL_FORMAT;
+        }
+        void* p = malloc(out.size());
+        if (!p) return INFUR_E_INVALID_ARG;
+        memcpy(p, out.data(), out.size());
+        *blob = p;
+        *blob_len = out.size();
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(nullptr, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    void* p = malloc(out.size());
-    if (!p) return INFUR_E_INVALID_ARG;
-    memcpy(p, out.data(), out.size());
-    *blob = p;
-    *blob_len = out.size();
-    return INFUR_OK;
 }
 
 void infur_buffer_free(void* p) { free(p); }
@@ -1060,85 +1057,136 @@ int32_t infur_model_lowres_dims(uint32_t h, uint32_t w, uint32_t* lh, uint32_t* 
 
 int32_t infur_model_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, void* d_out, void* d_aux,
                                 uint32_t* n_outputs) {
-    enter(c);
-    if (!c) return INFUR_E_INVALID_ARG;
-    if (n_outputs) *n_outputs = 0;
-    if (!c->loaded) return INFUR_OK;  // no session: out untouched, Ok(()) (predict_onnx.rs:318,333)
-    if (!d_bgr) return INFUR_E_INVALID_ARG;
-    if (w == 0 || h == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
-    RETIF(forward(c, (const uint8_t*)d_bgr, (int)w, (int)h));
-    const int K = c->num_classes;
-    const double up_bytes = (double)c->out_low.bytes() + 4.0 * (double)K * h * w;
-    if (d_out) {
-        ProfScope ps(c, "out.resize", "upsample_planar", 0, up_bytes);
-        HIPCHK(c, launch_upsample_planar((const float*)c->out_low.p, c->out_low.h, c->out_low.w, K, (float*)d_out, (int)h, (int)w, c->stream));
+    try {
+        enter(c);
+        if (!c) return INFUR_E_INVALID_ARG;
+        if (n_outputs) *n_outputs = 0;
+        if (!c->loaded) return INFUR_OK;  // no session: out untouched, Ok(()) (predict_onnx.rs:318,333)
+        if (!d_bgr) return INFUR_E_INVALID_ARG;
+        if (w == 0 || h == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
+        // checked BEFORE the forward pass: a model without the aux head (or a context with compute_aux = 0) has ONE output
+        if (d_aux && c->info.n_outputs < 2)
+            return fail(c, INFUR_E_INVALID_ARG, "aux output requested but this model/context has one output (infur_model_info.n_outputs)");
+        RETIF(forward(c, (const uint8_t*)d_bgr, (int)w, (int)h));
+        const int K = c->num_classes;
+        const double up_bytes = (double)c->out_low.bytes() + 4.0 * (double)K * h * w;
+        if (d_out) {
+            ProfScope ps(c, "out.resize", "upsample_planar", 0, up_bytes);
+            HIPCHK(c, launch_upsample_planar((const float*)c->out_low.p, c->out_low.h, c->out_low.w, K, (float*)d_out, (int)h, (int)w, c->stream));
+        }
+        if (d_aux) {
+            ProfScope ps(c, "aux.resize", "upsample_planar", 0, up_bytes);
+            HIPCHK(c, launch_upsample_planar((const float*)c->aux_low.p, c->aux_low.h, c->aux_low.w, K, (float*)d_aux, (int)h, (int)w, c->stream));
+        }
+        if (n_outputs) *n_outputs = c->info.n_outputs;
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    if (d_aux) {
-        if (!c->aux_low.p) return fail(c, INFUR_E_INVALID_ARG, "aux output requested but the aux head is disabled");
-        ProfScope ps(c, "aux.resize", "upsample_planar", 0, up_bytes);
-        HIPCHK(c, launch_upsample_planar((const float*)c->aux_low.p, c->aux_low.h, c->aux_low.w, K, (float*)d_aux, (int)h, (int)w, c->stream));
-    }
-    if (n_outputs) *n_outputs = 2;
-    return INFUR_OK;
 }
 
 int32_t infur_model_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float* out, float* aux,
                             uint32_t* n_outputs) {
-    enter(c);
-    if (!c) return INFUR_E_INVALID_ARG;
-    if (n_outputs) *n_outputs = 0;
-    if (!c->loaded) return INFUR_OK;
-    if (!bgr) return INFUR_E_INVALID_ARG;
-    if (w == 0 || h == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
-    const size_t in_bytes = (size_t)w * h * 3, lg = (size_t)c->num_classes * w * h * 4;
-    RETIF(ensure(c, c->st_in, in_bytes));
-    if (out) RETIF(ensure(c, c->st_f32a, lg));
-    if (aux) RETIF(ensure(c, c->st_f32b, lg));
-    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
-    RETIF(infur_model_advance_dev(c, c->st_in.p, w, h, out ? c->st_f32a.p : nullptr, aux ? c->st_f32b.p : nullptr, n_outputs));
-    if (out) HIPCHK(c, hipMemcpyAsync(out, c->st_f32a.p, lg, hipMemcpyDeviceToHost, c->stream));
-    if (aux) HIPCHK(c, hipMemcpyAsync(aux, c->st_f32b.p, lg, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return INFUR_OK;
+    try {
+        enter(c);
+        if (!c) return INFUR_E_INVALID_ARG;
+        if (n_outputs) *n_outputs = 0;
+        if (!c->loaded) return INFUR_OK;
+        if (!bgr) return INFUR_E_INVALID_ARG;
+        if (w == 0 || h == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
+        if (aux && c->info.n_outputs < 2)
+            return fail(c, INFUR_E_INVALID_ARG, "aux output requested but this model/context has one output (infur_model_info.n_outputs)");
+        const size_t in_bytes = (size_t)w * h * 3, lg = (size_t)c->num_classes * w * h * 4;
+        RETIF(ensure(c, c->st_in, in_bytes));
+        if (out) RETIF(ensure(c, c->st_f32a, lg));
+        if (aux) RETIF(ensure(c, c->st_f32b, lg));
+        HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
+        RETIF(infur_model_advance_dev(c, c->st_in.p, w, h, out ? c->st_f32a.p : nullptr, aux ? c->st_f32b.p : nullptr, n_outputs));
+        if (out) HIPCHK(c, hipMemcpyAsync(out, c->st_f32a.p, lg, hipMemcpyDeviceToHost, c->stream));
+        if (aux) HIPCHK(c, hipMemcpyAsync(aux, c->st_f32b.p, lg, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
+}
+
+int32_t infur_model_warmup(infur_ctx* c, uint32_t w, uint32_t h) {
+    try {
+        enter(c);
+        if (!c) return INFUR_E_INVALID_ARG;
+        if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
+        if (w == 0 || h == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
+        const size_t in_bytes = (size_t)w * h * 3;
+        RETIF(ensure(c, c->st_in, in_bytes));
+        HIPCHK(c, hipMemsetAsync(c->st_in.p, 0x55, in_bytes, c->stream));  // any frame will do: timings do not depend on values
+        const uint32_t prof = c->opt.profile;
+        c->opt.profile = 0;
+        const int32_t rc = forward(c, (const uint8_t*)c->st_in.p, (int)w, (int)h);
+        c->opt.profile = prof;
+        RETIF(rc);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 int32_t infur_model_read_lowres(infur_ctx* c, float* out_low, float* aux_low, uint32_t* lh, uint32_t* lw) {
-    enter(c);
-    if (!c) return INFUR_E_INVALID_ARG;
-    if (!c->loaded || !c->out_low.p) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no forward pass has run");
-    const Tensor& t = c->out_low;
-    if (lh) *lh = (uint32_t)t.h;
-    if (lw) *lw = (uint32_t)t.w;
-    const size_t bytes = t.elems() * 4;
-    RETIF(ensure(c, c->st_f32a, bytes));
-    for (int i = 0; i < 2; i++) {
-        float* dst = i == 0 ? out_low : aux_low;
-        const Tensor& src = i == 0 ? c->out_low : c->aux_low;
-        if (!dst) continue;
-        if (!src.p) return fail(c, INFUR_E_INVALID_ARG, "aux output requested but the aux head is disabled");
-        HIPCHK(c, launch_nhwc_to_planar(src.p, src.es == 2, src.h, src.w, src.c, (float*)c->st_f32a.p, c->stream));
-        HIPCHK(c, hipMemcpyAsync(dst, c->st_f32a.p, bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    try {
+        enter(c);
+        if (!c) return INFUR_E_INVALID_ARG;
+        if (!c->loaded || !c->out_low.p) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no forward pass has run");
+        if (aux_low && !c->aux_low.p) return fail(c, INFUR_E_INVALID_ARG, "aux output requested but the aux head is disabled");
+        const Tensor& t = c->out_low;
+        if (lh) *lh = (uint32_t)t.h;
+        if (lw) *lw = (uint32_t)t.w;
+        const size_t bytes = t.elems() * 4;
+        RETIF(ensure(c, c->st_f32a, bytes));
+        for (int i = 0; i < 2; i++) {
+            float* dst = i == 0 ? out_low : aux_low;
+            const Tensor& src = i == 0 ? c->out_low : c->aux_low;
+            if (!dst) continue;
+            HIPCHK(c, launch_nhwc_to_planar(src.p, src.es == 2, src.h, src.w, src.c, (float*)c->st_f32a.p, c->stream));
+            HIPCHK(c, hipMemcpyAsync(dst, c->st_f32a.p, bytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    return INFUR_OK;
 }
 
 int32_t infur_debug_read_activation(infur_ctx* c, uint32_t index, float* host, size_t cap, uint32_t* ch, uint32_t* h,
                                     uint32_t* w) {
-    enter(c);
-    if (!c || !host) return INFUR_E_INVALID_ARG;
-    if (!c->opt.keep_activations) return fail(c, INFUR_E_INVALID_ARG, "context was created without keep_activations");
-    if (index >= c->kept.size()) return fail(c, INFUR_E_INVALID_ARG, "activation %u of %zu", index, c->kept.size());
-    const Tensor& t = c->kept[index];
-    if (ch) *ch = (uint32_t)t.c;
-    if (h) *h = (uint32_t)t.h;
-    if (w) *w = (uint32_t)t.w;
-    if (cap < t.elems()) return fail(c, INFUR_E_CAPACITY, "activation needs %zu floats", t.elems());
-    RETIF(ensure(c, c->st_f32a, t.elems() * 4));
-    HIPCHK(c, launch_nhwc_to_planar(t.p, t.es == 2, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
-    HIPCHK(c, hipMemcpyAsync(host, c->st_f32a.p, t.elems() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return INFUR_OK;
+    try {
+        enter(c);
+        if (!c || !host) return INFUR_E_INVALID_ARG;
+        if (!c->opt.keep_activations) return fail(c, INFUR_E_INVALID_ARG, "context was created without keep_activations");
+        if (index >= c->kept.size()) return fail(c, INFUR_E_INVALID_ARG, "activation %u of %zu", index, c->kept.size());
+        const Tensor& t = c->kept[index];
+        if (ch) *ch = (uint32_t)t.c;
+        if (h) *h = (uint32_t)t.h;
+        if (w) *w = (uint32_t)t.w;
+        if (cap < t.elems()) return fail(c, INFUR_E_CAPACITY, "activation needs %zu floats", t.elems());
+        RETIF(ensure(c, c->st_f32a, t.elems() * 4));
+        HIPCHK(c, launch_nhwc_to_planar(t.p, t.es == 2, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(host, c->st_f32a.p, t.elems() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 // ---- pre-proc alone ----
@@ -1153,18 +1201,24 @@ int32_t infur_pack_normalize_dev(infur_ctx* c, const void* d_bgr, uint32_t w, ui
 }
 
 int32_t infur_pack_normalize(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float* chw) {
-    enter(c);
-    if (!c) return INFUR_E_INVALID_ARG;
-    const size_t npix = (size_t)w * h;
-    if (npix == 0) return INFUR_OK;
-    if (!bgr || !chw) return INFUR_E_INVALID_ARG;
-    RETIF(ensure(c, c->st_in, npix * 3));
-    RETIF(ensure(c, c->st_f32a, npix * 12));
-    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
-    RETIF(infur_pack_normalize_dev(c, c->st_in.p, w, h, c->st_f32a.p));
-    HIPCHK(c, hipMemcpyAsync(chw, c->st_f32a.p, npix * 12, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return INFUR_OK;
+    try {
+        enter(c);
+        if (!c) return INFUR_E_INVALID_ARG;
+        const size_t npix = (size_t)w * h;
+        if (npix == 0) return INFUR_OK;
+        if (!bgr || !chw) return INFUR_E_INVALID_ARG;
+        RETIF(ensure(c, c->st_in, npix * 3));
+        RETIF(ensure(c, c->st_f32a, npix * 12));
+        HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
+        RETIF(infur_pack_normalize_dev(c, c->st_in.p, w, h, c->st_f32a.p));
+        HIPCHK(c, hipMemcpyAsync(chw, c->st_f32a.p, npix * 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 // ---- ColorCode ----
@@ -1179,18 +1233,24 @@ int32_t infur_colorcode_dev(infur_ctx* c, const void* d_khw, uint32_t k, uint32_
 }
 
 int32_t infur_colorcode(infur_ctx* c, const float* khw, uint32_t k, uint32_t h, uint32_t w, uint8_t* rgba) {
-    enter(c);
-    if (!c) return INFUR_E_INVALID_ARG;
-    const size_t hw = (size_t)h * w;
-    if (hw == 0) return INFUR_OK;
-    if (!rgba || (k > 0 && !khw)) return INFUR_E_INVALID_ARG;
-    RETIF(ensure(c, c->st_f32a, hw * (k ? k : 1) * 4));
-    RETIF(ensure(c, c->st_rgba, hw * 4));
-    if (k) HIPCHK(c, hipMemcpyAsync(c->st_f32a.p, khw, hw * k * 4, hipMemcpyHostToDevice, c->stream));
-    RETIF(infur_colorcode_dev(c, c->st_f32a.p, k, h, w, c->st_rgba.p));
-    HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, hw * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return INFUR_OK;
+    try {
+        enter(c);
+        if (!c) return INFUR_E_INVALID_ARG;
+        const size_t hw = (size_t)h * w;
+        if (hw == 0) return INFUR_OK;
+        if (!rgba || (k > 0 && !khw)) return INFUR_E_INVALID_ARG;
+        RETIF(ensure(c, c->st_f32a, hw * (k ? k : 1) * 4));
+        RETIF(ensure(c, c->st_rgba, hw * 4));
+        if (k) HIPCHK(c, hipMemcpyAsync(c->st_f32a.p, khw, hw * k * 4, hipMemcpyHostToDevice, c->stream));
+        RETIF(infur_colorcode_dev(c, c->st_f32a.p, k, h, w, c->st_rgba.p));
+        HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, hw * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 // ---- display conversion ----
@@ -1205,82 +1265,100 @@ int32_t infur_bgr_to_rgba_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint3
 }
 
 int32_t infur_bgr_to_rgba(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, uint8_t* rgba) {
-    enter(c);
-    if (!c) return INFUR_E_INVALID_ARG;
-    const size_t npix = (size_t)w * h;
-    if (npix == 0) return INFUR_OK;
-    if (!bgr || !rgba) return INFUR_E_INVALID_ARG;
-    RETIF(ensure(c, c->st_in, npix * 3));
-    RETIF(ensure(c, c->st_rgba, npix * 4));
-    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
-    RETIF(infur_bgr_to_rgba_dev(c, c->st_in.p, w, h, c->st_rgba.p));
-    HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return INFUR_OK;
+    try {
+        enter(c);
+        if (!c) return INFUR_E_INVALID_ARG;
+        const size_t npix = (size_t)w * h;
+        if (npix == 0) return INFUR_OK;
+        if (!bgr || !rgba) return INFUR_E_INVALID_ARG;
+        RETIF(ensure(c, c->st_in, npix * 3));
+        RETIF(ensure(c, c->st_rgba, npix * 4));
+        HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
+        RETIF(infur_bgr_to_rgba_dev(c, c->st_in.p, w, h, c->st_rgba.p));
+        HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 // ---- fused frame path ----
 int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                                 void* d_rgba, size_t cap, void* d_scaled, uint32_t* ow, uint32_t* oh) {
-    enter(c);
-    if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
-    if (mode > INFUR_SCALE_BILINEAR) return fail(c, INFUR_E_INVALID_ARG, "unknown scale mode %u", mode);
-    int32_t rc = infur_scale_validate(factor);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    rc = infur_scale_out_dims(w, h, factor, ow, oh);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    if (!d_bgr) return INFUR_E_INVALID_ARG;
-    const size_t sbytes = (size_t)*ow * *oh * 3, need = (size_t)*ow * *oh * 4;
-    if (need == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", *ow, *oh);
-    const void* frame = d_bgr;
-    prof_reset(c);
-    std::vector<ProfRec> pre;
-    if (factor != 1.0f || d_scaled) {
-        void* dst = d_scaled;
-        if (!dst) {
-            RETIF(ensure(c, c->st_scaled, sbytes));
-            dst = c->st_scaled.p;
+    try {
+        enter(c);
+        if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
+        if (mode > INFUR_SCALE_BILINEAR) return fail(c, INFUR_E_INVALID_ARG, "unknown scale mode %u", mode);
+        int32_t rc = infur_scale_validate(factor);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        rc = infur_scale_out_dims(w, h, factor, ow, oh);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        if (!d_bgr) return INFUR_E_INVALID_ARG;
+        const size_t sbytes = (size_t)*ow * *oh * 3, need = (size_t)*ow * *oh * 4;
+        if (need == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", *ow, *oh);
+        const void* frame = d_bgr;
+        prof_reset(c);
+        std::vector<ProfRec> pre;
+        if (factor != 1.0f || d_scaled) {
+            void* dst = d_scaled;
+            if (!dst) {
+                RETIF(ensure(c, c->st_scaled, sbytes));
+                dst = c->st_scaled.p;
+            }
+            uint32_t a, b;
+            RETIF(infur_scale_dev(c, d_bgr, w, h, factor, mode, dst, sbytes, &a, &b));
+            frame = dst;
+            pre.swap(c->prof);  // forward() resets the records; keep the scale's
         }
-        uint32_t a, b;
-        RETIF(infur_scale_dev(c, d_bgr, w, h, factor, mode, dst, sbytes, &a, &b));
-        frame = dst;
-        pre.swap(c->prof);  // forward() resets the records; keep the scale's
+        if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");  // app.rs:127-129: mask cleared
+        if (!d_rgba) return INFUR_E_INVALID_ARG;
+        if (cap < need) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", need, cap);
+        RETIF(forward(c, (const uint8_t*)frame, (int)*ow, (int)*oh));
+        c->prof.insert(c->prof.begin(), pre.begin(), pre.end());
+        {
+            const Tensor& t = c->out_low;  // only out[0] is decoded, app.rs:116
+            ProfScope ps(c, "out.resize+colorcode", "upsample_argmax_shade", 0, (double)t.bytes() + (double)need);
+            HIPCHK(c, launch_upsample_argmax_shade((const float*)t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)*oh, (int)*ow, c->stream));
+        }
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");  // app.rs:127-129: mask cleared
-    if (!d_rgba) return INFUR_E_INVALID_ARG;
-    if (cap < need) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", need, cap);
-    RETIF(forward(c, (const uint8_t*)frame, (int)*ow, (int)*oh));
-    c->prof.insert(c->prof.begin(), pre.begin(), pre.end());
-    {
-        const Tensor& t = c->out_low;  // only out[0] is decoded, app.rs:116
-        ProfScope ps(c, "out.resize+colorcode", "upsample_argmax_shade", 0, (double)t.bytes() + (double)need);
-        HIPCHK(c, launch_upsample_argmax_shade((const float*)t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)*oh, (int)*ow, c->stream));
-    }
-    return INFUR_OK;
 }
 
 int32_t infur_frame_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                             uint8_t* rgba, size_t cap, uint8_t* scaled, uint32_t* ow, uint32_t* oh) {
-    enter(c);
-    if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
-    int32_t rc = infur_scale_validate(factor);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    rc = infur_scale_out_dims(w, h, factor, ow, oh);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    if (!bgr) return INFUR_E_INVALID_ARG;
-    const size_t in_bytes = (size_t)w * h * 3, sbytes = (size_t)*ow * *oh * 3, need = (size_t)*ow * *oh * 4;
-    if (rgba && cap < need) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", need, cap);
-    RETIF(ensure(c, c->st_in, in_bytes ? in_bytes : 1));
-    RETIF(ensure(c, c->st_rgba, need ? need : 1));
-    RETIF(ensure(c, c->st_scaled, sbytes ? sbytes : 1));
-    HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
-    rc = infur_frame_advance_dev(c, c->st_in.p, w, h, factor, mode, c->st_rgba.p, c->st_rgba.bytes,
-                                 (scaled || factor != 1.0f) ? c->st_scaled.p : nullptr, ow, oh);
-    if (rc != INFUR_OK && rc != INFUR_E_MODEL_NOT_LOADED) return rc;
-    if (scaled) HIPCHK(c, hipMemcpyAsync(scaled, c->st_scaled.p, sbytes, hipMemcpyDeviceToHost, c->stream));
-    if (rc == INFUR_OK && rgba) HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, need, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return rc;
+    try {
+        enter(c);
+        if (!c || !ow || !oh) return INFUR_E_INVALID_ARG;
+        int32_t rc = infur_scale_validate(factor);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        rc = infur_scale_out_dims(w, h, factor, ow, oh);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        if (!bgr) return INFUR_E_INVALID_ARG;
+        const size_t in_bytes = (size_t)w * h * 3, sbytes = (size_t)*ow * *oh * 3, need = (size_t)*ow * *oh * 4;
+        if (rgba && cap < need) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", need, cap);
+        RETIF(ensure(c, c->st_in, in_bytes ? in_bytes : 1));
+        RETIF(ensure(c, c->st_rgba, need ? need : 1));
+        RETIF(ensure(c, c->st_scaled, sbytes ? sbytes : 1));
+        HIPCHK(c, hipMemcpyAsync(c->st_in.p, bgr, in_bytes, hipMemcpyHostToDevice, c->stream));
+        rc = infur_frame_advance_dev(c, c->st_in.p, w, h, factor, mode, c->st_rgba.p, c->st_rgba.bytes,
+                                     (scaled || factor != 1.0f) ? c->st_scaled.p : nullptr, ow, oh);
+        if (rc != INFUR_OK && rc != INFUR_E_MODEL_NOT_LOADED) return rc;
+        if (scaled) HIPCHK(c, hipMemcpyAsync(scaled, c->st_scaled.p, sbytes, hipMemcpyDeviceToHost, c->stream));
+        if (rc == INFUR_OK && rgba) HIPCHK(c, hipMemcpyAsync(rgba, c->st_rgba.p, need, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 // ---- streaming ----
@@ -1327,33 +1405,11 @@ int32_t slot_reserve(infur_ctx* c, infur_stream::Slot& sl, size_t in_bytes, size
 }
 }  // namespace
 
-extern "C" {
-
-int32_t infur_stream_create(infur_ctx* c, uint32_t depth, infur_stream** out) {
+static void stream_orphan(infur_stream* st) {
+    infur_ctx* c = st->ctx;
+    if (!c) return;
     enter(c);
-    if (!c || !out || depth == 0 || depth > 64) return INFUR_E_INVALID_ARG;
-    *out = nullptr;
-    infur_stream* st = new infur_stream();
-    st->ctx = c;
-    st->slots.resize(depth);
-    bool ok = hipStreamCreateWithFlags(&st->s_h2d, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&st->s_d2h, hipStreamNonBlocking) == hipSuccess;
-    for (auto& sl : st->slots)
-        ok = ok && hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        infur_stream_destroy(st);
-        return fail(c, INFUR_E_HIP, "could not create the streaming ring");
-    }
-    *out = st;
-    return INFUR_OK;
-}
-
-void infur_stream_destroy(infur_stream* st) {
-    if (st) enter(st->ctx);
-    if (!st) return;
-    if (st->ctx && st->ctx->stream) (void)hipStreamSynchronize(st->ctx->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (st->s_h2d) (void)hipStreamSynchronize(st->s_h2d);
     if (st->s_d2h) (void)hipStreamSynchronize(st->s_d2h);
     for (auto& sl : st->slots) {
@@ -1364,8 +1420,52 @@ void infur_stream_destroy(infur_stream* st) {
         for (hipEvent_t e : {sl.ev_h2d, sl.ev_comp, sl.ev_done})
             if (e) (void)hipEventDestroy(e);
     }
+    st->slots.clear();
     if (st->s_h2d) (void)hipStreamDestroy(st->s_h2d);
     if (st->s_d2h) (void)hipStreamDestroy(st->s_d2h);
+    st->s_h2d = st->s_d2h = nullptr;
+    st->head = st->tail = 0;
+    for (size_t i = 0; i < c->streams.size(); i++)
+        if (c->streams[i] == st) {
+            c->streams.erase(c->streams.begin() + (long)i);
+            break;
+        }
+    st->ctx = nullptr;
+}
+
+extern "C" {
+
+int32_t infur_stream_create(infur_ctx* c, uint32_t depth, infur_stream** out) {
+    try {
+        enter(c);
+        if (!c || !out || depth == 0 || depth > 64) return INFUR_E_INVALID_ARG;
+        *out = nullptr;
+        infur_stream* st = new infur_stream();
+        st->ctx = c;
+        c->streams.push_back(st);
+        st->slots.resize(depth);
+        bool ok = hipStreamCreateWithFlags(&st->s_h2d, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&st->s_d2h, hipStreamNonBlocking) == hipSuccess;
+        for (auto& sl : st->slots)
+            ok = ok && hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            infur_stream_destroy(st);
+            return fail(c, INFUR_E_HIP, "could not create the streaming ring");
+        }
+        *out = st;
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
+}
+
+void infur_stream_destroy(infur_stream* st) {
+    if (!st) return;
+    stream_orphan(st);  // no-op when the context went first
     delete st;
 }
 
@@ -1373,46 +1473,51 @@ uint32_t infur_stream_pending(const infur_stream* st) { return st ? (uint32_t)(s
 
 int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                             uint64_t frame_id) {
-    if (st) enter(st->ctx);
-    if (!st || !bgr) return INFUR_E_INVALID_ARG;
-    infur_ctx* c = st->ctx;
-    int32_t rc = infur_scale_validate(factor);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    uint32_t ow = 0, oh = 0;
-    rc = infur_scale_out_dims(w, h, factor, &ow, &oh);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
-    const size_t depth = st->slots.size();
-    if (st->head - st->tail >= depth)
-        return fail(c, INFUR_E_CAPACITY, "all %zu slots are in flight: collect before submitting more", depth);
-    infur_stream::Slot& sl = st->slots[st->head % depth];
-    const size_t in_bytes = (size_t)w * h * 3, rgba_bytes = (size_t)ow * oh * 4, sc_bytes = (size_t)ow * oh * 3;
-    if (in_bytes == 0 || rgba_bytes == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
-    RETIF(slot_reserve(c, sl, in_bytes, rgba_bytes + sc_bytes));
-    memcpy(sl.h_in, bgr, in_bytes);  // the caller's buffer is free again when submit returns
-    sl.id = frame_id;
-    sl.ow = ow;
-    sl.oh = oh;
-    HIPCHK(c, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
-    HIPCHK(c, hipEventRecord(sl.ev_h2d, st->s_h2d));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_h2d, 0));
-    uint8_t* d_rgba = (uint8_t*)sl.d_out;
-    uint8_t* d_sc = d_rgba + rgba_bytes;
-    uint32_t a = 0, b = 0;
-    sl.status = infur_frame_advance_dev(c, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
-    if (sl.status != INFUR_OK) return sl.status;
-    HIPCHK(c, hipEventRecord(sl.ev_comp, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
-    HIPCHK(c, hipMemcpyAsync(sl.h_out, sl.d_out, rgba_bytes + sc_bytes, hipMemcpyDeviceToHost, st->s_d2h));
-    HIPCHK(c, hipEventRecord(sl.ev_done, st->s_d2h));
-    sl.busy = true;
-    st->head++;
-    return INFUR_OK;
+    try {
+        if (!st || !st->ctx || !bgr) return INFUR_E_INVALID_ARG;  // (a stream whose context was destroyed is dead)
+        enter(st->ctx);
+        infur_ctx* c = st->ctx;
+        int32_t rc = infur_scale_validate(factor);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        uint32_t ow = 0, oh = 0;
+        rc = infur_scale_out_dims(w, h, factor, &ow, &oh);
+        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+        if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
+        const size_t depth = st->slots.size();
+        if (st->head - st->tail >= depth)
+            return fail(c, INFUR_E_CAPACITY, "all %zu slots are in flight: collect before submitting more", depth);
+        infur_stream::Slot& sl = st->slots[st->head % depth];
+        const size_t in_bytes = (size_t)w * h * 3, rgba_bytes = (size_t)ow * oh * 4, sc_bytes = (size_t)ow * oh * 3;
+        if (in_bytes == 0 || rgba_bytes == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
+        RETIF(slot_reserve(c, sl, in_bytes, rgba_bytes + sc_bytes));
+        memcpy(sl.h_in, bgr, in_bytes);  // the caller's buffer is free again when submit returns
+        sl.id = frame_id;
+        sl.ow = ow;
+        sl.oh = oh;
+        HIPCHK(c, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
+        HIPCHK(c, hipEventRecord(sl.ev_h2d, st->s_h2d));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_h2d, 0));
+        uint8_t* d_rgba = (uint8_t*)sl.d_out;
+        uint8_t* d_sc = d_rgba + rgba_bytes;
+        uint32_t a = 0, b = 0;
+        sl.status = infur_frame_advance_dev(c, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
+        if (sl.status != INFUR_OK) return sl.status;
+        HIPCHK(c, hipEventRecord(sl.ev_comp, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
+        HIPCHK(c, hipMemcpyAsync(sl.h_out, sl.d_out, rgba_bytes + sc_bytes, hipMemcpyDeviceToHost, st->s_d2h));
+        HIPCHK(c, hipEventRecord(sl.ev_done, st->s_d2h));
+        sl.busy = true;
+        st->head++;
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(st ? st->ctx : nullptr, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(st ? st->ctx : nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
 }
 
 int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint32_t* ow, uint32_t* oh) {
-    if (st) enter(st->ctx);
-    if (!st || st->head == st->tail) return INFUR_E_INVALID_ARG;
+    if (!st || !st->ctx || st->head == st->tail) return INFUR_E_INVALID_ARG;
     const infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
     if (frame_id) *frame_id = sl.id;
     if (ow) *ow = sl.ow;
@@ -1422,8 +1527,8 @@ int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint3
 
 int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t cap, uint8_t* scaled, uint64_t* frame_id,
                              uint32_t* ow, uint32_t* oh) {
-    if (st) enter(st->ctx);
-    if (!st) return INFUR_E_INVALID_ARG;
+    if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
+    enter(st->ctx);
     infur_ctx* c = st->ctx;
     if (st->head == st->tail) return fail(c, INFUR_E_INVALID_ARG, "no frame is pending");
     infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
@@ -1444,35 +1549,41 @@ int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t cap, uint8_
 int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const uint32_t* ws, const uint32_t* hs, uint32_t n,
                             float factor, uint32_t mode, uint8_t* const* rgba, const size_t* caps, uint32_t* ows,
                             uint32_t* ohs) {
-    enter(c);
-    if (!c || (n && (!frames || !ws || !hs || !rgba || !caps))) return INFUR_E_INVALID_ARG;
-    if (n == 0) return INFUR_OK;
-    infur_stream* st = nullptr;
-    RETIF(infur_stream_create(c, 3, &st));
-    int32_t rc = INFUR_OK;
-    uint32_t done = 0;
-    auto collect_one = [&]() -> int32_t {
-        uint64_t id = 0;
-        uint32_t ow = 0, oh = 0;
-        int32_t r = infur_stream_next_dims(st, &id, &ow, &oh);
-        if (r != INFUR_OK) return r;
-        r = infur_stream_collect(st, rgba[id], caps[id], nullptr, &id, &ow, &oh);
-        if (r == INFUR_OK) {
-            if (ows) ows[id] = ow;
-            if (ohs) ohs[id] = oh;
-            done++;
+    try {
+        enter(c);
+        if (!c || (n && (!frames || !ws || !hs || !rgba || !caps))) return INFUR_E_INVALID_ARG;
+        if (n == 0) return INFUR_OK;
+        infur_stream* st = nullptr;
+        RETIF(infur_stream_create(c, 3, &st));
+        int32_t rc = INFUR_OK;
+        uint32_t done = 0;
+        auto collect_one = [&]() -> int32_t {
+            uint64_t id = 0;
+            uint32_t ow = 0, oh = 0;
+            int32_t r = infur_stream_next_dims(st, &id, &ow, &oh);
+            if (r != INFUR_OK) return r;
+            r = infur_stream_collect(st, rgba[id], caps[id], nullptr, &id, &ow, &oh);
+            if (r == INFUR_OK) {
+                if (ows) ows[id] = ow;
+                if (ohs) ohs[id] = oh;
+                done++;
+            }
+            return r;
+        };
+        for (uint32_t i = 0; i < n && rc == INFUR_OK; i++) {
+            if (infur_stream_pending(st) >= 3) rc = collect_one();
+            if (rc == INFUR_OK) rc = infur_stream_submit(st, frames[i], ws[i], hs[i], factor, mode, i);
         }
-        return r;
-    };
-    for (uint32_t i = 0; i < n && rc == INFUR_OK; i++) {
-        if (infur_stream_pending(st) >= 3) rc = collect_one();
-        if (rc == INFUR_OK) rc = infur_stream_submit(st, frames[i], ws[i], hs[i], factor, mode, i);
+        while (rc == INFUR_OK && infur_stream_pending(st) > 0) rc = collect_one();
+        const std::string keep = c->err;  // destroy() synchronises and must not lose the message
+        infur_stream_destroy(st);
+        c->err = keep;
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    while (rc == INFUR_OK && infur_stream_pending(st) > 0) rc = collect_one();
-    const std::string keep = c->err;  // destroy() synchronises and must not lose the message
-    infur_stream_destroy(st);
-    c->err = keep;
-    return rc;
 }
 
 // ---- range monitor of the split mode ----
@@ -1493,46 +1604,58 @@ int32_t infur_split_range(infur_ctx* c, float* act_amax, float* wino_amax, uint3
 
 // ---- tuning database ----
 int32_t infur_tune_export(infur_ctx* c, char* buf, size_t cap, size_t* len) {
-    enter(c);
-    if (!c || !len) return INFUR_E_INVALID_ARG;
-    std::string out;
-    char line[256];
-    for (const auto& kv : c->tuned) {
-        int n = 0;
-        for (int v : kv.first) n += snprintf(line + n, sizeof line - n, "%d ", v);
-        snprintf(line + n, sizeof line - n, "%d\n", kv.second);
-        out += line;
+    try {
+        enter(c);
+        if (!c || !len) return INFUR_E_INVALID_ARG;
+        std::string out;
+        char line[256];
+        for (const auto& kv : c->tuned) {
+            int n = 0;
+            for (int v : kv.first) n += snprintf(line + n, sizeof line - n, "%d ", v);
+            snprintf(line + n, sizeof line - n, "%d\n", kv.second);
+            out += line;
+        }
+        *len = out.size();
+        if (!buf) return INFUR_OK;
+        if (cap < out.size()) return fail(c, INFUR_E_CAPACITY, "tuning text needs %zu bytes", out.size());
+        memcpy(buf, out.data(), out.size());
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    *len = out.size();
-    if (!buf) return INFUR_OK;
-    if (cap < out.size()) return fail(c, INFUR_E_CAPACITY, "tuning text needs %zu bytes", out.size());
-    memcpy(buf, out.data(), out.size());
-    return INFUR_OK;
 }
 
 int32_t infur_tune_import(infur_ctx* c, const char* text, size_t len) {
-    enter(c);
-    if (!c || (!text && len)) return INFUR_E_INVALID_ARG;
-    std::string t(text ? text : "", len);
-    size_t pos = 0;
-    while (pos < t.size()) {
-        size_t eol = t.find('\n', pos);
-        if (eol == std::string::npos) eol = t.size();
-        const std::string ln = t.substr(pos, eol - pos);
-        pos = eol + 1;
-        if (ln.empty() || ln[0] == '#') continue;
-        std::array<int, 13> key;
-        int cfg = -1, off = 0, n = 0;
-        bool ok = true;
-        for (int i = 0; i < 13 && ok; i++) {
-            ok = sscanf(ln.c_str() + off, "%d%n", &key[i], &n) == 1;
-            off += n;
+    try {
+        enter(c);
+        if (!c || (!text && len)) return INFUR_E_INVALID_ARG;
+        std::string t(text ? text : "", len);
+        size_t pos = 0;
+        while (pos < t.size()) {
+            size_t eol = t.find('\n', pos);
+            if (eol == std::string::npos) eol = t.size();
+            const std::string ln = t.substr(pos, eol - pos);
+            pos = eol + 1;
+            if (ln.empty() || ln[0] == '#') continue;
+            std::array<int, 13> key;
+            int cfg = -1, off = 0, n = 0;
+            bool ok = true;
+            for (int i = 0; i < 13 && ok; i++) {
+                ok = sscanf(ln.c_str() + off, "%d%n", &key[i], &n) == 1;
+                off += n;
+            }
+            ok = ok && sscanf(ln.c_str() + off, "%d", &cfg) == 1;
+            if (!ok || cfg < 0 || cfg >= conv_igemm_num_configs()) return fail(c, INFUR_E_INVALID_ARG, "bad tuning line: %s", ln.c_str());
+            c->tuned[key] = cfg;
         }
-        ok = ok && sscanf(ln.c_str() + off, "%d", &cfg) == 1;
-        if (!ok || cfg < 0 || cfg >= conv_igemm_num_configs()) return fail(c, INFUR_E_INVALID_ARG, "bad tuning line: %s", ln.c_str());
-        c->tuned[key] = cfg;
+        return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(c, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
-    return INFUR_OK;
 }
 
 // ---- profiling ----
@@ -1597,6 +1720,20 @@ int32_t infur_memcpy_d2h(infur_ctx* c, void* d, const void* s, size_t n) {
 }
 
 }  // extern "C"
+
+namespace infur {
+int32_t ctx_fail(infur_ctx* c, int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+void ctx_enter(const infur_ctx* c) { enter(c); }
+void ctx_model_free(infur_ctx* c) { model_free(c); }
+}  // namespace infur
 
 #ifdef KTRACE
 namespace infur { hipError_t ktrace_read(unsigned long long* out); }

@@ -1,0 +1,115 @@
+// infur_ctx.h -- the context object behind the C ABI, shared by the host runtime files (infur_capi.cpp: single
+// context entry points; infur_multi.cpp: groups of contexts, RCCL).  Internal: not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/infur_hip.h"
+
+struct infur_stream;
+
+namespace infur {
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool used = false;
+    uint64_t last_use = 0;  // forward() number that last acquired it (pool trimming)
+};
+
+struct Tensor {  // NHWC activation (f32 or f16) living in the pool
+    void* p = nullptr;
+    int h = 0, w = 0, c = 0;
+    int slot = -1;
+    int es = 4;  // element size: 4 = f32, 2 = f16
+    size_t elems() const { return (size_t)h * w * c; }
+    size_t bytes() const { return elems() * (size_t)es; }
+};
+
+struct ConvLayer {
+    std::string name;
+    int cout = 0, cin = 0, k = 0, stride = 1, pad = 0, dil = 1;
+    bool relu = false;
+    char role = 0;        // s stem, 1 2 3 block convs, d downsample, h head3x3, c classifier
+    void* d_w = nullptr;   // repacked weights (context dtype; the stem's stay f32)
+    float* d_b = nullptr;  // bias, always f32
+    float* d_u = nullptr;  // Winograd-domain weights U[16][cout][cin] (f32 stride-1 3x3 convs only)
+    // INFUR_DTYPE_F32_SPLIT: d_w / d_u hold f16 (hi, lo) pairs of w * w_scale / u * u_scale (powers of two)
+    float w_scale = 1.0f, u_scale = 1.0f;
+    // conv3 of a stage's first block: its weights and the downsample branch's side by side ([cout][cin + ds.cin],
+    // context dtype), the two biases summed -- the two-source GEMM of run_conv_dual
+    void* d_wcat = nullptr;
+    float* d_bcat = nullptr;
+    float wcat_scale = 1.0f;
+};
+
+struct ProfRec {
+    std::string name;
+    const char* kernel;
+    double flops, bytes, algo_flops;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace infur
+
+struct infur_ctx {
+    infur_options opt{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // lookup tables
+    float* d_pre_lut = nullptr;     // [3][256] f32, RGB order
+    uint32_t* d_color_lut = nullptr;  // [20][256] premultiplied RGBA
+
+    // model
+    bool loaded = false;
+    infur_model_info info{};
+    int depth = 0, num_classes = 0;
+    bool has_aux = false;
+    std::vector<infur::ConvLayer> convs;
+    void* d_weights = nullptr;  // single allocation holding every repacked tensor
+    size_t weight_bytes = 0;
+
+    // activation pool + results of the last forward
+    std::vector<infur::Buf> pool;
+    infur::Tensor out_low, aux_low;  // NHWC [lh][lw][K]
+    int last_h = 0, last_w = 0;
+    uint64_t frame_no = 0;   // forward() calls so far
+    uint32_t same_size = 0;  // consecutive forwards at last_h x last_w
+    // live infur_stream objects of this context: infur_ctx_destroy releases their device resources and
+    // orphans them, so destroying context and streams in either order is safe
+    std::vector<infur_stream*> streams;
+    std::vector<infur::Tensor> kept;  // keep_activations: output of every conv
+
+    // staging for the host-pointer entry points
+    infur::Buf st_in, st_scaled, st_rgba, st_f32a, st_f32b;
+
+    // profiling
+    std::vector<infur::ProfRec> prof;
+    std::vector<hipEvent_t> ev_free;
+
+    // measured tile configuration per conv shape (see pick_cfg)
+    std::map<std::array<int, 13>, int> tuned;
+    bool tune_warm = false;
+
+    // INFUR_DTYPE_F32_SPLIT range monitor: [0] max |activation| fed to a GEMM, [1] max |Winograd-domain input|
+    // of the last forward (bit patterns of non-negative floats, atomicMax targets); infur_split_range
+    unsigned* d_range = nullptr;
+};
+
+
+namespace infur {
+// records the message on the context and returns `code`
+int32_t ctx_fail(infur_ctx* c, int32_t code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+// every entry point runs on its context's device (hipMalloc / launches follow the calling thread's current device)
+void ctx_enter(const infur_ctx* c);
+// releases the context's weights and marks it unloaded
+void ctx_model_free(infur_ctx* c);
+}  // namespace infur

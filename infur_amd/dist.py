@@ -61,14 +61,38 @@ def broadcast_blob(blob: Optional[bytes], device=None, src: int = 0):
 
 def load_model_everywhere(ctx, blob: Optional[bytes], src: int = 0, coll_device: Optional[str] = None):
     """Broadcast + per-rank load.  ``ctx``: infur_amd.processors.Context on this rank's GPU.
-    ``coll_device``: where the collective runs (default: this rank's GPU, i.e. RCCL)."""
+    ``coll_device``: where the collective runs (default: this rank's GPU, i.e. RCCL).
+    -> (blob bytes, milliseconds spent in the collective alone; 0.0 without a process group)."""
+    import time
+
     import torch
+    import torch.distributed as dist
 
     gpu = f"cuda:{ctx.device}"
-    t = broadcast_blob(blob, device=coll_device or gpu, src=src).to(gpu)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    bcast_ms = 0.0
+    if not multi:
+        t = broadcast_blob(blob, device=gpu, src=src)
+    else:
+        dev = torch.device(coll_device or gpu)
+        rank = dist.get_rank()
+        n = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=dev)
+        dist.broadcast(n, src=src)
+        # the payload is staged where the collective runs BEFORE the clock starts: bcast_ms is the broadcast alone
+        if rank == src:
+            t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        else:
+            t = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(t, src=src)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    t = t.to(gpu)
     torch.cuda.synchronize()
     ctx.check(ctx.L.infur_model_load_blob_dev(ctx.h, t.data_ptr(), t.numel()))
-    return t.numel()
+    return t.numel(), bcast_ms
 
 
 def gather_masks(local: List[np.ndarray], n_items: int):

@@ -319,30 +319,39 @@ class Model(Processor):
                          mi.weight_bytes)
 
     def advance(self, img: np.ndarray, out: list) -> None:
-        """Fills ``out`` with [out, aux], each [num_classes, h, w] f32; untouched when no model is loaded."""
+        """Fills ``out`` with the model's outputs, each [num_classes, h, w] f32 -- [out, aux], or [out] alone for a
+        model without the aux head / a context created with ``compute_aux=False`` (``get_info().output_names``);
+        untouched when no model is loaded."""
         info = self.get_info()
         if info is None:
             return  # Ok(()) with `out` untouched (predict_onnx.rs:318,333)
         img = _check_bgr(img)
         h, w = img.shape[:2]
         k = info.num_classes
-        o = np.empty((k, h, w), np.float32)
-        a = np.empty((k, h, w), np.float32)
+        bufs = [np.empty((k, h, w), np.float32) for _ in info.output_names]
         n = C.c_uint32(0)
-        rc = self.ctx.L.infur_model_advance(self.ctx.h, img.ctypes.data, w, h, o.ctypes.data, a.ctypes.data, C.byref(n))
+        rc = self.ctx.L.infur_model_advance(self.ctx.h, img.ctypes.data, w, h, bufs[0].ctypes.data,
+                                            bufs[1].ctypes.data if len(bufs) > 1 else None, C.byref(n))
         self.ctx.check(rc, ModelProcError)
+        assert n.value == len(bufs)
         out.clear()  # predict_onnx.rs:326
-        out.extend([o, a])
+        out.extend(bufs)
+
+    def warmup(self, w: int, h: int) -> None:
+        """Allocate the arena and pick tile configurations for w x h frames before the first real one."""
+        self.ctx.check(self.ctx.L.infur_model_warmup(self.ctx.h, w, h), ModelProcError)
 
     def lowres(self):
-        """Output-stride-8 logits of the last advance: (out_low, aux_low) [K, lh, lw] f32."""
+        """Output-stride-8 logits of the last advance: (out_low, aux_low) [K, lh, lw] f32; aux_low is None for a
+        one-output model."""
         info = self.get_info()
         L, h = self.ctx.L, self.ctx.h
         lh, lw = C.c_uint32(0), C.c_uint32(0)
         self.ctx.check(L.infur_model_read_lowres(h, None, None, C.byref(lh), C.byref(lw)))
         o = np.empty((info.num_classes, lh.value, lw.value), np.float32)
-        a = np.empty_like(o)
-        self.ctx.check(L.infur_model_read_lowres(h, o.ctypes.data, a.ctypes.data, C.byref(lh), C.byref(lw)))
+        a = np.empty_like(o) if len(info.output_names) > 1 else None
+        self.ctx.check(L.infur_model_read_lowres(h, o.ctypes.data, a.ctypes.data if a is not None else None,
+                                                 C.byref(lh), C.byref(lw)))
         return o, a
 
 
@@ -445,3 +454,75 @@ class FramePath:
                                                 d_rgba, rgba_capacity, d_scaled or None, C.byref(ow), C.byref(oh))
         self.ctx.check(rc)
         return ow.value, oh.value
+
+
+# --------------------------------------------------------------------------- #
+# several GPUs from one process (include/infur_hip.h: infur_group_*)
+# --------------------------------------------------------------------------- #
+class Group:
+    """``infur_group``: n contexts (one per GPU) driven together from one host process -- one worker thread per
+    context, RCCL weight broadcast over xGMI, contiguous frame slices with no data-path collective
+    (BASELINE configs[3]).  The reference runs all processors on one thread of one process
+    (infur/src/main.rs:38-40); this is how that host reaches 8 GPUs."""
+
+    def __init__(self, ctxs: List[Context]):
+        if not ctxs:
+            raise ValueError("a group needs at least one context")
+        self.ctxs = list(ctxs)
+        self.L = ctxs[0].L
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        g = C.c_void_p(None)
+        rc = self.L.infur_group_create(arr, len(ctxs), C.byref(g))
+        if rc != _lib.OK:
+            raise InfurError(rc, ctxs[0].last_error())
+        self.g = g
+
+    def check(self, rc: int):
+        if rc != _lib.OK:
+            raise InfurError(rc, self.L.infur_group_last_error(self.g).decode() or _lib.status_string(rc))
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self.L.infur_group_uses_rccl(self.g))
+
+    def __len__(self):
+        return self.L.infur_group_size(self.g)
+
+    def weights_broadcast(self, root: int = 0) -> None:
+        self.check(self.L.infur_group_weights_broadcast(self.g, root))
+
+    def advance_batch(self, imgs, factor: float = 1.0, scale_mode: int = _lib.SCALE_NEAREST):
+        imgs = [_check_bgr(i) for i in imgs]
+        n = len(imgs)
+        f = float(np.float32(factor))
+        outs = []
+        for im in imgs:
+            ow, oh = C.c_uint32(0), C.c_uint32(0)
+            rc = self.L.infur_scale_out_dims(im.shape[1], im.shape[0], f, C.byref(ow), C.byref(oh))
+            if rc:
+                raise ScaleProcError(rc)
+            outs.append(np.empty((oh.value, ow.value, 4), np.uint8))
+        fp = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ws = (C.c_uint32 * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_uint32 * n)(*[im.shape[0] for im in imgs])
+        caps = (C.c_size_t * n)(*[o.nbytes for o in outs])
+        self.check(self.L.infur_group_batch_advance(self.g, fp, ws, hs, n, f, scale_mode, op, caps, None, None))
+        return outs
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.infur_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

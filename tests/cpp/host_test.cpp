@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "infur_processor.hpp"
 
@@ -98,6 +99,67 @@ static int gpu_tests(const char* blob_path) {
             for (float v : t.data) CHECK(std::isfinite(v));
         }
         CHECK(m.control_load("") == INFUR_OK && !m.get_info());  // Load("") unloads
+    }
+    // a context that does not evaluate the aux head has ONE output (the Vec the reference would return has length 1)
+    {
+        infur::Context c1(0, /*compute_aux=*/false);
+        CHECK(c1.ok());
+        infur::Model m(c1);
+        CHECK(m.control_load(blob_path) == INFUR_OK);
+        auto info = m.get_info();
+        CHECK(info && info->output_names.size() == 1 && info->output_names[0] == "out");
+        std::vector<infur::Tensor3> out;
+        CHECK(m.advance(infur::BgrImage(96, 64), out) == INFUR_OK && out.size() == 1 && out[0].k == 21 && out[0].h == 64);
+        std::vector<float> aux((size_t)21 * 64 * 96);
+        infur::BgrImage img(96, 64);
+        uint32_t n = 9;
+        CHECK(infur_model_advance(c1.get(), img.data.data(), 96, 64, nullptr, aux.data(), &n) == INFUR_E_INVALID_ARG);
+        // a failed reload keeps the loaded model (Model::control leaves the session on error, predict_onnx.rs:288-309)
+        CHECK(m.control_load("/nonexistent/file") == INFUR_E_IO && m.get_info());
+        const char junk[64] = "INFURW01 but not really";
+        CHECK(m.control_load_blob(junk, sizeof junk) == INFUR_E_MODEL_FORMAT && m.get_info());
+        CHECK(m.advance(img, out) == INFUR_OK && out.size() == 1);
+    }
+    // several contexts from one process: weights replicated by infur_group_weights_broadcast, frames sharded by
+    // infur_group_batch_advance; masks identical to a single context's, in frame order.  On a 1-GPU box both
+    // contexts sit on device 0 (device-to-device copy; INFUR_FORCE_RCCL=1 routes it through a one-rank communicator)
+    {
+        const int ndev = infur_device_count();
+        infur::Context a(0), b(ndev > 1 ? 1 : 0);
+        CHECK(a.ok() && b.ok());
+        infur::Model ma(a), mb(b);
+        CHECK(ma.control_load(blob_path) == INFUR_OK && !mb.get_info());
+        infur::Group solo({&a});
+        CHECK(solo.ok() && infur_group_size(solo.get()) == 1);
+        CHECK(solo.weights_broadcast(0) == INFUR_OK);  // n_ctx = 1: nothing to do
+        std::vector<infur::BgrImage> frames;
+        for (int i = 0; i < 5; i++) {
+            infur::BgrImage f(160, 96 + 16 * (i % 2));  // ragged batch: two frame sizes
+            for (size_t j = 0; j < f.data.size(); j++) f.data[j] = (uint8_t)((j * 7 + i * 53) ^ (j >> 9));
+            frames.push_back(std::move(f));
+        }
+        std::vector<infur::ColorImage> ref, got;
+        CHECK(solo.batch_advance(frames, 0.5f, ref) == INFUR_OK);
+        infur::Group pair({&a, &b});
+        CHECK(pair.ok() && infur_group_size(pair.get()) == 2);
+        CHECK(pair.weights_broadcast(1) == INFUR_E_MODEL_NOT_LOADED);  // context 1 has nothing to send yet
+        CHECK(pair.weights_broadcast(0) == INFUR_OK);
+        auto ib = mb.get_info();
+        CHECK(ib && ib->output_names.size() == 2);
+        CHECK(pair.batch_advance(frames, 0.5f, got) == INFUR_OK);
+        CHECK(got.size() == ref.size());
+        for (size_t i = 0; i < ref.size(); i++) {
+            CHECK(got[i].width == 80 && got[i].height == ref[i].height && got[i].rgba == ref[i].rgba);
+        }
+        // the one-shot forms named in SURVEY 8b
+        infur_ctx* raw[2] = {a.get(), b.get()};
+        CHECK(infur_weights_broadcast(raw, 2) == INFUR_OK);
+        std::vector<infur::ColorImage> again;
+        CHECK(pair.batch_advance(frames, 0.5f, again) == INFUR_OK && again[4].rgba == ref[4].rgba);
+        // fewer frames than contexts: the empty slice is skipped
+        std::vector<infur::BgrImage> one(frames.begin(), frames.begin() + 1);
+        CHECK(pair.batch_advance(one, 0.5f, again) == INFUR_OK && again.size() == 1 && again[0].rgba == ref[0].rgba);
+        std::printf("group ok (rccl %u)\n", infur_group_uses_rccl(pair.get()));
     }
     std::printf("gpu ok\n");
     return 0;

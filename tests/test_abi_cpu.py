@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound(lib):
         assert hasattr(lib, s), f"{s} declared in include/infur_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.infur_abi_version() == 1
+    assert lib.infur_abi_version() == _lib.ABI_VERSION
 
 
 def test_struct_sizes_match_header(lib):

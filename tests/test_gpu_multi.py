@@ -1,0 +1,233 @@
+"""GPU tests of the round-2 host layer: one-output models, failed reloads, stream lifetime, warm-up, and the
+multi-GPU group (RCCL weight broadcast + frame-batch sharding) exercised on ONE device -- two contexts on
+device 0, directly and through a one-rank RCCL communicator -- plus bench.py's self-launched N = 2 run."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from infur_amd import _lib
+from infur_amd import weights as W
+from infur_amd.app import StreamPath
+from infur_amd.processors import Context, FramePath, Group, InfurError, Model, ModelCmd, ModelCmdError, ModelProcError
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- one-output models
+def test_compute_aux_off_has_one_output(blob50, oracle_model):
+    """Context(compute_aux=False): ModelInfo lists one output, Model.advance returns a 1-element list -- what the
+    reference's `Vec<ArrayD<f32>>` would hold for a one-output model (predict_onnx.rs:326-330) -- and `out` is
+    unchanged by skipping the aux head."""
+    fr = W.synth_frame(64, 96, index=3)
+    with Context(device=0, compute_aux=False) as c1, Context(device=0) as c2:
+        m1, m2 = Model(c1).control(ModelCmd.LoadBlob(blob50)), Model(c2).control(ModelCmd.LoadBlob(blob50))
+        assert m1.get_info().output_names == ["out"] and m2.get_info().output_names == ["out", "aux"]
+        o1, o2 = [], []
+        m1.advance(fr, o1)
+        m2.advance(fr, o2)
+        assert len(o1) == 1 and len(o2) == 2 and o1[0].shape == (21, 64, 96)
+        assert (o1[0].view(np.uint32) == o2[0].view(np.uint32)).all()
+        lo, la = m1.lowres()
+        assert la is None and lo.shape[0] == 21
+        # asking the C ABI for aux on a one-output context fails up front
+        aux = np.empty((21, 64, 96), np.float32)
+        n = C.c_uint32(7)
+        rc = c1.L.infur_model_advance(c1.h, fr.ctypes.data, 96, 64, None, aux.ctypes.data, C.byref(n))
+        assert rc == _lib.E_INVALID_ARG and "one output" in c1.last_error()
+
+
+def test_model_without_aux_head(oracle):
+    """An INFURW01 blob / ONNX file without the aux head (55 convs): one output, logits match the oracle."""
+    blob = W.synth_blob(aux=False)
+    fr = W.synth_frame(48, 64, index=1)
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(blob))
+        info = m.get_info()
+        assert info.output_names == ["out"]
+        out = []
+        m.advance(fr, out)
+        assert len(out) == 1
+        lo, la = m.lowres()
+        assert la is None
+        assert oracle.model_load(blob) == 0
+        ref = oracle.model_forward(oracle.pack_normalize(fr), full=False)
+        err = np.abs(lo - ref["out_low"]).max() / np.abs(ref["out_low"]).max()
+        assert err < 1e-3, err
+        rgba, _ = FramePath(c).advance(fr)
+        assert rgba.shape == (48, 64, 4)
+
+
+# ---------------------------------------------------------------- reload / lifetime / warm-up
+def test_failed_reload_keeps_the_loaded_model(blob50, tmp_path):
+    """Model::control leaves the old session in place on any load error (predict_onnx.rs:288-309)."""
+    fr = W.synth_frame(48, 64)
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(blob50))
+        ref, _ = FramePath(c).advance(fr)
+        bad = bytearray(blob50)
+        bad[32 + 56:32 + 64] = (2 ** 64 - 4).to_bytes(8, "little")  # conv 0 weight offset that wraps in off + n
+        with pytest.raises(ModelCmdError) as e:
+            m.control(ModelCmd.LoadBlob(bytes(bad)))
+        assert e.value.code == _lib.E_MODEL_FORMAT and "out of range" in str(e.value)
+        trunc = tmp_path / "trunc.infurw"
+        trunc.write_bytes(blob50[: len(blob50) // 2])
+        with pytest.raises(ModelCmdError):
+            m.control(ModelCmd.Load(str(trunc)))
+        with pytest.raises(ModelCmdError):
+            m.control(ModelCmd.Load("/nonexistent/model.onnx"))
+        assert m.get_info() is not None
+        again, _ = FramePath(c).advance(fr)
+        assert (again == ref).all()
+        m.control(ModelCmd.Load(""))  # the explicit unload still unloads
+        assert m.get_info() is None
+
+
+def test_stream_outlives_context_safely(blob50):
+    """closing the context before its StreamPath must not touch freed memory."""
+    c = Context(device=0)
+    Model(c).control(ModelCmd.LoadBlob(blob50))
+    sp = StreamPath(c, depth=2)
+    sp.submit(W.synth_frame(48, 64), 1.0, 1)
+    c.close()  # releases the ring; the handle becomes an empty shell
+    assert c.L.infur_stream_pending(sp.h) == 0
+    rc = c.L.infur_stream_submit(sp.h, W.synth_frame(48, 64).ctypes.data, 64, 48, 1.0, 0, 2)
+    assert rc == _lib.E_INVALID_ARG
+    sp.close()  # frees only the handle
+    # the usual order keeps working
+    with Context(device=0) as c2:
+        Model(c2).control(ModelCmd.LoadBlob(blob50))
+        sp2 = StreamPath(c2, depth=2)
+        sp2.submit(W.synth_frame(48, 64), 1.0, 5)
+        assert sp2.collect()[0] == 5
+        sp2.close()
+
+
+def test_warmup_pretunes_and_size_changes_trim_the_arena(blob50):
+    """infur_model_warmup: the first real frame at that size triggers no trial launches (tuning text unchanged);
+    after a run of small frames the big frame's arena has been returned and results are unchanged."""
+    big, small = W.synth_frame(128, 192, index=2), W.synth_frame(48, 64, index=2)
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(blob50))
+        with pytest.raises(InfurError):
+            m.warmup(0, 10)
+        m.warmup(192, 128)
+        tuned = c.tuning_text()
+        fp = FramePath(c)
+        ref_big, _ = fp.advance(big)
+        assert c.tuning_text() == tuned
+        ref_small = [fp.advance(small)[0] for _ in range(8)]  # > kPoolTrimAfter frames at the small size
+        assert all((r == ref_small[0]).all() for r in ref_small)
+        again, _ = fp.advance(big)
+        assert (again == ref_big).all()
+    with Context(device=0) as c:
+        with pytest.raises(InfurError) as e:
+            Model(c).warmup(64, 48)
+        assert e.value.code == _lib.E_MODEL_NOT_LOADED
+
+
+# ---------------------------------------------------------------- the group: several contexts, one process
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_group_broadcast_and_sharded_batch(blob50, force_rccl, monkeypatch):
+    """BASELINE configs[3] in one process: weights loaded on context 0 only, replicated by
+    infur_group_weights_broadcast, 7 frames of mixed sizes split 3/2/2 over three contexts on device 0; masks equal
+    the single-context results, in frame order.  force_rccl routes the replication through ncclBroadcast on a
+    one-rank communicator (ncclCommInitAll) so the RCCL code path executes on a 1-GPU box."""
+    if force_rccl:
+        monkeypatch.setenv("INFUR_FORCE_RCCL", "1")
+    else:
+        monkeypatch.delenv("INFUR_FORCE_RCCL", raising=False)
+    imgs = [W.synth_frame(64 + 16 * (i % 2), 96, index=i) for i in range(7)]
+    ctxs = [Context(device=0) for _ in range(3)]
+    try:
+        Model(ctxs[0]).control(ModelCmd.LoadBlob(blob50))
+        ref = FramePath(ctxs[0]).advance_batch(imgs, 0.5)
+        with Group(ctxs) as g:
+            assert len(g) == 3 and g.uses_rccl == force_rccl
+            with pytest.raises(InfurError) as e:
+                g.weights_broadcast(root=2)
+            assert e.value.code == _lib.E_MODEL_NOT_LOADED
+            g.weights_broadcast(root=0)
+            for c in ctxs[1:]:
+                info = Model(c).get_info()
+                assert info is not None and info.output_names == ["out", "aux"] and info.depth == 50
+            got = g.advance_batch(imgs, 0.5)
+            assert len(got) == 7
+            for a, b in zip(got, ref):
+                assert a.shape == b.shape and (a == b).all()
+            # every context really holds a working replica
+            for c in ctxs[1:]:
+                solo, _ = FramePath(c).advance(imgs[0], 0.5)
+                assert (solo == ref[0]).all()
+            assert g.advance_batch([], 1.0) == []
+            assert len(g.advance_batch(imgs[:2], 0.5)) == 2  # fewer frames than contexts
+            # a failing frame reports the owning context and its message (frame 5 belongs to context 2)
+            outs = [np.empty_like(r) for r in ref]
+            n = len(imgs)
+            fp = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+            op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+            ws = (C.c_uint32 * n)(*[i.shape[1] for i in imgs])
+            hs = (C.c_uint32 * n)(*[i.shape[0] for i in imgs])
+            caps = (C.c_size_t * n)(*[o.nbytes if k != 5 else 4 for k, o in enumerate(outs)])
+            rc = g.L.infur_group_batch_advance(g.g, fp, ws, hs, n, 0.5, 0, op, caps, None, None)
+            msg = g.L.infur_group_last_error(g.g).decode()
+            assert rc == _lib.E_CAPACITY and "context 2" in msg and "frames 5..6" in msg, msg
+            for k in range(5):  # the other slices completed
+                assert (outs[k] == ref[k]).all()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_group_rejects_mixed_dtypes_and_one_shot_forms(blob50):
+    a, b = Context(device=0), Context(device=0, dtype="f32s")
+    try:
+        Model(a).control(ModelCmd.LoadBlob(blob50))
+        with Group([a, b]) as g:
+            with pytest.raises(InfurError) as e:
+                g.weights_broadcast(0)
+            assert e.value.code == _lib.E_INVALID_ARG
+    finally:
+        b.close()
+    b = Context(device=0)
+    try:
+        arr = (C.c_void_p * 2)(a.h, b.h)
+        assert a.L.infur_weights_broadcast(arr, 2) == _lib.OK
+        imgs = [W.synth_frame(48, 64, index=i) for i in range(3)]
+        outs = [np.empty((48, 64, 4), np.uint8) for _ in imgs]
+        fp = (C.c_void_p * 3)(*[i.ctypes.data for i in imgs])
+        op = (C.c_void_p * 3)(*[o.ctypes.data for o in outs])
+        ws, hs = (C.c_uint32 * 3)(64, 64, 64), (C.c_uint32 * 3)(48, 48, 48)
+        caps = (C.c_size_t * 3)(*[o.nbytes for o in outs])
+        assert a.L.infur_batch_advance_multi(arr, 2, fp, ws, hs, 3, 1.0, 0, op, caps, None, None) == _lib.OK
+        for im, o in zip(imgs, outs):
+            assert (o == FramePath(a).advance(im)[0]).all()
+        dup = (C.c_void_p * 2)(a.h, a.h)
+        g = C.c_void_p(None)
+        assert a.L.infur_group_create(dup, 2, C.byref(g)) == _lib.E_INVALID_ARG
+    finally:
+        a.close()
+        b.close()
+
+
+# ---------------------------------------------------------------- bench.py launches its own ranks
+def test_bench_self_launches_two_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` (exactly what the driver runs) must start its own two ranks.  On this 1-GPU box
+    both ranks share device 0 and the collective runs over gloo; the JSON line reports n_gpus == 2 and both ranks
+    produce identical masks for the same frame (mask_sha of frame 0 is all-gathered and compared in bench.py)."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--frames-per-step", "2", "--width", "320", "--height", "240", "--no-cpu-baseline",
+                        "--no-split", "--no-side"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["weights_bcast_ms"] >= 0 and j["config"]["ranks_agree_on_frame0_mask"] is True
