@@ -5,16 +5,21 @@
 // the minimum needed to accept the same file here: a hand-written protobuf wire-format reader
 // (ModelProto -> GraphProto -> node / initializer / input / output) that
 //   * applies the reference's input checks with the reference's messages (:228-262),
-//   * walks the Conv nodes in graph order -- torchvision's FCN traces as stem, then per
-//     bottleneck conv1, conv2, conv3, downsample, then classifier and aux_classifier, which is
-//     exactly the INFURW01 order -- folding a trailing BatchNormalization when the exporter
-//     did not, and checks every shape / stride / dilation against the expected graph,
+//   * follows the graph's EDGES from the image input -- stem Conv -> Relu -> MaxPool, then per bottleneck
+//     conv1 -> Relu -> conv2 -> Relu -> conv3 -> Add(identity | downsample Conv) -> Relu, then the classifier
+//     (Conv -> Relu -> [Dropout] -> Conv -> Resize -> output 0) and the aux head off layer3 (-> output 1) --
+//     so every weight tensor is assigned to its INFURW01 slot by its place in the topology, never by its
+//     position in the serialized node list (conv3 and downsample.0 of layer1.0 have identical shapes);
+//     a trailing BatchNormalization is folded when the exporter did not; every shape / stride / dilation,
+//     the MaxPool, the Relu placement and the final Resize (linear, half-pixel coordinates) are checked
+//     against torchvision's fcn_resnet50/101 and anything else is a format error,
 //   * emits the INFURW01 blob that infur_model_load_blob consumes.
 // No onnx / protobuf library is used (none exists in the build image).  Host only.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -78,15 +83,22 @@ struct Tensor {
     const uint8_t* raw = nullptr;
     size_t raw_len = 0;
     std::vector<float> fdata;  // float_data (field 4)
-    size_t count() const {
-        size_t n = 1;
-        for (auto d : dims) n *= (size_t)d;
-        return n;
+    bool external = false;     // data_location = EXTERNAL / external_data entries present
+    // element count; false for non-positive dims or more than 2^31 elements (no tensor of this model family
+    // comes near; an absurd count must not reach a resize())
+    bool count(size_t& n) const {
+        n = 1;
+        for (auto d : dims) {
+            if (d <= 0 || d > (int64_t)1 << 31) return false;
+            n *= (size_t)d;
+            if (n > (size_t)1 << 31) return false;
+        }
+        return true;
     }
     bool floats(std::vector<float>& out) const {
-        const size_t n = count();
-        if (dtype != 1) return false;  // FLOAT
-        if (raw && raw_len == n * 4) {
+        size_t n;
+        if (dtype != 1 || external || !count(n)) return false;  // FLOAT, inline
+        if (raw && raw_len / 4 == n && raw_len % 4 == 0) {
             out.resize(n);
             memcpy(out.data(), raw, n * 4);
             return true;
@@ -104,6 +116,9 @@ struct Node {
     std::vector<std::string> in, out;
     std::map<std::string, std::vector<int64_t>> ints;
     std::map<std::string, float> f;
+    std::map<std::string, std::string> strs;
+    const uint8_t* value_t = nullptr;  // Constant: the `value` TensorProto
+    size_t value_len = 0;
 };
 
 void read_packed_i64(const uint8_t* d, size_t n, std::vector<int64_t>& v) {
@@ -123,7 +138,8 @@ bool parse_tensor(const uint8_t* d, size_t n, std::string& name, Tensor& t) {
         }
         else if (f == 8 && wt == 2) name.assign((const char*)s, l);
         else if (f == 9 && wt == 2) { t.raw = s; t.raw_len = l; }
-        else if (f == 14 && v != 0) return false;  // external data is not supported
+        else if (f == 13 && wt == 2) t.external = true;   // external_data entry
+        else if (f == 14 && v != 0) t.external = true;    // data_location = EXTERNAL
     }
     return r.ok;
 }
@@ -131,20 +147,26 @@ bool parse_tensor(const uint8_t* d, size_t n, std::string& name, Tensor& t) {
 bool parse_attr(const uint8_t* d, size_t n, Node& node) {
     PB r(d, n);
     uint32_t f, wt; uint64_t v; const uint8_t* s; size_t l;
-    std::string name;
+    std::string name, sv;
     std::vector<int64_t> ints;
-    bool has_i = false, has_f = false;
+    bool has_i = false, has_f = false, has_s = false;
     int64_t iv = 0;
     float fv = 0;
+    const uint8_t* tv = nullptr;
+    size_t tl = 0;
     while (r.next(f, wt, v, s, l)) {
         if (f == 1 && wt == 2) name.assign((const char*)s, l);
         else if (f == 2 && wt == 5) { uint32_t u = (uint32_t)v; memcpy(&fv, &u, 4); has_f = true; }
         else if (f == 3 && wt == 0) { iv = (int64_t)v; has_i = true; }
+        else if (f == 4 && wt == 2) { sv.assign((const char*)s, l); has_s = true; }
+        else if (f == 5 && wt == 2) { tv = s; tl = l; }
         else if (f == 8) { if (wt == 2) read_packed_i64(s, l, ints); else ints.push_back((int64_t)v); }
     }
     if (!ints.empty()) node.ints[name] = ints;
     else if (has_i) node.ints[name] = {iv};
     if (has_f) node.f[name] = fv;
+    if (has_s) node.strs[name] = sv;
+    if (tv && name == "value") { node.value_t = tv; node.value_len = tl; }
     return r.ok;
 }
 
@@ -284,19 +306,102 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
     info.input_dtype = "Float";
     for (auto& o : outputs) info.output_names.push_back(o.name);
 
-    // ---- Conv nodes in graph order (+ BatchNormalization folding) ----
-    std::map<std::string, const Node*> consumer_bn;
+    // ---- opset: Resize's coordinate rule is only spelled out from opset 11 on ----
+    int64_t opset = 0;
+    {
+        PB mm(data, len);
+        while (mm.next(f, wt, v, s, l)) {
+            if (f != 8 || wt != 2) continue;  // opset_import
+            PB os(s, l);
+            uint32_t f2, w2; uint64_t v2; const uint8_t* s2; size_t l2;
+            std::string domain;
+            int64_t ver = 0;
+            while (os.next(f2, w2, v2, s2, l2)) {
+                if (f2 == 1 && w2 == 2) domain.assign((const char*)s2, l2);
+                else if (f2 == 2 && w2 == 0) ver = (int64_t)v2;
+            }
+            if (domain.empty() || domain == "ai.onnx") opset = ver;
+        }
+    }
+
+    // ---- edges ----
+    // Constant nodes are initializers in all but name (old exporters write weights that way)
     for (auto& n : nodes)
-        if (n.op == "BatchNormalization" && !n.in.empty()) consumer_bn[n.in[0]] = &n;
-    struct Folded { std::vector<float> w, b; int cout, cin, kh, kw, stride, pad, dil; };
-    std::vector<Folded> convs;
-    for (auto& n : nodes) {
+        if (n.op == "Constant" && n.value_t && !n.out.empty()) {
+            std::string nm; Tensor t;
+            if (!parse_tensor(n.value_t, n.value_len, nm, t)) { err = "malformed Constant tensor"; return 1; }
+            inits[n.out[0]] = std::move(t);
+        }
+    std::map<std::string, std::vector<int>> consumers;  // tensor -> nodes reading it as a DATA input
+    std::map<std::string, int> producer;
+    for (size_t i = 0; i < nodes.size(); i++) {
+        for (auto& o : nodes[i].out) producer[o] = (int)i;
+        for (auto& in : nodes[i].in)
+            if (!in.empty() && !inits.count(in)) consumers[in].push_back((int)i);
+    }
+    // value-preserving nodes an exporter may leave between two layers (inference semantics)
+    auto transparent = [&](const Node& n) { return n.op == "Identity" || n.op == "Dropout"; };
+    // the nodes that compute on tensor t, looking through Identity / Dropout; Shape readers (the Resize size
+    // arithmetic) are not data consumers
+    std::function<void(const std::string&, std::vector<int>&)> users = [&](const std::string& t, std::vector<int>& out) {
+        auto it = consumers.find(t);
+        if (it == consumers.end()) return;
+        for (int i : it->second) {
+            const Node& n = nodes[i];
+            if (n.op == "Shape") continue;
+            if (transparent(n)) { if (!n.out.empty() && n.in[0] == t) users(n.out[0], out); }
+            else out.push_back(i);
+        }
+    };
+    // origin of a tensor, looking back through Identity / Dropout
+    auto origin = [&](std::string t) {
+        for (int guard = 0; guard < 64; guard++) {
+            auto it = producer.find(t);
+            if (it == producer.end() || !transparent(nodes[it->second]) || nodes[it->second].in.empty()) break;
+            t = nodes[it->second].in[0];
+        }
+        return t;
+    };
+    auto sole_user = [&](const std::string& t, const char* op, const char* what, int& idx) {
+        std::vector<int> u;
+        users(t, u);
+        if (u.size() != 1 || nodes[u[0]].op != op) {
+            err = std::string("expected exactly one ") + op + " after " + what + ", found " + std::to_string(u.size()) +
+                  (u.empty() ? "" : " (" + nodes[u[0]].op + ")");
+            return false;
+        }
+        idx = u[0];
+        return true;
+    };
+
+    for (auto& n : nodes)
         if (n.op == "QLinearConv" || n.op == "ConvInteger") { err = "quantised model (" + n.op + "): only float Conv models are supported"; return 2; }
-        if (n.op != "Conv") continue;
+    size_t n_conv_nodes = 0;
+    for (auto& n : nodes) n_conv_nodes += n.op == "Conv";
+    int depth = 0;
+    bool aux = false;
+    switch (n_conv_nodes) {
+        case 57: depth = 50; aux = true; break;
+        case 55: depth = 50; break;
+        case 108: depth = 101; aux = true; break;
+        case 106: depth = 101; break;
+        default: err = "model has " + std::to_string(n_conv_nodes) + " Conv nodes; fcn_resnet50 has 57 (55 without aux), fcn_resnet101 108 (106)"; return 2;
+    }
+
+    struct Folded { std::vector<float> w, b; int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, dil = 1; std::string out; };
+    std::vector<char> conv_used(nodes.size(), 0);
+    // Conv node -> folded weights; `out` = the tensor carrying its result (after a BatchNormalization it feeds alone)
+    auto fold = [&](int idx, Folded& c) -> int {
+        const Node& n = nodes[idx];
+        if (conv_used[idx]) { err = "a Conv node is reached twice while walking the graph"; return 2; }
+        conv_used[idx] = 1;
         if (n.in.size() < 2 || !inits.count(n.in[1])) { err = "Conv without an initializer weight"; return 1; }
         const Tensor& W = inits[n.in[1]];
+        if (W.external) { err = "tensor '" + n.in[1] + "' uses external_data: only single-file models are supported"; return 1; }
         if (W.dims.size() != 4) { err = "Conv weight is not 4-D"; return 1; }
-        Folded c;
+        if (W.dtype != 1) { err = "Conv weight '" + n.in[1] + "' has elem_type " + std::to_string(W.dtype) + ": only float (1) models are supported"; return 2; }
+        size_t cnt;
+        if (!W.count(cnt)) { err = "Conv weight '" + n.in[1] + "' has non-positive or absurd dimensions"; return 1; }
         c.cout = (int)W.dims[0]; c.cin = (int)W.dims[1]; c.kh = (int)W.dims[2]; c.kw = (int)W.dims[3];
         if (!W.floats(c.w)) { err = "Conv weight '" + n.in[1] + "' is not inline float data"; return 1; }
         if (n.in.size() > 2 && !n.in[2].empty()) {
@@ -306,18 +411,27 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
         }
         auto geti = [&](const char* k, size_t i, int64_t dflt) { auto it = n.ints.find(k); return it != n.ints.end() && it->second.size() > i ? it->second[i] : dflt; };
         if (geti("group", 0, 1) != 1) { err = "grouped Conv is not part of FCN-ResNet"; return 1; }
+        auto ap = n.strs.find("auto_pad");
+        if (ap != n.strs.end() && ap->second != "NOTSET") { err = "Conv auto_pad " + ap->second + " is not part of FCN-ResNet"; return 1; }
+        if (geti("kernel_shape", 0, c.kh) != c.kh || geti("kernel_shape", 1, c.kw) != c.kw) { err = "Conv kernel_shape disagrees with its weight"; return 1; }
         c.stride = (int)geti("strides", 0, 1);
         c.dil = (int)geti("dilations", 0, 1);
         c.pad = (int)geti("pads", 0, 0);
         if (geti("strides", 1, c.stride) != c.stride || geti("dilations", 1, c.dil) != c.dil || geti("pads", 1, c.pad) != c.pad ||
             geti("pads", 2, c.pad) != c.pad || geti("pads", 3, c.pad) != c.pad) { err = "anisotropic Conv attributes are not part of FCN-ResNet"; return 1; }
-        auto bn = n.out.empty() ? consumer_bn.end() : consumer_bn.find(n.out[0]);
-        if (bn != consumer_bn.end()) {  // W' = W*g/sqrt(v+eps), b' = (b-mean)*g/sqrt(v+eps) + beta
-            const Node& B = *bn->second;
+        if (n.out.empty()) { err = "Conv without an output"; return 1; }
+        c.out = n.out[0];
+        std::vector<int> u;
+        users(c.out, u);
+        if (u.size() == 1 && nodes[u[0]].op == "BatchNormalization" && !nodes[u[0]].in.empty() && origin(nodes[u[0]].in[0]) == c.out) {
+            // W' = W*g/sqrt(v+eps), b' = (b-mean)*g/sqrt(v+eps) + beta
+            const Node& B = nodes[u[0]];
             std::vector<float> ga, be, mu, va;
             if (B.in.size() < 5 || !inits.count(B.in[1]) || !inits.count(B.in[2]) || !inits.count(B.in[3]) || !inits.count(B.in[4]) ||
                 !inits[B.in[1]].floats(ga) || !inits[B.in[2]].floats(be) || !inits[B.in[3]].floats(mu) || !inits[B.in[4]].floats(va) ||
-                (int)ga.size() != c.cout) { err = "bad BatchNormalization parameters"; return 1; }
+                (int)ga.size() != c.cout || (int)be.size() != c.cout || (int)mu.size() != c.cout || (int)va.size() != c.cout || B.out.empty()) {
+                err = "bad BatchNormalization parameters"; return 1;
+            }
             auto e = B.f.find("epsilon");
             const double eps = e != B.f.end() ? e->second : 1e-5;
             const size_t per = (size_t)c.cin * c.kh * c.kw;
@@ -326,21 +440,158 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
                 for (size_t i = 0; i < per; i++) c.w[o * per + i] = (float)((double)c.w[o * per + i] * sc);
                 c.b[o] = (float)(((double)c.b[o] - mu[o]) * sc + be[o]);
             }
+            c.out = B.out[0];
         }
-        convs.push_back(std::move(c));
-    }
+        return 0;
+    };
 
-    int depth = 0;
-    bool aux = false;
-    switch (convs.size()) {
-        case 57: depth = 50; aux = true; break;
-        case 55: depth = 50; break;
-        case 108: depth = 101; aux = true; break;
-        case 106: depth = 101; break;
-        default: err = "model has " + std::to_string(convs.size()) + " Conv nodes; fcn_resnet50 has 57 (55 without aux), fcn_resnet101 108 (106)"; return 2;
+    // ---- walk ----
+    std::vector<ExpConv> exp = expected_graph(depth, /*ncls: patched below*/ 0, aux);
+    std::vector<Folded> convs(exp.size());
+    size_t slot = 0;
+    int idx = -1, rc = 0;
+    auto take = [&](int node_idx) -> int {  // fold nodes[node_idx] into the next slot
+        if (slot >= convs.size()) { err = "more convolutions on the path than fcn_resnet has"; return 2; }
+        return fold(node_idx, convs[slot++]);
+    };
+    auto relu_after = [&](const std::string& t, const char* what, std::string& out) {
+        int r;
+        if (!sole_user(t, "Relu", what, r)) return false;
+        out = nodes[r].out.empty() ? std::string() : nodes[r].out[0];
+        return true;
+    };
+
+    std::string t = in0->name, t3;
+    if (!sole_user(t, "Conv", "the image input", idx)) return 2;
+    if ((rc = take(idx))) return rc;
+    if (!relu_after(convs[slot - 1].out, "the stem convolution", t)) return 2;
+    if (!sole_user(t, "MaxPool", "the stem's Relu", idx)) return 2;
+    {
+        const Node& mp = nodes[idx];
+        auto geti = [&](const char* k, size_t i, int64_t dflt) { auto it = mp.ints.find(k); return it != mp.ints.end() && it->second.size() > i ? it->second[i] : dflt; };
+        bool ok = geti("kernel_shape", 0, 0) == 3 && geti("kernel_shape", 1, 0) == 3 && geti("strides", 0, 1) == 2 && geti("strides", 1, 1) == 2 &&
+                  geti("ceil_mode", 0, 0) == 0 && geti("dilations", 0, 1) == 1 && geti("dilations", 1, 1) == 1;
+        for (size_t i = 0; i < 4; i++) ok = ok && geti("pads", i, 0) == 1;
+        if (!ok || mp.out.empty()) { err = "the stem's MaxPool is not 3x3 / stride 2 / pad 1"; return 2; }
+        t = mp.out[0];
     }
+    const int lb50[4] = {3, 4, 6, 3}, lb101[4] = {3, 4, 23, 3};
+    const int* lb = depth == 50 ? lb50 : lb101;
+    int aux_conv = -1;  // the aux head's first conv: the Conv reader of layer3's output that belongs to no block
+    for (int L = 0; L < 4; L++)
+        for (int b = 0; b < lb[L]; b++) {
+            const std::string where = "backbone.layer" + std::to_string(L + 1) + "." + std::to_string(b);
+            std::vector<int> u;
+            users(t, u);
+            // conv1 = the Conv reader of the block input that starts conv -> Relu -> conv -> Relu -> conv -> Add
+            int c1 = -1, c2 = -1, c3 = -1, add = -1;
+            for (int cand : u) {
+                if (nodes[cand].op != "Conv" || nodes[cand].out.empty()) continue;
+                auto step = [&](const std::string& from, const char* op) {  // sole user of `from` (through a folded BN) with that op
+                    std::string cur = from;
+                    for (int hop = 0; hop < 2; hop++) {
+                        std::vector<int> uu;
+                        users(cur, uu);
+                        if (uu.size() != 1) return -1;
+                        if (nodes[uu[0]].op == op) return uu[0];
+                        if (nodes[uu[0]].op != "BatchNormalization" || nodes[uu[0]].out.empty()) return -1;
+                        cur = nodes[uu[0]].out[0];
+                    }
+                    return -1;
+                };
+                const int r1 = step(nodes[cand].out[0], "Relu");
+                const int k2 = r1 >= 0 && !nodes[r1].out.empty() ? step(nodes[r1].out[0], "Conv") : -1;
+                const int r2 = k2 >= 0 && !nodes[k2].out.empty() ? step(nodes[k2].out[0], "Relu") : -1;
+                const int k3 = r2 >= 0 && !nodes[r2].out.empty() ? step(nodes[r2].out[0], "Conv") : -1;
+                const int ad = k3 >= 0 && !nodes[k3].out.empty() ? step(nodes[k3].out[0], "Add") : -1;
+                if (ad < 0) continue;
+                if (c1 >= 0) { err = where + ": two Conv chains leave the block input"; return 2; }
+                c1 = cand; c2 = k2; c3 = k3; add = ad;
+            }
+            if (c1 < 0) { err = where + ": no conv1 -> Relu -> conv2 -> Relu -> conv3 -> Add chain leaves the block input"; return 2; }
+            if ((rc = take(c1)) || (rc = take(c2)) || (rc = take(c3))) return rc;
+            const Folded& f3 = convs[slot - 1];
+            const Node& A = nodes[add];
+            if (A.in.size() != 2 || A.out.empty()) { err = where + ": malformed Add"; return 2; }
+            const std::string a0 = origin(A.in[0]), a1 = origin(A.in[1]);
+            if (a0 != f3.out && a1 != f3.out) { err = where + ": the residual Add does not read conv3"; return 2; }
+            const std::string other = a0 == f3.out ? a1 : a0;
+            const bool want_ds = b == 0;
+            if (!want_ds) {
+                if (other != origin(t)) { err = where + ": the residual Add must read the block input (identity shortcut)"; return 2; }
+            } else {
+                // the shortcut is a Conv (+BN) that reads the block input
+                auto pit = producer.find(other);
+                int dn = pit == producer.end() ? -1 : pit->second;
+                if (dn >= 0 && nodes[dn].op == "BatchNormalization" && !nodes[dn].in.empty()) {
+                    auto p2 = producer.find(origin(nodes[dn].in[0]));
+                    dn = p2 == producer.end() ? -1 : p2->second;
+                }
+                if (dn < 0 || nodes[dn].op != "Conv" || nodes[dn].in.empty() || origin(nodes[dn].in[0]) != origin(t)) {
+                    err = where + ": the shortcut of a stage's first block must be a downsample Conv reading the block input"; return 2;
+                }
+                if ((rc = take(dn))) return rc;
+                if (convs[slot - 1].out != other) { err = where + ": the downsample branch does not feed the residual Add directly"; return 2; }
+            }
+            // every other reader of the block input must be accounted for: the Add (identity), or -- only for
+            // layer3's output, seen as layer4.0's input -- the aux head's conv
+            for (int cand : u) {
+                if (cand == c1 || cand == add || conv_used[cand]) continue;
+                if (nodes[cand].op == "Conv" && L == 3 && b == 0 && aux && aux_conv < 0) { aux_conv = cand; continue; }
+                err = where + ": unexpected " + nodes[cand].op + " reads the block input"; return 2;
+            }
+            if (L == 3 && b == 0) t3 = t;
+            if (!relu_after(A.out[0], (where + "'s residual Add").c_str(), t)) return 2;
+        }
+    // ---- heads: Conv 3x3 -> Relu -> [Dropout] -> Conv 1x1 -> Resize -> graph output ----
+    auto head = [&](const std::string& feat, int first_conv, const char* what, size_t out_index) -> int {
+        int h0 = first_conv;
+        if (h0 < 0) {
+            std::vector<int> u;
+            users(feat, u);
+            for (int cand : u)
+                if (nodes[cand].op == "Conv" && !conv_used[cand]) { if (h0 >= 0) { err = std::string(what) + ": two candidate head convolutions"; return 2; } h0 = cand; }
+                else if (!conv_used[cand]) { err = std::string(what) + ": unexpected " + nodes[cand].op + " reads the backbone output"; return 2; }
+            if (h0 < 0) { err = std::string(what) + ": no head convolution reads the backbone output"; return 2; }
+        }
+        int r2;
+        if ((r2 = take(h0))) return r2;
+        std::string th;
+        if (!relu_after(convs[slot - 1].out, what, th)) return 2;
+        int h1;
+        if (!sole_user(th, "Conv", what, h1)) return 2;
+        if ((r2 = take(h1))) return r2;
+        std::vector<int> u;
+        users(convs[slot - 1].out, u);
+        if (u.size() != 1 || (nodes[u[0]].op != "Resize" && nodes[u[0]].op != "Upsample")) { err = std::string(what) + ": the logits must feed exactly one Resize"; return 2; }
+        const Node& R = nodes[u[0]];
+        if (R.op == "Upsample" || opset < 11) { err = std::string(what) + ": " + R.op + " under opset " + std::to_string(opset) + " has no half-pixel coordinate rule (need Resize, opset >= 11)"; return 2; }
+        auto m = R.strs.find("mode");
+        if (m == R.strs.end() || m->second != "linear") { err = std::string(what) + ": Resize mode must be linear (bilinear up-sampling), got '" + (m == R.strs.end() ? "nearest" : m->second) + "'"; return 2; }
+        auto cm = R.strs.find("coordinate_transformation_mode");
+        const std::string cmode = cm == R.strs.end() ? "half_pixel" : cm->second;
+        if (cmode != "pytorch_half_pixel" && cmode != "half_pixel") { err = std::string(what) + ": Resize coordinate_transformation_mode '" + cmode + "' is not align_corners=False bilinear"; return 2; }
+        if (origin(R.in[0]) != convs[slot - 1].out || R.out.empty()) { err = std::string(what) + ": Resize does not read the logits"; return 2; }
+        // ... and that Resize is graph output #out_index (the reference decodes outputs[0], app.rs:116)
+        if (out_index >= outputs.size() || origin(outputs[out_index].name) != R.out[0]) {
+            err = std::string(what) + ": its up-sampled logits are not graph output #" + std::to_string(out_index); return 2;
+        }
+        return 0;
+    };
+    if ((rc = head(t, -1, "classifier", 0))) return rc;
+    if (aux) {
+        if (aux_conv < 0) { err = "aux_classifier: no head convolution reads layer3's output"; return 2; }
+        if ((rc = head(t3, aux_conv, "aux_classifier", 1))) return rc;
+    } else if (aux_conv >= 0) {
+        err = "a convolution besides layer4 reads layer3's output but the model has no aux head"; return 2;
+    }
+    if (slot != convs.size()) { err = "the walk assigned " + std::to_string(slot) + " of " + std::to_string(convs.size()) + " convolutions"; return 2; }
+    for (size_t i = 0; i < nodes.size(); i++)
+        if (nodes[i].op == "Conv" && !conv_used[i]) { err = "a Conv node is not part of the FCN-ResNet topology"; return 2; }
+
     const int ncls = convs[aux ? convs.size() - 3 : convs.size() - 1].cout;
-    const std::vector<ExpConv> exp = expected_graph(depth, ncls, aux);
+    if (aux && convs.back().cout != ncls) { err = "out and aux heads disagree on the class count"; return 2; }
+    exp = expected_graph(depth, ncls, aux);
     for (size_t i = 0; i < exp.size(); i++) {
         const Folded& c = convs[i];
         const ExpConv& e = exp[i];

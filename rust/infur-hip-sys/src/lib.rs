@@ -10,6 +10,10 @@ pub struct infur_ctx {
 pub struct infur_stream {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct infur_group {
+    _private: [u8; 0],
+}
 
 #[repr(C)]
 pub struct infur_options {
@@ -46,7 +50,11 @@ pub const INFUR_E_SHAPE: i32 = 4;
 pub const INFUR_E_MODEL_NOT_LOADED: i32 = 5;
 pub const INFUR_E_MODEL_FORMAT: i32 = 6;
 pub const INFUR_E_HIP: i32 = 7;
+pub const INFUR_E_RCCL: i32 = 8;
+pub const INFUR_E_INVALID_ARG: i32 = 9;
+pub const INFUR_E_IO: i32 = 10;
 pub const INFUR_E_CAPACITY: i32 = 11;
+pub const INFUR_ABI_VERSION: u32 = 2;
 pub const INFUR_SCALE_NEAREST: u32 = 0;
 pub const INFUR_SCALE_BILINEAR: u32 = 1;
 pub const INFUR_DTYPE_F32: u32 = 0;
@@ -90,6 +98,27 @@ extern "C" {
     pub fn infur_stream_next_dims(s: *const infur_stream, frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
     pub fn infur_stream_collect(s: *mut infur_stream, rgba: *mut u8, cap: usize, scaled_bgr: *mut u8,
                                 frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
+    /// n frames through one context's depth-3 ring, masks in frame order (BASELINE configs[3] on one GPU)
+    pub fn infur_batch_advance(c: *mut infur_ctx, frames: *const *const u8, ws: *const u32, hs: *const u32, n: u32,
+                               factor: f32, mode: u32, rgba: *const *mut u8, caps: *const usize,
+                               ows: *mut u32, ohs: *mut u32) -> i32;
+    pub fn infur_model_warmup(c: *mut infur_ctx, w: u32, h: u32) -> i32;
+
+    // several GPUs from one process: RCCL weight broadcast + frame-batch sharding
+    pub fn infur_group_create(ctxs: *const *mut infur_ctx, n_ctx: u32, out: *mut *mut infur_group) -> i32;
+    pub fn infur_group_destroy(g: *mut infur_group);
+    pub fn infur_group_last_error(g: *const infur_group) -> *const c_char;
+    pub fn infur_group_size(g: *const infur_group) -> u32;
+    pub fn infur_group_uses_rccl(g: *const infur_group) -> u32;
+    pub fn infur_group_weights_broadcast(g: *mut infur_group, root: u32) -> i32;
+    pub fn infur_group_batch_advance(g: *mut infur_group, frames: *const *const u8, ws: *const u32, hs: *const u32,
+                                     n: u32, factor: f32, mode: u32, rgba: *const *mut u8, caps: *const usize,
+                                     ows: *mut u32, ohs: *mut u32) -> i32;
+    pub fn infur_weights_broadcast(ctxs: *const *mut infur_ctx, n_ctx: u32) -> i32;
+    pub fn infur_batch_advance_multi(ctxs: *const *mut infur_ctx, n_ctx: u32, frames: *const *const u8, ws: *const u32,
+                                     hs: *const u32, n: u32, factor: f32, mode: u32, rgba: *const *mut u8,
+                                     caps: *const usize, ows: *mut u32, ohs: *mut u32) -> i32;
+
     /// INFUR_DTYPE_F32_SPLIT: largest |activation| fed to a GEMM and largest |Winograd-domain input| of the last
     /// forward, and whether either left the exact range of the f16 pairs
     pub fn infur_split_range(c: *mut infur_ctx, act_amax: *mut f32, wino_amax: *mut f32, saturated: *mut u32) -> i32;

@@ -156,37 +156,113 @@ impl HipModel {
         })
     }
 }
+/// Error processing model -- the reference's `ModelProcError` (`predict_onnx.rs:32-39`) with the ORT arm replaced
+/// by the HIP runtime's (same variant names, same messages, so `AppProcError` keeps its `#[from]`, app.rs:17-36)
+#[derive(Error, Debug)]
+pub enum ModelProcError {
+    #[error("couldn't transform image")]
+    ShapeError(#[from] ndarray::ShapeError),
+    #[error("scaling to 0-sized output")]
+    RuntimeError(#[from] HipError),
+}
+
+/// Error loading model -- the reference's `ModelCmdError` (`predict_onnx.rs:41-48`): the runtime's own load error,
+/// or the file's input 0 not being an image the path can run (`infer_img_pre_proc`, `predict_onnx.rs:223-265`)
+#[derive(Error, Debug)]
+pub enum ModelCmdError {
+    #[error(transparent)]
+    Hip(HipError),
+    #[error(transparent)]
+    RuntimeError(#[from] ModelInputFormatError),
+}
+
+#[derive(Error, Debug)]
+pub enum ModelInputFormatError {
+    #[error("couldn't infer image input")]
+    Infer(String),
+}
+
 impl Processor for HipModel {
     type Command = ModelCmd;
-    type ControlError = HipError;
+    type ControlError = ModelCmdError;
     type Input = BgrImage;
     type Output = Vec<ArrayD<f32>>;
-    type ProcessResult = Result<(), HipError>;
+    type ProcessResult = Result<(), ModelProcError>;
 
-    fn control(&mut self, cmd: ModelCmd) -> Result<&mut Self, HipError> {
+    fn control(&mut self, cmd: ModelCmd) -> Result<&mut Self, ModelCmdError> {
         let ModelCmd::Load(path) = cmd; // "" unloads inside the library (predict_onnx.rs:310-312)
-        let c = CString::new(path).map_err(|_| HipError { code: 9, msg: "path contains NUL".into() })?;
+        let c = CString::new(path).map_err(|_| ModelCmdError::Hip(HipError { code: sys::INFUR_E_INVALID_ARG, msg: "path contains NUL".into() }))?;
         match unsafe { sys::infur_model_load(self.ctx.0, c.as_ptr()) } {
             sys::INFUR_OK => Ok(self),
-            rc => Err(self.ctx.err(rc)),
+            // the library reports input-layout problems with the reference's own messages (onnx_reader.cpp)
+            sys::INFUR_E_MODEL_FORMAT => Err(ModelInputFormatError::Infer(self.ctx.err(sys::INFUR_E_MODEL_FORMAT).msg).into()),
+            rc => Err(ModelCmdError::Hip(self.ctx.err(rc))),
         }
     }
     fn is_dirty(&self) -> bool { false }
-    fn advance(&mut self, img: &BgrImage, out: &mut Vec<ArrayD<f32>>) -> Result<(), HipError> {
+    fn advance(&mut self, img: &BgrImage, out: &mut Vec<ArrayD<f32>>) -> Result<(), ModelProcError> {
         let mi = match self.raw_info() { Some(mi) => mi, None => return Ok(()) }; // no session: out untouched
         let (k, h, w) = (mi.num_classes as usize, img.height() as usize, img.width() as usize);
-        let (mut o, mut a) = (vec![0f32; k * h * w], vec![0f32; k * h * w]);
+        // as many tensors as the model has outputs: [out, aux], or [out] without the aux head
+        let mut bufs: Vec<Vec<f32>> = (0..mi.n_outputs).map(|_| vec![0f32; k * h * w]).collect();
+        let aux = if bufs.len() > 1 { bufs[1].as_mut_ptr() } else { std::ptr::null_mut() };
         let mut n = 0u32;
         let rc = unsafe {
             sys::infur_model_advance(self.ctx.0, img.as_raw().as_ptr(), w as u32, h as u32,
-                                     o.as_mut_ptr(), a.as_mut_ptr(), &mut n)
+                                     bufs[0].as_mut_ptr(), aux, &mut n)
         };
-        if rc != sys::INFUR_OK { return Err(self.ctx.err(rc)); }
+        if rc != sys::INFUR_OK { return Err(self.ctx.err(rc).into()); }
         out.clear();
-        out.push(ArrayD::from_shape_vec(IxDyn(&[k, h, w]), o).expect("shape"));
-        out.push(ArrayD::from_shape_vec(IxDyn(&[k, h, w]), a).expect("shape"));
+        for b in bufs { out.push(ArrayD::from_shape_vec(IxDyn(&[k, h, w]), b)?); }
         Ok(())
     }
+}
+
+// ---------------------------------------------------------------- several GPUs (main.rs:38-40: one Proc thread)
+/// `infur_group`: the contexts of one process driven together -- RCCL weight broadcast over xGMI and frame-batch
+/// sharding (BASELINE configs[3]).  The `Ctx`s are kept alive by the `Rc`s held here.
+pub struct HipGroup { raw: *mut sys::infur_group, ctxs: Vec<Rc<Ctx>> }
+impl HipGroup {
+    pub fn new(ctxs: Vec<Rc<Ctx>>) -> Result<Self, HipError> {
+        let ptrs: Vec<*mut sys::infur_ctx> = ctxs.iter().map(|c| c.0).collect();
+        let mut raw = std::ptr::null_mut();
+        match unsafe { sys::infur_group_create(ptrs.as_ptr(), ptrs.len() as u32, &mut raw) } {
+            sys::INFUR_OK => Ok(Self { raw, ctxs }),
+            rc => Err(ctxs[0].err(rc)),
+        }
+    }
+    fn err(&self, rc: i32) -> HipError {
+        let msg = unsafe { CStr::from_ptr(sys::infur_group_last_error(self.raw)) }.to_string_lossy().into_owned();
+        HipError { code: rc, msg }
+    }
+    /// Replicate the model loaded in `ctxs[root]` to every other context (one ncclBroadcast of the repacked arena).
+    pub fn weights_broadcast(&mut self, root: u32) -> Result<(), HipError> {
+        match unsafe { sys::infur_group_weights_broadcast(self.raw, root) } { sys::INFUR_OK => Ok(()), rc => Err(self.err(rc)) }
+    }
+    /// scale -> model -> decode for a batch of independent frames, contiguous slices per context, masks in frame order.
+    pub fn batch_advance(&mut self, frames: &[BgrImage], factor: f32, masks: &mut Vec<ColorImage>) -> Result<(), HipError> {
+        masks.clear();
+        for f in frames {
+            let (mut ow, mut oh) = (0u32, 0u32);
+            let rc = unsafe { sys::infur_scale_out_dims(f.width(), f.height(), factor, &mut ow, &mut oh) };
+            if rc != sys::INFUR_OK { return Err(HipError::status(rc)); }
+            masks.push(ColorImage::new([ow as usize, oh as usize], Color32::BLACK));
+        }
+        let ins: Vec<*const u8> = frames.iter().map(|f| f.as_raw().as_ptr()).collect();
+        let outs: Vec<*mut u8> = masks.iter_mut().map(|m| m.pixels.as_mut_ptr() as *mut u8).collect();
+        let ws: Vec<u32> = frames.iter().map(|f| f.width()).collect();
+        let hs: Vec<u32> = frames.iter().map(|f| f.height()).collect();
+        let caps: Vec<usize> = masks.iter().map(|m| m.pixels.len() * 4).collect();
+        let rc = unsafe {
+            sys::infur_group_batch_advance(self.raw, ins.as_ptr(), ws.as_ptr(), hs.as_ptr(), frames.len() as u32, factor,
+                                           sys::INFUR_SCALE_NEAREST, outs.as_ptr(), caps.as_ptr(), std::ptr::null_mut(), std::ptr::null_mut())
+        };
+        if rc == sys::INFUR_OK { Ok(()) } else { Err(self.err(rc)) }
+    }
+    pub fn len(&self) -> usize { self.ctxs.len() }
+}
+impl Drop for HipGroup {
+    fn drop(&mut self) { unsafe { sys::infur_group_destroy(self.raw) } }
 }
 
 // ---------------------------------------------------------------- ColorCode (decode_predict.rs:38-84)

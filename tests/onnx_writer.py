@@ -80,23 +80,73 @@ def value_info(name, elem_type, dims):
     return f_str(1, name) + f_bytes(2, f_bytes(1, tt))
 
 
+def attr_str(name, v: str):
+    return f_str(1, name) + f_bytes(4, v.encode()) + f_varint(20, 3)
+
+
+def attr_tensor(name, t: bytes):
+    return f_str(1, name) + f_bytes(5, t) + f_varint(20, 4)
+
+
+def tensor_i64(name: str, vals) -> bytes:
+    arr = np.asarray(vals, np.int64)
+    return f_bytes(1, b"".join(_varint(d) for d in arr.shape)) + f_varint(2, 7) + f_bytes(9, arr.tobytes()) + f_str(8, name)
+
+
+def tensor_external(name: str, shape, location="weights.bin") -> bytes:
+    body = f_bytes(1, b"".join(_varint(d) for d in shape)) + f_varint(2, 1) + f_str(8, name)
+    body += f_bytes(13, f_str(1, "location") + f_str(2, location))  # external_data entry
+    return body + f_varint(14, 1)  # data_location = EXTERNAL
+
+
 def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, inits_as_inputs=False,
-              input_type=1, input_dims=("N", 3, "H", "W"), conv_op="Conv", drop_last=0, rng=None):
-    """tensors: [(name, W OIHW f32, b f32)] in graph order; specs: infur_amd.weights.graph(...).
-    unfold_bn: emit Conv(no bias) + BatchNormalization whose folding reproduces (W, b)."""
+              input_type=1, input_dims=("N", 3, "H", "W"), conv_op="Conv", drop_last=0, rng=None,
+              order="topo", dropout=False, identities=False, resize_subgraph=True, resize_mode="linear",
+              coord_mode="pytorch_half_pixel", swap_outputs=False, external=None, missing_relu=None, opset=12,
+              const_nodes=False, extra_conv=False):
+    """A torchvision-shaped fcn_resnet ModelProto: stem -> Relu -> MaxPool -> bottlenecks (conv1/conv2/conv3 [+ downsample],
+    Add, Relu) -> classifier (Conv, Relu, [Dropout], Conv, Resize) and the aux head off layer3, as torch.onnx.export
+    writes it (dynamic H/W: Shape -> Gather -> Unsqueeze -> Concat feeding Resize's `sizes`).
+
+    tensors: [(name, W OIHW f32, b f32)] in INFURW01 order; specs: infur_amd.weights.graph(...).
+    unfold_bn: Conv(no bias) + BatchNormalization whose folding reproduces (W, b).
+    order: "topo" (export order) | "ds_first" (every downsample conv serialised BEFORE its block's conv1..conv3) |
+           "shuffled" (random node order: slot assignment must come from the edges, not from positions).
+    """
     rng = rng or np.random.default_rng(0)
-    g = b""
-    inits = []
-    prev = "input"
     items = list(zip(specs, tensors))
     if drop_last:
         items = items[:-drop_last]
-    bn_params = {}
-    for i, (s, (name, w, b)) in enumerate(items):
+    by_name = {s.name: (s, t) for s, t in items}
+    inits, nodes, bn_params = [], [], {}
+    uid = [0]
+
+    def fresh(prefix):
+        uid[0] += 1
+        return f"{prefix}_{uid[0]}"
+
+    def emit(op, ins, outs, attrs=()):
+        nodes.append(f_bytes(1, node(op, ins, outs, attrs)))
+
+    def passthrough(t):
+        if identities and rng.random() < 0.3:
+            o = fresh("id")
+            emit("Identity", [t], [o])
+            return o
+        return t
+
+    def conv(name, x):
+        if name not in by_name:
+            return None
+        s, (_, w, b) = by_name[name]
         attrs = [attr_ints("dilations", [s.dil, s.dil]), attr_int("group", 1), attr_ints("kernel_shape", [s.k, s.k]),
                  attr_ints("pads", [s.pad] * 4), attr_ints("strides", [s.stride, s.stride])]
-        wn, bn_, out = f"{name}.weight", f"{name}.bias", f"conv_{i}"
-        if unfold_bn and s.has_bn:
+        wn, bn_, out = f"{name}.weight", f"{name}.bias", fresh("conv")
+        if external == name:
+            inits.append(tensor_external(wn, w.shape))
+            inits.append(tensor(bn_, b, raw, packed_dims))
+            emit(conv_op, [x, wn, bn_], [out], attrs)
+        elif unfold_bn and s.has_bn:
             gamma = (0.5 + rng.random(s.cout)).astype(np.float32)
             var = (0.5 + rng.random(s.cout)).astype(np.float32)
             mean = ((rng.random(s.cout) - 0.5) * 0.2).astype(np.float32)
@@ -104,26 +154,121 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
             w_raw = (rng.standard_normal(w.shape) * 0.05).astype(np.float32)
             bn_params[name] = (w_raw, gamma, beta, mean, var)
             inits.append(tensor(wn, w_raw, raw, packed_dims))
-            g += f_bytes(1, node(conv_op, [prev, wn], [out], attrs))
+            emit(conv_op, [x, wn], [out], attrs)
             names = [f"{name}.bn.{k}" for k in ("weight", "bias", "running_mean", "running_var")]
             for nm, arr in zip(names, (gamma, beta, mean, var)):
                 inits.append(tensor(nm, arr, raw, packed_dims))
-            g += f_bytes(1, node("BatchNormalization", [out] + names, [out + "_bn"], [attr_float("epsilon", 1e-5)]))
+            emit("BatchNormalization", [out] + names, [out + "_bn"], [attr_float("epsilon", 1e-5)])
             out = out + "_bn"
         else:
-            inits.append(tensor(wn, w, raw, packed_dims))
+            if const_nodes and name == "backbone.layer1.0.conv1":  # weights as a Constant node instead of an initializer
+                emit("Constant", [], [wn], [attr_tensor("value", tensor(wn, w, raw, packed_dims))])
+            else:
+                inits.append(tensor(wn, w, raw, packed_dims))
             inits.append(tensor(bn_, b, raw, packed_dims))
-            g += f_bytes(1, node(conv_op, [prev, wn, bn_], [out], attrs))
-        if s.relu:
-            g += f_bytes(1, node("Relu", [out], [out + "_relu"]))
-            out = out + "_relu"
-        prev = out
+            emit(conv_op, [x, wn, bn_], [out], attrs)
+        return out
+
+    def relu(x, tag):
+        if missing_relu == tag:
+            return x
+        o = fresh("relu")
+        emit("Relu", [x], [o])
+        return passthrough(o)
+
+    # ---- backbone ----
+    x = relu(conv("backbone.conv1", "input"), "stem")
+    o = fresh("pool")
+    emit("MaxPool", [x], [o], [attr_ints("kernel_shape", [3, 3]), attr_ints("pads", [1, 1, 1, 1]), attr_ints("strides", [2, 2]),
+                                attr_int("ceil_mode", 0)])
+    x = o
+    l3 = None
+    blocks = sorted({s.name.rsplit(".", 1)[0] for s, _ in items if s.role == "conv1"}, key=lambda p: [int(v) if v.isdigit() else v for v in p.replace("layer", "layer.").split(".")])
+    for p in blocks:
+        start = len(nodes)
+        ds_nodes = (0, 0)
+        t = relu(conv(p + ".conv1", x), p + ".conv1")
+        t = relu(conv(p + ".conv2", t), p + ".conv2")
+        t = conv(p + ".conv3", t)
+        idt = x
+        if (p + ".downsample.0") in by_name:
+            d0 = len(nodes)
+            idt = conv(p + ".downsample.0", x)
+            ds_nodes = (d0, len(nodes))
+        if order == "ds_first" and ds_nodes[1] > ds_nodes[0]:
+            blk = nodes[start:]
+            ds = blk[ds_nodes[0] - start:ds_nodes[1] - start]
+            rest = blk[:ds_nodes[0] - start] + blk[ds_nodes[1] - start:]
+            nodes[start:] = ds + rest
+        if t is None:
+            break
+        a = fresh("add")
+        emit("Add", [t, idt] if rng.random() < 0.5 else [idt, t], [a])
+        x = relu(a, p + ".out")
+        if p.startswith("backbone.layer3."):
+            l3 = x
+
+    def head(prefix, feat, out_name):
+        h = conv(prefix + ".0", feat)
+        if h is None:
+            return
+        h = relu(h, prefix + ".0")
+        if dropout:
+            d, m = fresh("drop"), fresh("mask")
+            emit("Dropout", [h], [d, m])
+            h = d
+        lo = conv(prefix + ".4", h)
+        if lo is None:
+            return
+        if resize_subgraph:  # sizes = concat(shape(lo)[:2], shape(input)[2:]) built from Shape/Gather/Unsqueeze/Concat
+            shp, sl = fresh("shape"), fresh("slice")
+            emit("Shape", [lo], [shp])
+            for nm, v in ((sl + "_s", [0]), (sl + "_e", [2]), (sl + "_a", [0])):
+                emit("Constant", [], [nm], [attr_tensor("value", tensor_i64(nm, v))])
+            emit("Slice", [shp, sl + "_s", sl + "_e", sl + "_a"], [sl])
+            dims = []
+            for ax in (2, 3):
+                ishp, gi, g, u = fresh("ishape"), fresh("gidx"), fresh("gather"), fresh("unsq")
+                emit("Shape", ["input"], [ishp])
+                emit("Constant", [], [gi], [attr_tensor("value", tensor_i64(gi, ax))])
+                emit("Gather", [ishp, gi], [g], [attr_int("axis", 0)])
+                emit("Unsqueeze", [g], [u], [attr_ints("axes", [0])])
+                dims.append(u)
+            cc, cast, sizes = fresh("concat"), fresh("cast"), fresh("sizes")
+            emit("Concat", dims, [cc], [attr_int("axis", 0)])
+            emit("Cast", [cc], [cast], [attr_int("to", 7)])
+            emit("Concat", [sl, cast], [sizes], [attr_int("axis", 0)])
+            roi, scales = fresh("roi"), fresh("scales")
+            emit("Constant", [], [roi], [attr_tensor("value", tensor(roi, np.zeros((0,), np.float32)))])
+            emit("Constant", [], [scales], [attr_tensor("value", tensor(scales, np.zeros((0,), np.float32)))])
+            rin = [lo, roi, scales, sizes]
+        else:
+            inits.append(tensor(out_name + ".scales", np.array([1, 1, 8, 8], np.float32)))
+            rin = [lo, "", out_name + ".scales"]
+        attrs = [attr_str("mode", resize_mode)]
+        if coord_mode is not None:
+            attrs.append(attr_str("coordinate_transformation_mode", coord_mode))
+        emit("Resize" if opset >= 10 else "Upsample", rin, [out_name], attrs)
+
+    onames = ("aux", "out") if swap_outputs else ("out", "aux")
+    head("classifier", x, onames[0])
+    head("aux_classifier", l3, onames[1])
+    if extra_conv:  # a conv that is not part of FCN-ResNet hanging off the graph
+        w = np.zeros((4, 21, 1, 1), np.float32)
+        inits.append(tensor("extra.weight", w))
+        emit("Conv", ["out", "extra.weight"], ["extra_out"], [attr_ints("kernel_shape", [1, 1])])
+
+    if order == "shuffled":
+        perm = rng.permutation(len(nodes))
+        nodes = [nodes[i] for i in perm]
+    g = b"".join(nodes)
     g += f_str(2, "torch-jit-export")
     g += b"".join(f_bytes(5, t) for t in inits)
     g += f_bytes(11, value_info("input", input_type, input_dims))
     if inits_as_inputs:  # IR < 4 exporters list every initializer as a graph input too
-        g += f_bytes(11, value_info("backbone.conv1.weight", 1, (64, 3, 7, 7)))
+        g = f_bytes(11, value_info("backbone.conv1.weight", 1, (64, 3, 7, 7))) + g
+        g += f_bytes(11, value_info("classifier.4.bias", 1, (21,)))
     g += f_bytes(12, value_info("out", 1, ("N", 21, "H", "W")))
     g += f_bytes(12, value_info("aux", 1, ("N", 21, "H", "W")))
-    model = f_varint(1, 6) + f_str(2, "pytorch") + f_bytes(7, g) + f_bytes(8, f_str(1, "") + f_varint(2, 12))
+    model = f_varint(1, 6) + f_str(2, "pytorch") + f_bytes(7, g) + f_bytes(8, f_str(1, "") + f_varint(2, opset))
     return model, bn_params

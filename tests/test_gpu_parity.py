@@ -334,9 +334,10 @@ def test_frame_advance_scaled_equals_unfused(ctx, model, oracle):
         assert (rgba == c_out.value).all()
 
 
-@pytest.mark.parametrize("wh", [(1920, 1080), (960, 540)])
+@pytest.mark.parametrize("wh", [(1920, 1080), (960, 540), (640, 480)])
 def test_full_size_properties(ctx, model, oracle, blob50, wh):
-    """BASELINE configs C2/C3 at full size: determinism, fused == unfused, logits vs torch-CPU oracle."""
+    """BASELINE configs C2/C3 at full size and configs[0]'s 640x480 clip frame: determinism, fused == unfused, logits vs
+    the torch-CPU oracle."""
     from oracle.infur_oracle import TorchModel
 
     w, h = wh

@@ -88,3 +88,86 @@ def test_wrong_conv_attributes_are_rejected(lib, tensors50):
     model, _ = OW.fcn_model(tensors50, bad)
     rc, err, _ = convert(lib, model)
     assert rc == _lib.E_MODEL_FORMAT and "layer1.1.conv2" in err
+
+
+# ---- round 2: slots come from the graph's edges, and real exporter output has more than Conv/Relu ----
+def _same_blob(a: bytes, b: bytes):
+    (ma, ta), (mb, tb) = W.unpack_blob(a), W.unpack_blob(b)
+    assert ma == mb
+    for (n0, w0, b0), (n1, w1, b1) in zip(ta, tb):
+        assert n0 == n1 and (w0.view(np.uint32) == w1.view(np.uint32)).all() and (b0.view(np.uint32) == b1.view(np.uint32)).all(), n0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(order="ds_first"),                       # downsample serialised before conv1..conv3 (layer1.0: same shape as conv3)
+    dict(order="shuffled"),                       # any node order
+    dict(dropout=True, identities=True),          # Dropout / Identity nodes between layers
+    dict(resize_subgraph=False),                  # constant `scales` instead of the Shape/Gather/Concat size arithmetic
+    dict(coord_mode="half_pixel"),
+    dict(coord_mode=None),                        # attribute absent: half_pixel is the opset-11 default
+    dict(const_nodes=True, inits_as_inputs=True),  # weights in a Constant node; initializers listed as graph inputs
+    dict(order="shuffled", unfold_bn=False, dropout=True, identities=True, raw=False, packed_dims=False),
+])
+def test_slots_follow_the_topology_not_the_node_order(lib, blob50, tensors50, kw):
+    """conv3 and downsample.0 of layer1.0 are both [256,64,1,1] s1 p0 -- a file that serialises them in
+    the other order must still put each weight set in its own slot."""
+    model, _ = OW.fcn_model(tensors50, W.graph(50), rng=np.random.default_rng(7), **kw)
+    rc, err, out = convert(lib, model)
+    assert rc == 0, err
+    _same_blob(out, blob50)
+
+
+def test_unfolded_bn_in_any_order(lib, tensors50):
+    specs = W.graph(50)
+    m0, _ = OW.fcn_model(tensors50, specs, unfold_bn=True, rng=np.random.default_rng(3))
+    m1, _ = OW.fcn_model(tensors50, specs, unfold_bn=True, rng=np.random.default_rng(3), order="ds_first")
+    (rc0, e0, b0), (rc1, e1, b1) = convert(lib, m0), convert(lib, m1)
+    assert rc0 == 0 and rc1 == 0, (e0, e1)
+    _same_blob(b0, b1)
+
+
+def test_model_without_aux_head_and_resnet101_shape(lib):
+    t = W.unpack_blob(W.synth_blob(aux=False))[1]
+    model, _ = OW.fcn_model(t, W.graph(50, aux=False), order="shuffled")
+    rc, err, out = convert(lib, model)
+    assert rc == 0, err
+    assert W.unpack_blob(out)[0] == {"depth": 50, "num_classes": 21, "aux": False, "n_convs": 55}
+
+
+def test_graphs_that_are_not_fcn_resnet_are_rejected(lib, tensors50):
+    g = W.graph(50)
+    cases = [
+        (dict(resize_mode="nearest"), "Resize mode must be linear"),
+        (dict(coord_mode="align_corners"), "coordinate_transformation_mode 'align_corners'"),
+        (dict(coord_mode="asymmetric"), "coordinate_transformation_mode"),
+        (dict(opset=10), "opset 10"),
+        (dict(opset=9), "Upsample"),
+        (dict(swap_outputs=True), "graph output #0"),
+        (dict(missing_relu="backbone.layer2.1.conv2"), "backbone.layer2.1"),
+        (dict(missing_relu="backbone.layer3.0.out"), "Relu"),
+        (dict(missing_relu="stem"), "Relu"),
+        (dict(missing_relu="classifier.0"), "classifier"),
+        (dict(external="backbone.layer4.0.conv2"), "external_data"),
+        (dict(extra_conv=True), "Conv nodes"),
+    ]
+    for kw, msg in cases:
+        model, _ = OW.fcn_model(tensors50, g, **kw)
+        rc, err, _ = convert(lib, model)
+        assert rc == _lib.E_MODEL_FORMAT and msg in err, (kw, err)
+
+
+def test_hostile_tensor_dims_do_not_reach_an_allocation(lib):
+    """negative / overflowing dims in an initializer are a format error, not a bad_alloc through the C ABI."""
+    dims = [(-1, 3, 7, 7), (2 ** 40, 2 ** 40, 7, 7), (0, 3, 7, 7)]
+    for d in dims:
+        body = OW.f_bytes(1, b"".join(OW._varint(x) for x in d)) + OW.f_varint(2, 1) + OW.f_bytes(9, b"\0" * 16) + OW.f_str(8, "w")
+        nodes = OW.f_bytes(1, OW.node("Conv", ["input", "w"], ["y"], [OW.attr_ints("kernel_shape", [7, 7])]))
+        g = nodes + OW.f_bytes(5, body) + OW.f_bytes(11, OW.value_info("input", 1, ("N", 3, "H", "W"))) + OW.f_bytes(12, OW.value_info("y", 1, ("N", 64, "H", "W")))
+        model = OW.f_varint(1, 6) + OW.f_bytes(7, g) + OW.f_bytes(8, OW.f_str(1, "") + OW.f_varint(2, 12))
+        rc, err, _ = convert(lib, model)
+        assert rc == _lib.E_MODEL_FORMAT, (d, err)
+    # truncated length prefixes / random bytes after a valid header
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        junk = b"\x08\x06" + bytes(rng.integers(0, 256, int(rng.integers(1, 200)), dtype=np.uint8))
+        assert convert(lib, junk)[0] == _lib.E_MODEL_FORMAT
