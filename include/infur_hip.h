@@ -86,6 +86,8 @@ typedef struct infur_options {
                                   (results are bit-identical across configurations); 1: fixed heuristic */
     uint32_t no_fuse_downsample; /* 0 (default): the first block of a stage runs conv3 and its downsample branch as one
                                   two-source GEMM (the branch tensor is never written); 1: two launches + residual */
+    uint32_t no_fuse_stem_pool; /* 0 (default): the 7x7 stem convolution and the 3x3/2 max-pool run as one kernel (the stem
+                                  tensor is never written); 1: two kernels.  Results are bit-identical. */
     void* stream;          /* optional caller-owned hipStream_t; NULL = context creates one */
 } infur_options;
 

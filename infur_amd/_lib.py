@@ -45,6 +45,7 @@ class Options(C.Structure):
         ("winograd_tile", C.c_uint32),
         ("no_autotune", C.c_uint32),
         ("no_fuse_downsample", C.c_uint32),
+        ("no_fuse_stem_pool", C.c_uint32),
         ("stream", C.c_void_p),
     ]
 

@@ -657,20 +657,30 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     size_t ci = 0;
     const ConvLayer& stem = c->convs[ci++];
     Tensor s, x;
-    {
-        const int oh = conv_out(h, 7, 2, 3, 1), ow = conv_out(w, 7, 2, 3, 1);
-        RETIF(talloc(c, oh, ow, 64, act_es(c), &s));
-        ProfScope ps(c, stem.name, "stem_conv7x7", 2.0 * oh * ow * 64 * 147, (double)h * w * 3 + (double)s.bytes());
-        HIPCHK(c, launch_stem_conv7x7(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, c->d_pre_lut, s.p, ctx_f16(c) ? 1 : 0, oh, ow, c->stream));
+    const int sh = conv_out(h, 7, 2, 3, 1), sw = conv_out(w, 7, 2, 3, 1);
+    const int ph = conv_out(sh, 3, 2, 1, 1), pw = conv_out(sw, 3, 2, 1, 1);
+    // stem and max-pool as one kernel unless the per-layer read-back wants the stem tensor (keep_activations) or
+    // the caller asked for the two-kernel form (options.no_fuse_stem_pool: a test / measurement knob)
+    if (!c->opt.keep_activations && !c->opt.no_fuse_stem_pool) {
+        RETIF(talloc(c, ph, pw, 64, act_es(c), &x));
+        ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes(),
+                     2.0 * sh * sw * 64 * 147);
+        HIPCHK(c, launch_stem_pool(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, c->d_pre_lut, x.p, ctx_f16(c) ? 1 : 0, sh, sw, ph, pw,
+                                   c->d_range, c->stream));
+    } else {
+        {
+            RETIF(talloc(c, sh, sw, 64, act_es(c), &s));
+            ProfScope ps(c, stem.name, "stem_conv7x7", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)s.bytes());
+            HIPCHK(c, launch_stem_conv7x7(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, c->d_pre_lut, s.p, ctx_f16(c) ? 1 : 0, sh, sw, c->stream));
+        }
+        if (c->opt.keep_activations) c->kept.push_back(s);
+        {
+            RETIF(talloc(c, ph, pw, 64, act_es(c), &x));
+            ProfScope ps(c, "backbone.maxpool", "maxpool3x3s2", 0, (double)s.bytes() + (double)x.bytes());
+            HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, x.p, ctx_f16(c) ? 1 : 0, ph, pw, c->d_range, c->stream));
+        }
+        pool_release(c, s);
     }
-    if (c->opt.keep_activations) c->kept.push_back(s);
-    {
-        const int oh = conv_out(s.h, 3, 2, 1, 1), ow = conv_out(s.w, 3, 2, 1, 1);
-        RETIF(talloc(c, oh, ow, 64, act_es(c), &x));
-        ProfScope ps(c, "backbone.maxpool", "maxpool3x3s2", 0, (double)s.bytes() + (double)x.bytes());
-        HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, x.p, ctx_f16(c) ? 1 : 0, oh, ow, c->d_range, c->stream));
-    }
-    pool_release(c, s);
 
     Tensor l3;
     while (c->convs[ci].role == '1') {

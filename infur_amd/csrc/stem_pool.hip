@@ -136,6 +136,189 @@ hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt
 }
 
 // ---------------------------------------------------------------------------------------
+// stem + max-pool fused: the 7x7/2 convolution's output (132.7 MB at 1080p) is never written.
+// A workgroup owns a 5 x 11 tile of POOLED pixels; their 3x3/2 windows cover 11 x 23 = 253 stem pixels (one halo
+// row/column recomputed: 1.15x the MFMA work of the unfused stem), which are exactly 8 M-blocks of 32 -- two per
+// wave, the same 2 x 2 accumulator tiles as stem_conv7x7_kernel, the same k order (bit-identical values).  The
+// stem tile (+bias, ReLU) goes to LDS -- over the then idle input patch and weights -- and is max-pooled from there;
+// stem pixels outside the image are skipped, as MaxPool's -inf padding does.
+// ---------------------------------------------------------------------------------------
+constexpr int SP_PR = 5, SP_PC = 11;
+constexpr int SP_SR = 2 * SP_PR + 1, SP_SC = 2 * SP_PC + 1;  // 11 x 23 stem pixels
+constexpr int SP_NPIX = SP_SR * SP_SC;                       // 253
+constexpr int SP_IH = 2 * SP_SR + 5, SP_IW = 2 * SP_SC + 5;  // 27 x 51 input pixels
+constexpr int SP_STAGE = 68;                                 // floats per staged stem pixel (64 + pad: conflict-free b128 writes)
+constexpr int SP_PATCH = SP_IH * SP_IW * 3;
+constexpr int SP_LDS_FLOATS = (SP_PATCH + ST_KP * 64 + 768) > 256 * SP_STAGE ? (SP_PATCH + ST_KP * 64 + 768) : 256 * SP_STAGE;  // patch, weights, LUT | stem tile
+static_assert(SP_NPIX <= 256 && SP_NPIX > 224, "the stem tile must fill 8 M-blocks of 32");
+
+__host__ __device__ constexpr int sp_koff(int k) { return (k / 21) * (SP_IW * 3) + (k % 21); }
+
+template <typename OutT>
+__global__ void __launch_bounds__(256, 2)
+    stem_pool_kernel(const uint8_t* __restrict__ bgr, int H, int W, const float* __restrict__ wt, const float* __restrict__ bias,
+                     const float* __restrict__ lut, OutT* __restrict__ out, int SH, int SW, int PH, int PW,
+                     unsigned* __restrict__ amax) {
+    __shared__ __attribute__((aligned(16))) float smem[SP_LDS_FLOATS];
+    float* patch = smem;
+    float* wsm = smem + SP_PATCH;
+    const int tid = threadIdx.x;
+    const int py0 = blockIdx.y * SP_PR, px0 = blockIdx.x * SP_PC;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;  // first stem pixel of the tile (may be -1: outside)
+    const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;
+
+    // Prologue built for latency: every global load of the workgroup's inputs is issued before the first one is
+    // used (frame bytes, the 3 KB look-up table, the 38 KB of weights); the table goes to LDS so that the
+    // byte -> normalised value look-ups are LDS gathers instead of a second dependent trip to L2.  (With plain loops
+    // the prologue was ~20 us of serial L2 round trips per workgroup against 8 us of MFMA work.)
+    float* slut = smem + SP_LDS_FLOATS - 768;  // top of the allocation: overwritten only by the stem tile, after the barrier
+    constexpr int NPX = (SP_IH * SP_IW + 255) / 256;  // 6 frame pixels per thread
+    constexpr int NW4 = (ST_KP * 64 / 4 + 255) / 256;  // 10 float4 of weights per thread
+    uint8_t pb[NPX][3];
+    bool pin[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; j++) {
+        const int i = tid + 256 * j;
+        const int r = i / SP_IW, q = i - r * SP_IW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        pin[j] = i < SP_IH * SP_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const uint8_t* p = bgr + ((size_t)(pin[j] ? iy : 0) * W + (pin[j] ? ix : 0)) * 3;
+        pb[j][0] = p[0];
+        pb[j][1] = p[1];
+        pb[j][2] = p[2];
+    }
+    float4 w4[NW4];
+#pragma unroll
+    for (int j = 0; j < NW4; j++) {
+        const int i = tid + 256 * j;
+        w4[j] = make_float4(0.f, 0.f, 0.f, 0.f);  // row 147: the zero row that pads K to a multiple of 2
+        if (i < ST_K * 64 / 4) w4[j] = reinterpret_cast<const float4*>(wt)[i];
+    }
+    const float l0 = lut[tid], l1 = lut[tid + 256], l2 = lut[tid + 512];
+    slut[tid] = l0;
+    slut[tid + 256] = l1;
+    slut[tid + 512] = l2;
+#pragma unroll
+    for (int j = 0; j < NW4; j++) {
+        const int i = tid + 256 * j;
+        if (i < ST_KP * 64 / 4) reinterpret_cast<float4*>(wsm)[i] = w4[j];
+    }
+    __syncthreads();  // the table is in LDS
+#pragma unroll
+    for (int j = 0; j < NPX; j++) {
+        const int i = tid + 256 * j;
+        if (i >= SP_IH * SP_IW) continue;
+        // zero padding of the NORMALISED tensor outside the frame
+        patch[i * 3 + 0] = pin[j] ? slut[0 * 256 + pb[j][2]] : 0.f;  // R
+        patch[i * 3 + 1] = pin[j] ? slut[1 * 256 + pb[j][1]] : 0.f;  // G
+        patch[i * 3 + 2] = pin[j] ? slut[2 * 256 + pb[j][0]] : 0.f;  // B
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int px = lane & 31, half = lane >> 5;
+    f32x16s acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // a lane's two stem pixels: linear index over the 11 x 23 tile; slots 253..255 recompute pixel 252 (never used)
+    int pidx[2];
+    const float* pa[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        pidx[i] = (2 * wave + i) * 32 + px;
+        const int p = pidx[i] < SP_NPIX ? pidx[i] : SP_NPIX - 1;
+        const int r = p / SP_SC, c = p - r * SP_SC;
+        pa[i] = patch + ((2 * r) * SP_IW + 2 * c) * 3;
+    }
+    const float* pw = wsm + half * 64 + px;
+#pragma unroll
+    for (int s = 0; s < ST_KP / 2; s++) {
+        constexpr int kLast = ST_K - 1;
+        const int k0 = 2 * s, k1 = 2 * s + 1 > kLast ? kLast : 2 * s + 1;
+        const int off = half ? sp_koff(k1) : sp_koff(k0);
+        const float a0 = pa[0][off], a1 = pa[1][off];
+        const float b0 = pw[(2 * s) * 64], b1 = pw[(2 * s) * 64 + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the patch and the weights: their LDS becomes the stem tile
+
+    float* stage = smem;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float* o = stage + pidx[i] * SP_STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = j * 32 + 8 * g + 4 * half;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+                float4 v;
+                v.x = fmaxf(acc[i][j][4 * g + 0] + b4.x, 0.f);
+                v.y = fmaxf(acc[i][j][4 * g + 1] + b4.y, 0.f);
+                v.z = fmaxf(acc[i][j][4 * g + 2] + b4.z, 0.f);
+                v.w = fmaxf(acc[i][j][4 * g + 3] + b4.w, 0.f);
+                if constexpr (sizeof(OutT) == 2) {  // the unfused path stores the stem output as f16: round here, max after
+                    v.x = (float)(_Float16)v.x; v.y = (float)(_Float16)v.y; v.z = (float)(_Float16)v.z; v.w = (float)(_Float16)v.w;
+                }
+                *reinterpret_cast<float4*>(o + n) = v;
+            }
+    }
+    __syncthreads();
+
+    float vmax = 0.f;
+    for (int it = tid; it < SP_PR * SP_PC * 16; it += 256) {
+        const int c4 = it & 15, pp = it >> 4;
+        const int pr = pp / SP_PC, pc = pp - pr * SP_PC;
+        const int py = py0 + pr, pxo = px0 + pc;
+        if (py >= PH || pxo >= PW) continue;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const int sr = 2 * pr + dy;  // stem row inside the tile; absolute row sy0 + sr
+            if ((unsigned)(sy0 + sr) >= (unsigned)SH) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const int sc = 2 * pc + dx;
+                if ((unsigned)(sx0 + sc) >= (unsigned)SW) continue;
+                const float4 v = *reinterpret_cast<const float4*>(stage + (sr * SP_SC + sc) * SP_STAGE + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        OutT* o = out + ((size_t)py * PW + pxo) * 64 + c4 * 4;
+        if constexpr (sizeof(OutT) == 4) {
+            *reinterpret_cast<float4*>(o) = m;
+        } else {
+            f16x4 hv = {(_Float16)m.x, (_Float16)m.y, (_Float16)m.z, (_Float16)m.w};
+            *reinterpret_cast<f16x4*>(o) = hv;
+        }
+        vmax = fmaxf(vmax, fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w)));
+    }
+    if (amax) {  // range monitor of the split mode (pooled values are >= 0)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(vmax));
+    }
+}
+
+hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const float* bias, const float* lut, void* out,
+                            int f16, int SH, int SW, int PH, int PW, unsigned* amax, hipStream_t s) {
+    dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
+    if (f16)
+        hipLaunchKernelGGL(stem_pool_kernel<_Float16>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (_Float16*)out, SH, SW, PH, PW, amax);
+    else
+        hipLaunchKernelGGL(stem_pool_kernel<float>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW, amax);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // maxpool 3x3 / 2, pad 1, NHWC: one thread = one output pixel x 4 channels
 // ---------------------------------------------------------------------------------------
 template <typename T, typename V4>

@@ -17,6 +17,8 @@
 // Dilation: the output grid splits into d x d interleaved sub-grids (oy = d*y' + ry); on each the
 // dilated conv is an ordinary 3x3 / pad-1 conv over the equally sub-sampled input, so a tile is
 // (ry, rx, ty, tx) and its (m+2)^2 input patch sits at rows d*(m*ty - 1 + i) + ry.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace infur {
@@ -36,23 +38,25 @@ __device__ __forceinline__ void tile_coords(const WinoGeom& g, int t, int& ry, i
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
 
 // 1-D transforms on strided arrays of vectors (all loops unrolled; S = element stride)
-template <int MT, int S, typename V>
-__device__ __forceinline__ void bt_1d(const V* d, V* t) {  // B^T d : (MT+2) -> (MT+2)
+template <int MT, int S, int SO = S, typename V>
+__device__ __forceinline__ void bt_1d(const V* d, V* t) {  // B^T d : (MT+2) -> (MT+2); S / SO = input / output stride
     if constexpr (MT == 2) {
-        t[0 * S] = d[0 * S] - d[2 * S];
-        t[1 * S] = d[1 * S] + d[2 * S];
-        t[2 * S] = d[2 * S] - d[1 * S];
-        t[3 * S] = d[1 * S] - d[3 * S];
+        const V d0 = d[0 * S], d1 = d[1 * S], d2 = d[2 * S], d3 = d[3 * S];
+        t[0 * SO] = d0 - d2;
+        t[1 * SO] = d1 + d2;
+        t[2 * SO] = d2 - d1;
+        t[3 * SO] = d1 - d3;
     } else {
         const V d0 = d[0 * S], d1 = d[1 * S], d2 = d[2 * S], d3 = d[3 * S], d4 = d[4 * S], d5 = d[5 * S];
-        t[0 * S] = 4.0f * d0 - 5.0f * d2 + d4;
-        t[1 * S] = -4.0f * d1 - 4.0f * d2 + d3 + d4;
-        t[2 * S] = 4.0f * d1 - 4.0f * d2 - d3 + d4;
-        t[3 * S] = -2.0f * d1 - d2 + 2.0f * d3 + d4;
-        t[4 * S] = 2.0f * d1 - d2 - 2.0f * d3 + d4;
-        t[5 * S] = 4.0f * d1 - 5.0f * d3 + d5;
+        t[0 * SO] = 4.0f * d0 - 5.0f * d2 + d4;
+        t[1 * SO] = -4.0f * d1 - 4.0f * d2 + d3 + d4;
+        t[2 * SO] = 4.0f * d1 - 4.0f * d2 - d3 + d4;
+        t[3 * SO] = -2.0f * d1 - d2 + 2.0f * d3 + d4;
+        t[4 * SO] = 2.0f * d1 - d2 - 2.0f * d3 + d4;
+        t[5 * SO] = 4.0f * d1 - 5.0f * d3 + d5;
     }
 }
 
@@ -87,13 +91,16 @@ __device__ __forceinline__ void g_1d(float g0, float g1, float g2, float* u) {  
     }
 }
 
-// ---- input transform: one thread = one tile x 2 channels ----
-template <int MT>
+// ---- input transform: one thread = one tile x VW channels (VW = 4: 16-byte accesses; VW = 2 for C % 4 != 0) ----
+// All (m+2)^2 patch loads are issued first (they are independent: 36 x 16 bytes in flight per lane), the column
+// pass runs in place, the row pass stores each transformed row as soon as it is complete.
+template <int MT, typename VT>
 __global__ void __launch_bounds__(256)
     wino_input_kernel(const float* __restrict__ in, WinoGeom g, int C, int T, float* __restrict__ V, unsigned* __restrict__ amax) {
+    constexpr int VW = sizeof(VT) / 4;
     float vmax = 0.f;
     constexpr int AL = MT + 2;
-    const int cvn = C >> 1;
+    const int cvn = C / VW;
     const size_t total = (size_t)T * cvn;
     const size_t plane = (size_t)T * C;  // floats per xi plane
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -101,28 +108,37 @@ __global__ void __launch_bounds__(256)
         const int t = (int)(i / cvn);
         int ry, rx, ty, tx;
         tile_coords(g, t, ry, rx, ty, tx);
-        f32x2 d[AL * AL], r[AL * AL];
+        VT d[AL * AL];
 #pragma unroll
         for (int a = 0; a < AL; a++) {
             const int y = g.d * (MT * ty - 1 + a) + ry;
 #pragma unroll
             for (int b = 0; b < AL; b++) {
                 const int x = g.d * (MT * tx - 1 + b) + rx;
-                f32x2 v = {0.f, 0.f};
+                VT v = {};
                 if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
-                    v = *reinterpret_cast<const f32x2*>(in + ((size_t)y * g.W + x) * C + cv * 2);
+                    v = *reinterpret_cast<const VT*>(in + ((size_t)y * g.W + x) * C + cv * VW);
                 d[a * AL + b] = v;
             }
         }
 #pragma unroll
-        for (int b = 0; b < AL; b++) bt_1d<MT, AL>(d + b, r + b);      // columns: B^T d
+        for (int b = 0; b < AL; b++) {  // columns: B^T d, in place
+            VT col[AL];
+            bt_1d<MT, AL, 1>(d + b, col);
 #pragma unroll
-        for (int a = 0; a < AL; a++) bt_1d<MT, 1>(r + a * AL, d + a * AL);  // rows: (.) B
-        float* o = V + (size_t)t * C + cv * 2;
+            for (int a = 0; a < AL; a++) d[a * AL + b] = col[a];
+        }
+        float* o = V + (size_t)t * C + cv * VW;
 #pragma unroll
-        for (int xi = 0; xi < AL * AL; xi++) {
-            *reinterpret_cast<f32x2*>(o + (size_t)xi * plane) = d[xi];
-            vmax = fmaxf(vmax, fmaxf(fabsf(d[xi].x), fabsf(d[xi].y)));
+        for (int a = 0; a < AL; a++) {  // rows: (.) B, stored as they complete
+            VT row[AL];
+            bt_1d<MT, 1>(d + a * AL, row);
+#pragma unroll
+            for (int b = 0; b < AL; b++) {
+                *reinterpret_cast<VT*>(o + (size_t)(a * AL + b) * plane) = row[b];
+#pragma unroll
+                for (int e = 0; e < VW; e++) vmax = fmaxf(vmax, fabsf(row[b][e]));
+            }
         }
     }
     if (amax) {  // range monitor of the split mode: max |V|, one atomic per wave
@@ -132,14 +148,17 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// ---- output transform: one thread = one tile x 2 output channels; + bias, ReLU ----
-template <int MT>
+// ---- output transform: one thread = one tile x VW output channels; + bias, ReLU ----
+// The (m+2)^2 plane loads are issued first; the column pass A^T m reduces them to m x (m+2) in place, the row pass
+// emits one output row at a time.
+template <int MT, typename VT>
 __global__ void __launch_bounds__(256)
     wino_output_kernel(const float* __restrict__ M, WinoGeom g, int Cout, int T, const float* __restrict__ bias,
                        int relu, float* __restrict__ out, unsigned* __restrict__ amax) {
+    constexpr int VW = sizeof(VT) / 4;
     float vmax = 0.f;
     constexpr int AL = MT + 2;
-    const int nvn = Cout >> 1;
+    const int nvn = Cout / VW;
     const size_t total = (size_t)T * nvn;
     const size_t plane = (size_t)T * Cout;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -147,30 +166,30 @@ __global__ void __launch_bounds__(256)
         const int t = (int)(i / nvn);
         int ry, rx, ty, tx;
         tile_coords(g, t, ry, rx, ty, tx);
-        const float* mp = M + (size_t)t * Cout + nv * 2;
-        f32x2 m[AL * AL], s[MT * AL], yv[MT * MT];
+        const float* mp = M + (size_t)t * Cout + nv * VW;
+        VT m[AL * AL], s[MT * AL];
 #pragma unroll
-        for (int xi = 0; xi < AL * AL; xi++) m[xi] = *reinterpret_cast<const f32x2*>(mp + (size_t)xi * plane);
+        for (int xi = 0; xi < AL * AL; xi++) m[xi] = *reinterpret_cast<const VT*>(mp + (size_t)xi * plane);
 #pragma unroll
         for (int b = 0; b < AL; b++) at_1d<MT, AL>(m + b, s + b);        // columns: A^T m  -> [MT][AL]
-#pragma unroll
-        for (int a = 0; a < MT; a++) at_1d<MT, 1>(s + a * AL, yv + a * MT);  // rows: (.) A -> [MT][MT]
-        const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + nv * 2);
+        const VT bv = *reinterpret_cast<const VT*>(bias + nv * VW);
 #pragma unroll
         for (int a = 0; a < MT; a++) {
+            VT yv[MT];
+            at_1d<MT, 1>(s + a * AL, yv);  // rows: (.) A -> [MT]
             const int y = g.d * (MT * ty + a) + ry;
             if (y >= g.H) continue;
 #pragma unroll
             for (int b = 0; b < MT; b++) {
                 const int x = g.d * (MT * tx + b) + rx;
                 if (x >= g.W) continue;
-                f32x2 v = yv[a * MT + b] + bv;
-                if (relu) {
-                    v.x = fmaxf(v.x, 0.f);
-                    v.y = fmaxf(v.y, 0.f);
+                VT v = yv[b] + bv;
+#pragma unroll
+                for (int e = 0; e < VW; e++) {
+                    if (relu) v[e] = fmaxf(v[e], 0.f);
+                    vmax = fmaxf(vmax, fabsf(v[e]));
                 }
-                *reinterpret_cast<f32x2*>(out + ((size_t)y * g.W + x) * Cout + nv * 2) = v;
-                vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+                *reinterpret_cast<VT*>(out + ((size_t)y * g.W + x) * Cout + nv * VW) = v;
             }
         }
     }
@@ -225,14 +244,25 @@ static unsigned grid_for(size_t work) {
     return (unsigned)blocks;
 }
 
+// test/measurement hook: INFUR_WINO_VEC=2 forces the 8-byte form
+static bool wino_vec4(int C) {
+    static const int forced = getenv("INFUR_WINO_VEC") ? atoi(getenv("INFUR_WINO_VEC")) : 0;
+    return (C & 3) == 0 && forced != 2;
+}
+
 hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, unsigned* amax, hipStream_t s) {
     const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
-    const unsigned blocks = grid_for((size_t)T * (C / 2));
-    if (mt == 2)
-        hipLaunchKernelGGL(wino_input_kernel<2>, dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
+    const bool v4 = wino_vec4(C);
+    const unsigned blocks = grid_for((size_t)T * (C / (v4 ? 4 : 2)));
+    if (mt == 2 && v4)
+        hipLaunchKernelGGL((wino_input_kernel<2, f32x4w>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
+    else if (mt == 2)
+        hipLaunchKernelGGL((wino_input_kernel<2, f32x2>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
+    else if (v4)
+        hipLaunchKernelGGL((wino_input_kernel<4, f32x4w>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
     else
-        hipLaunchKernelGGL(wino_input_kernel<4>, dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
+        hipLaunchKernelGGL((wino_input_kernel<4, f32x2>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
     return hipGetLastError();
 }
 
@@ -240,11 +270,16 @@ hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int
                               float* out, unsigned* amax, hipStream_t s) {
     const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
-    const unsigned blocks = grid_for((size_t)T * (Cout / 2));
-    if (mt == 2)
-        hipLaunchKernelGGL(wino_output_kernel<2>, dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
+    const bool v4 = wino_vec4(Cout);
+    const unsigned blocks = grid_for((size_t)T * (Cout / (v4 ? 4 : 2)));
+    if (mt == 2 && v4)
+        hipLaunchKernelGGL((wino_output_kernel<2, f32x4w>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
+    else if (mt == 2)
+        hipLaunchKernelGGL((wino_output_kernel<2, f32x2>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
+    else if (v4)
+        hipLaunchKernelGGL((wino_output_kernel<4, f32x4w>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
     else
-        hipLaunchKernelGGL(wino_output_kernel<4>, dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
+        hipLaunchKernelGGL((wino_output_kernel<4, f32x2>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
     return hipGetLastError();
 }
 

@@ -103,7 +103,8 @@ class Context:
 
     def __init__(self, device: int = 0, compute_aux: bool = True, profile: bool = False,
                  keep_activations: bool = False, stream: Optional[int] = None, dtype: str = "f32",
-                 winograd_min_cin: int = 0, winograd_tile: int = 0, autotune: bool = True, fuse_downsample: bool = True):
+                 winograd_min_cin: int = 0, winograd_tile: int = 0, autotune: bool = True, fuse_downsample: bool = True,
+                 fuse_stem_pool: bool = True):
         L = self.L = _lib.load()
         o = _lib.Options()
         L.infur_options_default(C.byref(o))
@@ -117,6 +118,7 @@ class Context:
         o.winograd_tile = winograd_tile  # 0 = default F(4x4,3x3), 2 = F(2x2,3x3)
         o.no_autotune = 0 if autotune else 1
         o.no_fuse_downsample = 0 if fuse_downsample else 1
+        o.no_fuse_stem_pool = 0 if fuse_stem_pool else 1
         o.stream = stream
         h = C.c_void_p(None)
         rc = L.infur_ctx_create(C.byref(o), C.byref(h))

@@ -27,6 +27,7 @@ pub struct infur_options {
     pub winograd_tile: u32,
     pub no_autotune: u32,
     pub no_fuse_downsample: u32,
+    pub no_fuse_stem_pool: u32,
     pub stream: *mut c_void,
 }
 

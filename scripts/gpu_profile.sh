@@ -1,15 +1,24 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/ on the GPU box (run through gpurun).
-#   bash scripts/gpu_profile.sh [dtype]  -> gpurun_out/prof[_dtype]/{trace,pmc_*}
+#   bash scripts/gpu_profile.sh [dtype] [tag] [extra bench.py args...]  -> gpurun_out/prof[_dtype][_tag]/{trace,pmc_*,smi.csv}
+#   e.g. bash scripts/gpu_profile.sh f16 4k --depth 101 --width 3840 --height 2160   (BASELINE configs[4])
 # --pmc passes are separate runs with --kernel-trace only (gpurun refuses other combinations).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 DT=${1:-f32}
-OUT=$R/gpurun_out/prof$([ $DT = f32 ] || echo _$DT)
+TAG=${2:-}
+shift; shift
+EXTRA="$@"
+OUT=$R/gpurun_out/prof$([ $DT = f32 ] || echo _$DT)$([ -z "$TAG" ] || echo _$TAG)
 rm -rf $OUT; mkdir -p $OUT
+# power / clock trace next to the counters (rocm-smi once per 200 ms while the trace run is alive): the evidence behind
+# any "the package clocks down under f16 MFMA load" statement in DESIGN.md
+( while true; do rocm-smi --showpower --showclocks --csv 2>/dev/null | tail -n +2 | sed "s/^/$(date +%s.%N),/"; sleep 0.2; done ) > $OUT/smi.csv &
+SMI=$!
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --dtype $DT --no-split --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --dtype $DT --no-split --no-side --no-cpu-baseline $EXTRA > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"
-SMALL="--dtype $DT --no-split --no-cpu-baseline --no-profile --steps 1 --warmup 1 --frames-per-step 2"
+kill $SMI 2>/dev/null
+SMALL="--dtype $DT --no-split --no-side --no-cpu-baseline --no-profile --steps 1 --warmup 1 --frames-per-step 2 $EXTRA"
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
   timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$P -- python $R/bench.py $SMALL > /dev/null 2> $OUT/pmc_$P.err; echo "pmc $P rc=$?"
 done

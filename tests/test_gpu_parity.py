@@ -369,9 +369,10 @@ def test_profile_records(blob50):
     # GEMM) + maxpool + fused post; the 11 stride-1 3x3 convs with Cin >= 256 (layer3 x6, layer4 x3, both
     # heads) run in the Winograd domain and add an input and an output transform each
     wino = [r for r in recs if r["kernel"] in ("wino_input", "wino_output")]
-    assert names[0] == "backbone.conv1" and names[-1] == "out.resize+colorcode"
+    # (the stem convolution and the max-pool are one kernel)
+    assert names[0] == "backbone.conv1+maxpool" and names[-1] == "out.resize+colorcode"
     assert sum(n.endswith("conv3+downsample") for n in names) == 4
-    assert len(wino) == 22 and len(recs) == 53 + 2 + len(wino)
+    assert len(wino) == 22 and len(recs) == 53 + 1 + len(wino)
     algo = sum(r["algo_flops"] for r in recs)
     assert abs(algo - W.conv_flops(96, 128)["total"]) < 1e-6 * algo
     assert sum(r["flops"] for r in recs) < algo  # Winograd executes 2.25x - 4x fewer MACs on those layers
@@ -473,3 +474,23 @@ def test_tiny_and_ragged_frames(ctx, model, oracle_model, wh):
     model.advance(fr, out)
     assert out[0].shape == (21, h, w)
     assert (out[0].view(np.uint32) == oracle_model.upsample_bilinear(lo, h, w).view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f32s"])
+def test_fused_stem_pool_is_bit_identical(blob50, dtype):
+    """stem 7x7/2 + max-pool 3x3/2 as one kernel (the 132.7 MB stem tensor is never written) == the two-kernel form,
+    bit for bit, at sizes that exercise ragged pooled tiles, odd stem extents and 1-pixel maps."""
+    lows = {}
+    sizes = [(64, 48), (97, 61), (5, 3), (1, 1), (130, 66), (320, 240), (175, 93)]
+    for fuse in (True, False):
+        with Context(device=0, dtype=dtype, fuse_stem_pool=fuse) as c:
+            m = Model(c).control(ModelCmd.LoadBlob(blob50))
+            res = []
+            for (w, h) in sizes:
+                out = []
+                m.advance(W.synth_frame(h, w, index=w), out)
+                res.append([x.copy() for x in m.lowres()])
+            lows[fuse] = res
+    for (w, h), a, b in zip(sizes, lows[True], lows[False]):
+        for x, y in zip(a, b):
+            assert (x.view(np.uint32) == y.view(np.uint32)).all(), (dtype, w, h)
