@@ -72,8 +72,13 @@ __device__ __forceinline__ void store_split(char* dst, const u32x4 r, const floa
 
 // dynamic LDS of a workgroup: the operand images, or the epilogue's per-wave staging slices
 // (32 pixel rows of BN / WN f32 channels + 16 bytes) if those need more
+// NBUF == 4 (the LDS-DMA form): rows are the bare 128 bytes -- a DMA piece lands lane-linear, so there is no room for
+// padding; bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index instead (lds_swz)
+constexpr int lds_row_bytes(int nbuf) { return nbuf == 4 ? ROW_BYTES : LDS_ROW; }
+__host__ __device__ constexpr int lds_swz(int row) { return (row >> 1) & 7; }
+
 constexpr int lds_bytes(int bm, int bn, int wm, int wn, int nbuf) {
-    const int operands = (nbuf == 1 ? 1 : 2) * (bm + bn) * LDS_ROW;
+    const int operands = (nbuf == 1 ? 1 : 2) * (bm + bn) * lds_row_bytes(nbuf);
     const int staging = wm * wn * 32 * (bn / wn * 4 + 16);
     return operands > staging ? operands : staging;
 }
@@ -85,6 +90,26 @@ constexpr int min_waves_per_simd(int bm, int bn, int wm, int wn, int nbuf) {
     const int w = blocks * waves / 4;
     return w < 1 ? 1 : (w > 2 ? 2 : w);
 }
+
+// LDS-DMA: 16 bytes per lane straight from HBM/L2 into LDS at (wave-uniform byte address in M0) + lane*16, no staging
+// VGPRs and no ds_write pass; a byte offset beyond the descriptor's num_records lands zeros (the same branch-free
+// padding as the register path).  Inline asm on purpose: hipcc (ROCm 7.2) drains every LDS-DMA it knows about with
+// vmcnt(0) before the next ds_read; this form is ordered by our own vmcnt + barrier instead.  M0 is compiler-reserved:
+// saved and restored inside the statement.
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16(const u32x4r rsrc, const unsigned lds, const unsigned voff, const unsigned soff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 // T = operand type (float: v_mfma_f32_32x32x2_f32, exact f32; _Float16: v_mfma_f32_32x32x16_f16
 // with f32 accumulation), OutT = type of the stored activation (f32 for the classifier logits).
@@ -139,9 +164,15 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     // instead of poisoning the accumulators with inf - inf
     if constexpr (SPLIT) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                        // [NBUF][BM][LDS_ROW]
+    // NBUF == 4: operand tiles travel HBM/L2 -> LDS by DMA (dma16), two images, one barrier per K step; rows are the
+    // bare 128 bytes with the 16-byte chunk index XOR-swizzled by lds_swz(row) -- applied to the SOURCE address of the
+    // DMA (a piece lands lane-linear) and to the fragment reads.  No staging registers, no ds_write pass.
+    constexpr bool GLDS = NBUF == 4;
+    static_assert(!GLDS || (!F32 && !SPLIT), "the LDS-DMA form is built for the f16 operands");
+    constexpr int LR = lds_row_bytes(NBUF);  // LDS row stride
+    char* As = smem;                        // [NIMG][BM][LR]
     constexpr int NIMG = NBUF == 1 ? 1 : 2;     // LDS images (NBUF 3 = two images, fragments single-buffered)
-    char* Bs = smem + NIMG * BM * LDS_ROW;  // [NIMG][BN][LDS_ROW]
+    char* Bs = smem + NIMG * BM * LR;  // [NIMG][BN][LR]
 
     // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous run of
     // tiles (n fastest) so the N-tiles that share an activation tile share one L2.
@@ -177,12 +208,16 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     const auto wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(wt_base), 0, (unsigned)((size_t)a.Cout * Ktot * ES), 0x00020000);
 
-    // per-thread gather coordinates of the A rows it stages
+    // per-thread gather coordinates of the A rows it stages.  Register path: thread (tid >> 3) + i * NT/8 is the tile
+    // row, tid & 7 the 16-byte chunk.  DMA path: a wave instruction fills 8 whole rows (1 KB); wave w owns the row
+    // groups w * IT + i, lane l row l >> 3 of the group at LDS chunk position l & 7, i.e. data chunk (l & 7) ^ swz(row).
     int a_iy0[A_IT], a_ix0[A_IT];
-    const int c4 = tid & 7;  // which 16-byte chunk of the 128-byte channel slice
+    auto st_row = [&](int i, int it) { return GLDS ? 8 * (wave * it + i) + (lane >> 3) : (tid >> 3) + i * (NT / 8); };
+    auto st_chunk = [&](int row) { return GLDS ? ((lane & 7) ^ lds_swz(row)) : (tid & 7); };
 #pragma unroll
     for (int i = 0; i < A_IT; i++) {
-        const int row = (tid >> 3) + i * (NT / 8);
+        const int row = st_row(i, A_IT);
+        const int c4 = st_chunk(row);
         const int m = m0 + row;
         const int oy = m / a.OW, ox = m - oy * a.OW;
         // rows past M get coordinates that fail the bounds test for every tap
@@ -198,10 +233,32 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     unsigned b_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; i++) {
-        const int row = (tid >> 3) + i * (NT / 8);
+        const int row = st_row(i, B_IT);
         const int n = n0 + row;
-        b_off[i] = n < a.Cout ? (unsigned)n * (unsigned)(Ktot * ES) + c4 * 16u : OOB;
+        b_off[i] = n < a.Cout ? (unsigned)n * (unsigned)(Ktot * ES) + st_chunk(row) * 16u : OOB;
     }
+    // DMA path: the descriptors as plain SGPR quadruples for the asm statement, and the LDS byte address of smem
+    u32x4r in_v = {}, in2_v = {}, wt_v = {};
+    unsigned lds0 = 0;
+    int ld_buf = 0;  // LDS image the next load_step fills
+    if constexpr (GLDS) {
+        auto mk = [](const void* p, unsigned bytes) {
+            const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+            u32x4r r;
+            r.x = __builtin_amdgcn_readfirstlane((unsigned)v);
+            r.y = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32) & 0xffffu);
+            r.z = __builtin_amdgcn_readfirstlane(bytes);
+            r.w = 0x00020000u;
+            return r;
+        };
+        in_v = mk(in_base, (unsigned)((size_t)a.H * a.W * a.Cin * ES));
+        wt_v = mk(wt_base, (unsigned)((size_t)a.Cout * Ktot * ES));
+        in2_v = mk(DUAL ? a.in2 : a.in, DUAL ? (unsigned)((size_t)a.H2 * a.W2 * a.Cin2 * ES) : 0u);
+        lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+    }
+    // one 16-byte piece of operand A (row group i of this wave) / B: register load, or DMA into image ld_buf
+    auto dst_a = [&](int i) { return __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(ld_buf * BM * LR + (wave * A_IT + i) * 1024)); };
+    auto dst_b = [&](int i) { return __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(NIMG * BM * LR + ld_buf * BN * LR + (wave * B_IT + i) * 1024)); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -225,23 +282,36 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             if (DUAL && kload >= cchunks) {  // wave-uniform: the second tensor's K steps
                 const unsigned so = (unsigned)(kload - cchunks) * (unsigned)ROW_BYTES;
 #pragma unroll
-                for (int i = 0; i < A_IT; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in2_rsrc, (unsigned)a_ix0[i], so, 0);
+                for (int i = 0; i < A_IT; i++) {
+                    if constexpr (GLDS)
+                        dma16(in2_v, dst_a(i), (unsigned)a_ix0[i], so);
+                    else
+                        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in2_rsrc, (unsigned)a_ix0[i], so, 0);
+                }
             } else {
                 const unsigned so = (unsigned)kload * (unsigned)ROW_BYTES;
 #pragma unroll
-                for (int i = 0; i < A_IT; i++) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (unsigned)a_iy0[i], so, 0);
+                for (int i = 0; i < A_IT; i++) {
+                    if constexpr (GLDS)
+                        dma16(in_v, dst_a(i), (unsigned)a_iy0[i], so);
+                    else
+                        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (unsigned)a_iy0[i], so, 0);
+                }
             }
             kload++;
             return;
         }
         const int dy = ky * a.dil, dx = kx * a.dil;
-        const unsigned coff = (unsigned)(cc * ROW_BYTES + c4 * 16);
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
+            const unsigned coff = (unsigned)(cc * ROW_BYTES + st_chunk(st_row(i, A_IT)) * 16);
             const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
             const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const unsigned off = (unsigned)(iy * a.W + ix) * (unsigned)(a.Cin * ES) + coff;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
+            if constexpr (GLDS)
+                dma16(in_v, dst_a(i), ok ? off : OOB, 0u);
+            else
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
         }
         // advance (ky,kx,cc) to the next K step, branch-free (all wave-uniform scalars)
         cc += 1;
@@ -255,30 +325,37 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     auto load_b = [&](int ks) {
         const unsigned koff = (unsigned)ks * (unsigned)ROW_BYTES;
 #pragma unroll
-        for (int i = 0; i < B_IT; i++)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, b_off[i], koff, 0);  // K step in the scalar offset
+        for (int i = 0; i < B_IT; i++) {  // K step in the scalar offset
+            if constexpr (GLDS)
+                dma16(wt_v, dst_b(i), b_off[i], koff);
+            else
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, b_off[i], koff, 0);
+        }
     };
     auto load_step = [&](int ks) {
         load_a();
         load_b(ks);
     };
+    const int c4 = tid & 7;  // register path: which 16-byte chunk of the 128-byte row this thread stages
     auto store_a = [&](int buf) {
-        char* Ab = As + buf * BM * LDS_ROW;
+        if constexpr (GLDS) return;  // the DMA wrote the image
+        char* Ab = As + buf * BM * LR;
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
             if constexpr (SPLIT)
-                store_split(Ab + row * LDS_ROW + c4 * 8, ra[i], a.a_scale);
+                store_split(Ab + row * LR + c4 * 8, ra[i], a.a_scale);
             else
-                *reinterpret_cast<u32x4*>(Ab + row * LDS_ROW + c4 * 16) = ra[i];
+                *reinterpret_cast<u32x4*>(Ab + row * LR + c4 * 16) = ra[i];
         }
     };
     auto store_b = [&](int buf) {
-        char* Bb = Bs + buf * BN * LDS_ROW;
+        if constexpr (GLDS) return;
+        char* Bb = Bs + buf * BN * LR;
 #pragma unroll
         for (int i = 0; i < B_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
-            *reinterpret_cast<u32x4*>(Bb + row * LDS_ROW + c4 * 16) = rb[i];  // SPLIT: split at load time
+            *reinterpret_cast<u32x4*>(Bb + row * LR + c4 * 16) = rb[i];  // SPLIT: split at load time
         }
     };
     auto store_step = [&](int buf) {
@@ -288,19 +365,21 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
 
     // LDS -> register fragments for one 32-byte k slice of buffer `buf`: lanes 0-31 take the
     // first 16 bytes (4 f32 / 8 f16 consecutive k), lanes 32-63 the second
-    const int a_lds = (wm * TM * 32 + (lane & 31)) * LDS_ROW + (lane >> 5) * 16;
-    const int b_lds = (wn * TN * 32 + (lane & 31)) * LDS_ROW + (lane >> 5) * 16;
+    const int a_lds = (wm * TM * 32 + (lane & 31)) * LR + (GLDS ? 0 : (lane >> 5) * 16);
+    const int b_lds = (wn * TN * 32 + (lane & 31)) * LR + (GLDS ? 0 : (lane >> 5) * 16);
+    // DMA image: chunk q of a row sits at position q ^ swz(row); a fragment's rows are 32 apart, which leaves swz unchanged
+    const int a_swz = lds_swz(lane & 31), b_swz = a_swz;
     auto read_frags = [&](int buf, int kk, float4 (&fa)[TM * NF], float4 (&fb)[TN * NF]) {
-        const char* Ab = As + buf * BM * LDS_ROW + a_lds + kk * 32;
-        const char* Bb = Bs + buf * BN * LDS_ROW + b_lds + kk * 32;
+        const char* Ab = As + buf * BM * LR + a_lds + (GLDS ? (((2 * kk + (lane >> 5)) ^ a_swz) * 16) : kk * 32);
+        const char* Bb = Bs + buf * BN * LR + b_lds + (GLDS ? (((2 * kk + (lane >> 5)) ^ b_swz) * 16) : kk * 32);
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int p = 0; p < NF; p++) fa[i * NF + p] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + p * 64);
+            for (int p = 0; p < NF; p++) fa[i * NF + p] = *reinterpret_cast<const float4*>(Ab + i * 32 * LR + p * 64);
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int p = 0; p < NF; p++) fb[j * NF + p] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + p * 64);
+            for (int p = 0; p < NF; p++) fb[j * NF + p] = *reinterpret_cast<const float4*>(Bb + j * 32 * LR + p * 64);
     };
 
     float4 fa[TM * NF], fb[TN * NF], fa_n[TM * NF], fb_n[TN * NF];
@@ -400,10 +479,17 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     constexpr auto Y = std::true_type{};
     constexpr auto N = std::false_type{};
 
-    load_step(0);
-    store_step(0);
-    if (ksteps > 1) load_step(1);
-    __syncthreads();
+    if constexpr (GLDS) {
+        ld_buf = 0;
+        load_step(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        load_step(0);
+        store_step(0);
+        if (ksteps > 1) load_step(1);
+        __syncthreads();
+    }
 #ifdef KTRACE
     const unsigned long long kt_loop = __builtin_amdgcn_s_memtime();
 #endif
@@ -445,6 +531,24 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else if constexpr (NBUF == 4) {
+        // LDS-DMA form: the DMA of K step ks + 1 into the other image is issued first and lands while this step's
+        // 32 MFMAs per wave run; every wave waits for its own pieces (vmcnt) and its fragment reads (lgkmcnt) before
+        // the barrier that ends the step -- after it the other image is complete and this one may be overwritten.
+        for (int ks = 0; ks < ksteps; ks++) {
+            const int buf = ks & 1;
+            if (ks + 1 < ksteps) {
+                ld_buf = buf ^ 1;
+                load_step(ks + 1);
+            }
+#pragma unroll
+            for (int kk = 0; kk < NSL; kk++) {
+                read_frags(buf, kk, fa, fb);
+                mma_slice();
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
     } else if constexpr (NBUF == 2) {
@@ -662,6 +766,9 @@ static const CfgInfo kCfgs[] = {
     {64, 64, {"conv_igemm_f32<64,64,1buf>", "conv_igemm_f16<64,64,1buf>", "conv_igemm_f32s<64,64,1buf>"}},
     {256, 256, {"conv_igemm_f32<256,256,1frag>", "conv_igemm_f16<256,256,1frag>", "conv_igemm_f32s<256,256,1frag>"}},
     {256, 128, {"conv_igemm_f32<256,128,1frag>", "conv_igemm_f16<256,128,1frag>", "conv_igemm_f32s<256,128,1frag>"}},
+    // LDS-DMA staging (f16 operands only, conv_igemm_config_valid_mode)
+    {256, 256, {"conv_igemm_f32<256,256,dma>", "conv_igemm_f16<256,256,dma>", "conv_igemm_f32s<256,256,dma>"}},
+    {256, 128, {"conv_igemm_f32<256,128,dma>", "conv_igemm_f16<256,128,dma>", "conv_igemm_f32s<256,128,dma>"}},
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -679,9 +786,10 @@ int conv_igemm_default_config(const ConvArgs& a) {
     return 4;
 }
 
-// a configuration is a candidate when its N tile is not mostly padding
-bool conv_igemm_config_valid(const ConvArgs& a, int cfg) {
+// a configuration is a candidate when its N tile is not mostly padding (and, for the LDS-DMA forms, in the f16 mode)
+bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode) {
     if (cfg < 0 || cfg >= kNumCfgs) return false;
+    if (cfg >= 13 && mode != 1) return false;
     const int bn = kCfgs[cfg].bn;
     if (a.Cout <= 32) return bn == 32;
     if (bn == 32) return false;
@@ -710,6 +818,13 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 10: return launch_cfg<T, OutT, SPLIT, 64, 64, 2, 2, 1>(a, s);
         case 11: return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 3>(a, s);  // 8 waves of 128x64, one fragment set
         case 12: return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 3>(a, s);  // 8 waves of 64x64, one fragment set
+        case 13:
+        case 14:
+            if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {
+                if (cfg == 13) return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 4>(a, s);  // LDS-DMA staging
+                return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 4>(a, s);
+            }
+            return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

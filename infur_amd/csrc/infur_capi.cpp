@@ -494,14 +494,14 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
     // test hook: INFUR_CONV_CFG=<k> forces configuration k wherever it is a candidate
     static const int forced = getenv("INFUR_CONV_CFG") ? atoi(getenv("INFUR_CONV_CFG")) : -1;
     if (forced >= 0) {
-        if (conv_igemm_config_valid(a, forced)) *cfg = forced;
+        if (conv_igemm_config_valid(a, forced, mode)) *cfg = forced;
         return INFUR_OK;
     }
     if (c->opt.no_autotune) return INFUR_OK;
     const std::array<int, 13> key = {a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.stride, a.dil, a.batch,
                                      a.res ? 1 : (a.in2 ? 2 : 0), mode, out_f32};
     auto it = c->tuned.find(key);
-    if (it != c->tuned.end() && conv_igemm_config_valid(a, it->second)) {
+    if (it != c->tuned.end() && conv_igemm_config_valid(a, it->second, mode)) {
         *cfg = it->second;
         return INFUR_OK;
     }
@@ -515,7 +515,7 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
     }
     float best = 1e30f;
     for (int k = 0; k < conv_igemm_num_configs(); k++) {
-        if (!conv_igemm_config_valid(a, k)) continue;
+        if (!conv_igemm_config_valid(a, k, mode)) continue;
         HIPCHK(c, launch_conv_igemm(a, mode, out_f32, k, c->stream));  // warm-up (attributes, caches)
         float fastest = 1e30f;
         for (int r = 0; r < 4; r++) {  // minimum of 4 single-launch timings

@@ -46,7 +46,7 @@ struct ConvArgs {
 hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, hipStream_t s);
 int conv_igemm_num_configs();
 int conv_igemm_default_config(const ConvArgs& a);
-bool conv_igemm_config_valid(const ConvArgs& a, int cfg);
+bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode);
 const char* conv_igemm_config_name(int cfg, int mode);
 
 // Winograd F(mt x mt, 3x3), mt = 2 or 4, for stride-1 3x3 convs (f32, any dilation d with pad = d);

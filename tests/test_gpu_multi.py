@@ -42,8 +42,11 @@ def test_compute_aux_off_has_one_output(blob50, oracle_model):
         assert rc == _lib.E_INVALID_ARG and "one output" in c1.last_error()
 
 
-def test_model_without_aux_head(oracle):
+def test_model_without_aux_head():
     """An INFURW01 blob / ONNX file without the aux head (55 convs): one output, logits match the oracle."""
+    from oracle.infur_oracle import COracle
+
+    oracle = COracle()  # its own instance: the session-wide oracle keeps the two-headed model loaded
     blob = W.synth_blob(aux=False)
     fr = W.synth_frame(48, 64, index=1)
     with Context(device=0) as c:
