@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--scale-mode", type=int, default=0, help="0 nearest (reference), 1 bilinear")
     ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--contexts-per-gpu", type=int, default=2,
+                    help="contexts (HIP streams + arenas) per GPU working on different frames of the batch at the same time: the "
+                         "tail of one frame's kernel overlaps the next frame's (2: +3..5 %% frames/s; 1: strictly one frame at a time)")
     ap.add_argument("--no-aux", action="store_true", help="skip the aux head (the ONNX graph always evaluates it)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,17 +271,27 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    stream = torch.cuda.Stream()
-    ctx = Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=stream.cuda_stream, dtype=a.dtype,
-                  winograd_min_cin=a.winograd_min_cin & 0xFFFFFFFF, winograd_tile=a.winograd_tile)
+    # K contexts per GPU, each with its own stream and activation arena, take the frames of a step in turn: kernels
+    # of different frames overlap where one of them leaves CUs idle (tails of a launch, HBM-bound next to MFMA-bound)
+    K = max(1, a.contexts_per_gpu)
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    ctxs = [Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=st.cuda_stream, dtype=a.dtype,
+                    winograd_min_cin=a.winograd_min_cin & 0xFFFFFFFF, winograd_tile=a.winograd_tile) for st in streams]
+    ctx = ctxs[0]
 
-    # ---- weights: rank 0 synthesises, RCCL broadcast over xGMI, every rank repacks locally ----
+    # ---- weights: rank 0 synthesises, RCCL broadcast over xGMI, every rank repacks locally; the rank's other
+    #      contexts get the repacked arena through the C ABI's group call (device-to-device on one GPU) ----
     blob = W.synth_blob(depth=a.depth) if rank == 0 else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nbytes, bcast_ms = idist.load_model_everywhere(ctx, blob, coll_device=coll_dev)
+    if K > 1:
+        from infur_amd.processors import Group
+
+        with Group(ctxs) as grp:
+            grp.weights_broadcast(0)
     torch.cuda.synchronize()
     load_ms = (time.perf_counter() - t0) * 1e3
 
@@ -288,18 +301,28 @@ def main():
     d_frames = [torch.from_numpy(f).cuda() for f in frames_np]
     rc_w, rc_h = idims(ctx, Wd, H, a.scale)
     d_masks = [torch.empty((rc_h, rc_w, 4), dtype=torch.uint8, device="cuda") for _ in range(B)]
-    fp = FramePath(ctx, a.scale_mode)
+    fps_ = [FramePath(c, a.scale_mode) for c in ctxs]
+    fp = fps_[0]
     torch.cuda.synchronize()
+
+    def sync_all():
+        for c in ctxs:
+            c.synchronize()
 
     def step(profile_last=False):
         for i in range(B):
+            k = i % K
             if profile_last and i == B - 1:
-                ctx.L.infur_profile_enable(ctx.h, 1)  # per-kernel HIP events for this frame only
-            fp.advance_dev(d_frames[i].data_ptr(), Wd, H, a.scale, d_masks[i].data_ptr(), d_masks[i].numel())
+                # the roofline sample: per-kernel HIP events for this frame only, and the frame runs ALONE (the other
+                # contexts are drained first) so that an event pair brackets one kernel and nothing else
+                sync_all()
+                k = 0
+                ctx.L.infur_profile_enable(ctx.h, 1)
+            fps_[k].advance_dev(d_frames[i].data_ptr(), Wd, H, a.scale, d_masks[i].data_ptr(), d_masks[i].numel())
 
     for _ in range(a.warmup):
         step()
-    ctx.synchronize()
+    sync_all()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -307,10 +330,11 @@ def main():
     t0 = time.perf_counter()
     # Per-kernel HIP events bracket every launch of the LAST frame of the timed region only (the
     # roofline sample); recording them on all frames costs ~2.5 % of throughput in event packets.
-    ctx.L.infur_profile_enable(ctx.h, 0)
+    for c in ctxs:
+        c.L.infur_profile_enable(c.h, 0)
     for k in range(a.steps):
         step(profile_last=(not a.no_profile) and k == a.steps - 1)
-    ctx.synchronize()
+    sync_all()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -324,8 +348,8 @@ def main():
     agree = None
     if world > 1:
         f0 = torch.from_numpy(W.synth_frame(H, Wd, index=0)).cuda()
-        fp.advance_dev(f0.data_ptr(), Wd, H, a.scale, d_masks[0].data_ptr(), d_masks[0].numel())
-        ctx.synchronize()
+        fps_[K - 1].advance_dev(f0.data_ptr(), Wd, H, a.scale, d_masks[0].data_ptr(), d_masks[0].numel())
+        sync_all()
         sha = hashlib.sha256(d_masks[0].cpu().numpy().tobytes()).hexdigest()
         shas = [None] * world
         dist.all_gather_object(shas, sha)
@@ -341,7 +365,7 @@ def main():
         "config": {
             "workload": f"{Wd}x{H} packed-BGR frame, FCN-ResNet{a.depth} {a.dtype} (aux head {'off' if a.no_aux else 'on'}), "
                         f"scale={a.scale}" + (" [BASELINE configs[1]]" if (Wd, H, a.scale, a.dtype, a.depth) == (1920, 1080, 1.0, "f32", 50) else ""),
-            "frames_per_step_per_gpu": B, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if world > 1 else None,
+            "frames_per_step_per_gpu": B, "contexts_per_gpu": K, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if world > 1 else None,
             "weights": f"synthetic seed {W.DEFAULT_SEED:#x}, {nbytes / 1e6:.1f} MB blob",
             "weights_load_ms": round(load_ms, 2), "weights_bcast_ms": round(bcast_ms, 3),
             "weights_note": "weights_load_ms = broadcast + per-rank repack into kernel layouts; weights_bcast_ms = the "
@@ -452,41 +476,63 @@ def main():
             out["cpu_baseline"] = cpu_baseline(blob, frames_np[0], a.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def resident_rate(a, dev, dtype, blob, d_frames, d_masks, Wd, H, scale, n_frames):
+    """frames/s of the fused path on HBM-resident frames with a.contexts_per_gpu contexts taking the frames in turn
+    (weights loaded once, replicated to the other contexts through infur_group_weights_broadcast)."""
+    from infur_amd.processors import Context, FramePath, Group, Model, ModelCmd
+
+    K = max(1, a.contexts_per_gpu)
+    ctxs = [Context(device=dev, compute_aux=not a.no_aux, profile=False, dtype=dtype) for _ in range(K)]
+    Model(ctxs[0]).control(ModelCmd.LoadBlob(blob))
+    if K > 1:
+        with Group(ctxs) as g:
+            g.weights_broadcast(0)
+    fps_ = [FramePath(c, a.scale_mode) for c in ctxs]
+    B = len(d_frames)
+
+    def run(n):
+        for i in range(n):
+            fps_[i % K].advance_dev(d_frames[i % B].data_ptr(), Wd, H, scale, d_masks[i % B].data_ptr(), d_masks[i % B].numel())
+        for c in ctxs:
+            c.synchronize()
+
+    run(max(4 * K, 16) if n_frames >= 32 else 2 * K)  # arenas, tile configurations, and the clocks back up after the idle gap
+    t0 = time.perf_counter()
+    run(n_frames)
+    dt = time.perf_counter() - t0
+    for c in ctxs:
+        c.close()
+    return n_frames / dt, dt / n_frames * 1e3
 
 
 def split_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H):
     """The same frames through INFUR_DTYPE_F32_SPLIT (f32 tensors, conv GEMMs on the f16 matrix cores with every
     operand split into an f16 hi+lo pair, f32 accumulation): reported NEXT TO the native-f32 headline, not as it.
     Its logits match the f32 CPU oracle as closely as the native f32 MFMA path does (tests/test_gpu_split.py)."""
-    import torch
+    fps, ms = resident_rate(a, dev, "f32s", blob, d_frames, d_masks, Wd, H, a.scale, len(d_frames) * a.steps)
+    flops = None
+    try:
+        from infur_amd import weights as W
 
-    from infur_amd.processors import Context, FramePath, Model, ModelCmd
-
-    stream = torch.cuda.Stream()
-    ctx = Context(device=dev, compute_aux=not a.no_aux, profile=False, stream=stream.cuda_stream, dtype="f32s")
-    Model(ctx).control(ModelCmd.LoadBlob(blob))
-    fp = FramePath(ctx, a.scale_mode)
-    B = len(d_frames)
-
-    def step():
-        for i in range(B):
-            fp.advance_dev(d_frames[i].data_ptr(), Wd, H, a.scale, d_masks[i].data_ptr(), d_masks[i].numel())
-
-    step()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
-    ctx.close()
-    return {"value": B * a.steps / dt, "unit": "frames/s", "dtype": "f32s", "ms_per_frame": dt / (B * a.steps) * 1e3,
-            "parity": "logits within 3e-5 of the f32 oracle enforced in tests/test_gpu_split.py (measured 2.5e-6 .. 4e-6, the "
-                      "native f32 MFMA mode measures 3e-6 .. 4e-6); class maps identical outside a 3e-5 band",
-            "run": "python bench.py --dtype f32s"}
+        flops = W.conv_flops(H, Wd, depth=a.depth, aux=not a.no_aux)["total"]
+    except Exception:
+        pass
+    out = {"value": fps, "unit": "frames/s", "dtype": "f32s", "ms_per_frame": ms, "contexts_per_gpu": max(1, a.contexts_per_gpu),
+           "parity": "logits within 3e-5 of the f32 oracle enforced in tests/test_gpu_split.py (measured 2.5e-6 .. 4e-6, the "
+                     "native f32 MFMA mode measures 3e-6 .. 4e-6); class maps identical outside a 3e-5 band",
+           "run": "python bench.py --dtype f32s"}
+    if flops:
+        ceil = PEAK_F16_MFMA_TFLOPS / 3.0
+        out["roofline"] = {"bound": "mfma", "achieved": flops * fps / 1e12, "peak": ceil, "unit": "TFLOP/s", "frac": flops * fps / 1e12 / ceil,
+                           "note": "whole-frame algorithmic (direct-conv) FLOPs x frames/s against a third of the dense f16 MFMA peak "
+                                   "(three f16 MFMAs per f32 product); 11 convs run as Winograd F(4x4)"}
+    return out
 
 
 def stream_scale05_rate(a, dev, blob, frames_np):
@@ -509,30 +555,22 @@ def stream_scale05_rate(a, dev, blob, frames_np):
     got = list(sp.run(frames, 0.5))
     dt = time.perf_counter() - t0
     sp.close()
-    # the same per-frame work with the frame already in HBM
+    ctx.close()
+    # the same per-frame work with the frames already in HBM
     import torch
 
-    fp = FramePath(ctx)
     oh, ow = got[0][1].shape[:2]
-    d_in = torch.from_numpy(frames_np[0]).cuda()
-    d_out = torch.empty((oh, ow, 4), dtype=torch.uint8, device="cuda")
-    for _ in range(4):
-        fp.advance_dev(d_in.data_ptr(), Wd, H, 0.5, d_out.data_ptr(), d_out.numel())
-    ctx.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(32):
-        fp.advance_dev(d_in.data_ptr(), Wd, H, 0.5, d_out.data_ptr(), d_out.numel())
-    ctx.synchronize()
-    dt_dev = time.perf_counter() - t1
-    ctx.close()
+    d_in = [torch.from_numpy(f).cuda() for f in frames_np[:4]]
+    d_out = [torch.empty((oh, ow, 4), dtype=torch.uint8, device="cuda") for _ in d_in]
+    res_fps, _ = resident_rate(a, dev, "f32", blob, d_in, d_out, Wd, H, 0.5, 64)
     gflop = W.conv_flops(oh, ow, depth=50, aux=not a.no_aux)["total"] / 1e9
     fps = n / dt
     return {"value": fps, "unit": "frames/s", "dtype": "f32", "frames": n, "realtime_30fps_streams": fps / 30.0,
             "workload": f"{Wd}x{H} bgr24 frames from host memory -> scale 0.5 (nearest) -> {ow}x{oh} FCN-ResNet50 -> mask to host; "
                         "infur_stream depth 3, PCIe inclusive",
-            "hbm_resident_frames_per_s": 32 / dt_dev, "conv_gflop_per_frame": gflop,
-            "roofline": {"bound": "mfma", "achieved": gflop * (32 / dt_dev) / 1e3, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gflop * (32 / dt_dev) / 1e3 / PEAK_F32_MFMA_TFLOPS,
+            "hbm_resident_frames_per_s": res_fps, "conv_gflop_per_frame": gflop,
+            "roofline": {"bound": "mfma", "achieved": gflop * res_fps / 1e3, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gflop * res_fps / 1e3 / PEAK_F32_MFMA_TFLOPS,
                          "note": "whole-frame algorithmic (direct-conv) FLOPs x HBM-resident frames/s; 11 convs run as Winograd F(4x4)"}}
 
 
@@ -546,24 +584,14 @@ def r101_f16_4k_rate(a, dev):
     from infur_amd.processors import Context, FramePath, Model, ModelCmd
 
     H, Wd = 2160, 3840
-    ctx = Context(device=dev, compute_aux=not a.no_aux, dtype="f16")
-    Model(ctx).control(ModelCmd.LoadBlob(W.synth_blob(depth=101)))
-    fp = FramePath(ctx)
-    d_in = torch.from_numpy(W.synth_frame(H, Wd, index=0)).cuda()
-    d_out = torch.empty((H, Wd, 4), dtype=torch.uint8, device="cuda")
-    for _ in range(2):
-        fp.advance_dev(d_in.data_ptr(), Wd, H, 1.0, d_out.data_ptr(), d_out.numel())
-    ctx.synchronize()
-    n = 8
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fp.advance_dev(d_in.data_ptr(), Wd, H, 1.0, d_out.data_ptr(), d_out.numel())
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
-    ctx.close()
+    d_in = [torch.from_numpy(W.synth_frame(H, Wd, index=i)).cuda() for i in range(2)]
+    d_out = [torch.empty((H, Wd, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    n = 12
+    fps, ms = resident_rate(a, dev, "f16", W.synth_blob(depth=101), d_in, d_out, Wd, H, 1.0, n)
+    dt = ms * n / 1e3
     gflop = W.conv_flops(H, Wd, depth=101, aux=not a.no_aux)["total"] / 1e9
-    fps = n / dt
     return {"value": fps, "unit": "frames/s", "dtype": "f16", "ms_per_frame": dt / n * 1e3, "frames": n,
+            "contexts_per_gpu": max(1, a.contexts_per_gpu),
             "workload": f"{Wd}x{H} frame, FCN-ResNet101 f16 operands / f32 accumulation, scale 1.0, HBM resident",
             "conv_gflop_per_frame": gflop,
             "roofline": {"bound": "mfma", "achieved": gflop * fps / 1e3, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -537,6 +537,9 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         // LDS-DMA form: the DMA of K step ks + 1 into the other image is issued first and lands while this step's
         // 32 MFMAs per wave run; every wave waits for its own pieces (vmcnt) and its fragment reads (lgkmcnt) before
         // the barrier that ends the step -- after it the other image is complete and this one may be overwritten.
+        // (Reading the next slice's fragments ahead of this slice's MFMAs -- the register path's prefetch -- was
+        // measured here and is slower: 1187 vs 1225 TFLOP/s on the 4K classifier.0; the second wave on the SIMD already
+        // covers the ds_read latency and the extra register set costs more than it hides.)
         for (int ks = 0; ks < ksteps; ks++) {
             const int buf = ks & 1;
             if (ks + 1 < ksteps) {
