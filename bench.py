@@ -313,10 +313,12 @@ def main():
         for i in range(B):
             k = i % K
             if profile_last and i == B - 1:
-                # the roofline sample: per-kernel HIP events for this frame only, and the frame runs ALONE (the other
-                # contexts are drained first) so that an event pair brackets one kernel and nothing else
-                sync_all()
+                # the roofline sample: per-kernel HIP events for this frame only, and the frame runs ALONE -- context 0's
+                # stream waits (on the GPU, no host round trip that would let the chip idle and clock down) for the frames
+                # the other contexts have in flight, so that an event pair brackets one kernel and nothing else
                 k = 0
+                for st in streams[1:]:
+                    streams[0].wait_stream(st)
                 ctx.L.infur_profile_enable(ctx.h, 1)
             fps_[k].advance_dev(d_frames[i].data_ptr(), Wd, H, a.scale, d_masks[i].data_ptr(), d_masks[i].numel())
 

@@ -772,6 +772,8 @@ static const CfgInfo kCfgs[] = {
     // LDS-DMA staging (f16 operands only, conv_igemm_config_valid_mode)
     {256, 256, {"conv_igemm_f32<256,256,dma>", "conv_igemm_f16<256,256,dma>", "conv_igemm_f32s<256,256,dma>"}},
     {256, 128, {"conv_igemm_f32<256,128,dma>", "conv_igemm_f16<256,128,dma>", "conv_igemm_f32s<256,128,dma>"}},
+    // (128x128 and 128x256 DMA tiles were measured too: slower than the register-staged forms on every layer of the 4K
+    // FCN-ResNet101, including the HBM-bound 1x1 convs they were meant for -- 0.199 / 0.208 ms vs 0.170 on layer3 conv3)
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -823,8 +825,8 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 12: return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 3>(a, s);  // 8 waves of 64x64, one fragment set
         case 13:
         case 14:
-            if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {
-                if (cfg == 13) return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 4>(a, s);  // LDS-DMA staging
+            if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {  // LDS-DMA staging
+                if (cfg == 13) return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 4>(a, s);
                 return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 4>(a, s);
             }
             return hipErrorInvalidValue;

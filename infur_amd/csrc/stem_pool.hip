@@ -7,6 +7,8 @@
 //    tensor the reference materialises (24.9 MB at 1080p) never exists here.
 //  * maxpool3x3s2: MaxPool 3x3 stride 2 pad 1 on NHWC f32.
 //  * weight repacks (one-off at model load).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace infur {
@@ -154,7 +156,9 @@ static_assert(SP_NPIX <= 256 && SP_NPIX > 224, "the stem tile must fill 8 M-bloc
 
 __host__ __device__ constexpr int sp_koff(int k) { return (k / 21) * (SP_IW * 3) + (k % 21); }
 
-template <typename OutT>
+// ABL: timing ablations (INFUR_STEM_ABL, results wrong): 1 = no MFMA loop, 2 = no prologue loads (LDS left as is),
+// 3 = no stage/pool phase
+template <typename OutT, int ABL = 0>
 __global__ void __launch_bounds__(256, 2)
     stem_pool_kernel(const uint8_t* __restrict__ bgr, int H, int W, const float* __restrict__ wt, const float* __restrict__ bias,
                      const float* __restrict__ lut, OutT* __restrict__ out, int SH, int SW, int PH, int PW,
@@ -174,6 +178,7 @@ __global__ void __launch_bounds__(256, 2)
     float* slut = smem + SP_LDS_FLOATS - 768;  // top of the allocation: overwritten only by the stem tile, after the barrier
     constexpr int NPX = (SP_IH * SP_IW + 255) / 256;  // 6 frame pixels per thread
     constexpr int NW4 = (ST_KP * 64 / 4 + 255) / 256;  // 10 float4 of weights per thread
+    if constexpr (ABL != 2) {
     uint8_t pb[NPX][3];
     bool pin[NPX];
 #pragma unroll
@@ -215,6 +220,7 @@ __global__ void __launch_bounds__(256, 2)
     }
     __syncthreads();
 
+    }
     const int wave = tid >> 6, lane = tid & 63;
     const int px = lane & 31, half = lane >> 5;
     f32x16s acc[2][2];
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(256, 2)
     }
     const float* pw = wsm + half * 64 + px;
 #pragma unroll
-    for (int s = 0; s < ST_KP / 2; s++) {
+    for (int s = 0; s < (ABL == 1 ? 1 : ST_KP / 2); s++) {
         constexpr int kLast = ST_K - 1;
         const int k0 = 2 * s, k1 = 2 * s + 1 > kLast ? kLast : 2 * s + 1;
         const int off = half ? sp_koff(k1) : sp_koff(k0);
@@ -249,6 +255,10 @@ __global__ void __launch_bounds__(256, 2)
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
     }
     __syncthreads();  // every wave is done with the patch and the weights: their LDS becomes the stem tile
+    if constexpr (ABL == 3) {
+        if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 123.456f) out[0] = (OutT)1;  // keep the MFMAs alive
+        return;
+    }
 
     float* stage = smem;
 #pragma unroll
@@ -311,8 +321,15 @@ __global__ void __launch_bounds__(256, 2)
 hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const float* bias, const float* lut, void* out,
                             int f16, int SH, int SW, int PH, int PW, unsigned* amax, hipStream_t s) {
     dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
+    static const int abl = getenv("INFUR_STEM_ABL") ? atoi(getenv("INFUR_STEM_ABL")) : 0;
     if (f16)
         hipLaunchKernelGGL(stem_pool_kernel<_Float16>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (_Float16*)out, SH, SW, PH, PW, amax);
+    else if (abl == 1)
+        hipLaunchKernelGGL((stem_pool_kernel<float, 1>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW, amax);
+    else if (abl == 2)
+        hipLaunchKernelGGL((stem_pool_kernel<float, 2>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW, amax);
+    else if (abl == 3)
+        hipLaunchKernelGGL((stem_pool_kernel<float, 3>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW, amax);
     else
         hipLaunchKernelGGL(stem_pool_kernel<float>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW, amax);
     return hipGetLastError();

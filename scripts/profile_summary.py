@@ -23,7 +23,19 @@ def find(d, pat):
     return max(g, key=os.path.getmtime) if g else None  # newest (gpurun merges, never deletes)
 
 
+_DEMANGLED = {}
+
+
 def short(name):
+    if name.startswith("_Z"):  # rocprofv3 leaves some template instantiations mangled
+        if name not in _DEMANGLED:
+            try:
+                import subprocess
+
+                _DEMANGLED[name] = subprocess.run(["c++filt", name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+            except (OSError, subprocess.SubprocessError):
+                _DEMANGLED[name] = name
+        name = _DEMANGLED[name]
     n = name.replace("void infur::", "").replace("infur::", "")
     return n.split("(")[0]
 
