@@ -772,6 +772,11 @@ static const CfgInfo kCfgs[] = {
     // LDS-DMA staging (f16 operands only, conv_igemm_config_valid_mode)
     {256, 256, {"conv_igemm_f32<256,256,dma>", "conv_igemm_f16<256,256,dma>", "conv_igemm_f32s<256,256,dma>"}},
     {256, 128, {"conv_igemm_f32<256,128,dma>", "conv_igemm_f16<256,128,dma>", "conv_igemm_f32s<256,128,dma>"}},
+    // (a two-group PING-PONG schedule on top of the DMA form -- waves 0-3 load while waves 4-7 compute, 4 barriers per K
+    // step, raised priority on the MFMA clusters -- was built, is bit-identical, and is NOT faster: 1143 vs 1183 TFLOP/s on
+    // the 4K classifier.0.  The matrix pipe is not waiting for a better schedule: MfmaUtil is 57.5 % in cycle terms and the
+    // rest of the gap is the package clock, 1.99 GHz on real data against 2.38 GHz on all-zero operands for the SAME
+    // binary -- scripts/zero_data_probe.py, profiles/r02_dvfs_probe.md.)
     // (128x128 and 128x256 DMA tiles were measured too: slower than the register-staged forms on every layer of the 4K
     // FCN-ResNet101, including the HBM-bound 1x1 convs they were meant for -- 0.199 / 0.208 ms vs 0.170 on layer3 conv3)
 };
