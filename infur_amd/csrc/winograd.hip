@@ -60,17 +60,18 @@ __device__ __forceinline__ void bt_1d(const V* d, V* t) {  // B^T d : (MT+2) -> 
     }
 }
 
-template <int MT, int S, typename V>
-__device__ __forceinline__ void at_1d(const V* m, V* y) {  // A^T m : (MT+2) -> MT
+template <int MT, int S, int SO = S, typename V>
+__device__ __forceinline__ void at_1d(const V* m, V* y) {  // A^T m : (MT+2) -> MT; S / SO = input / output stride
     if constexpr (MT == 2) {
-        y[0 * S] = m[0 * S] + m[1 * S] + m[2 * S];
-        y[1 * S] = m[1 * S] - m[2 * S] - m[3 * S];
+        const V m0 = m[0 * S], m1 = m[1 * S], m2 = m[2 * S], m3 = m[3 * S];
+        y[0 * SO] = m0 + m1 + m2;
+        y[1 * SO] = m1 - m2 - m3;
     } else {
         const V m0 = m[0 * S], m1 = m[1 * S], m2 = m[2 * S], m3 = m[3 * S], m4 = m[4 * S], m5 = m[5 * S];
-        y[0 * S] = m0 + m1 + m2 + m3 + m4;
-        y[1 * S] = m1 - m2 + 2.0f * m3 - 2.0f * m4;
-        y[2 * S] = m1 + m2 + 4.0f * m3 + 4.0f * m4;
-        y[3 * S] = m1 - m2 + 8.0f * m3 - 8.0f * m4 + m5;
+        y[0 * SO] = m0 + m1 + m2 + m3 + m4;
+        y[1 * SO] = m1 - m2 + 2.0f * m3 - 2.0f * m4;
+        y[2 * SO] = m1 + m2 + 4.0f * m3 + 4.0f * m4;
+        y[3 * SO] = m1 - m2 + 8.0f * m3 - 8.0f * m4 + m5;
     }
 }
 
@@ -167,11 +168,17 @@ __global__ void __launch_bounds__(256)
         int ry, rx, ty, tx;
         tile_coords(g, t, ry, rx, ty, tx);
         const float* mp = M + (size_t)t * Cout + nv * VW;
-        VT m[AL * AL], s[MT * AL];
+        // column by column: the 6 plane vectors of column b are reduced to 4 at once.  (hipcc still hoists all 36 loads
+        // to the top -- 207 VGPRs, 2 waves per SIMD; forcing <= 128 registers spills and runs 2x slower, and the kernel
+        // moves 4.7-4.9 TB/s either way.)
+        VT s[MT * AL];
 #pragma unroll
-        for (int xi = 0; xi < AL * AL; xi++) m[xi] = *reinterpret_cast<const VT*>(mp + (size_t)xi * plane);
+        for (int b = 0; b < AL; b++) {
+            VT col[AL];
 #pragma unroll
-        for (int b = 0; b < AL; b++) at_1d<MT, AL>(m + b, s + b);        // columns: A^T m  -> [MT][AL]
+            for (int a = 0; a < AL; a++) col[a] = *reinterpret_cast<const VT*>(mp + (size_t)(a * AL + b) * plane);
+            at_1d<MT, 1, AL>(col, s + b);  // A^T m  -> [MT][AL]
+        }
         const VT bv = *reinterpret_cast<const VT*>(bias + nv * VW);
 #pragma unroll
         for (int a = 0; a < MT; a++) {

@@ -32,7 +32,9 @@ def short(name):
             try:
                 import subprocess
 
-                _DEMANGLED[name] = subprocess.run(["c++filt", name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+                # binutils' demangler does not know DF16_ (_Float16): go through Dh (half) and rename
+                out = subprocess.run(["c++filt", name.replace("DF16_", "Dh")], capture_output=True, text=True, timeout=10).stdout.strip()
+                _DEMANGLED[name] = out.replace("half", "_Float16") if out and not out.startswith("_Z") else name
             except (OSError, subprocess.SubprocessError):
                 _DEMANGLED[name] = name
         name = _DEMANGLED[name]
