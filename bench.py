@@ -546,10 +546,19 @@ def stream_scale05_rate(a, dev, blob, frames_np):
     from infur_amd.app import StreamPath
     from infur_amd.processors import Context, FramePath, Model, ModelCmd
 
-    ctx = Context(device=dev, compute_aux=not a.no_aux)
+    from infur_amd.processors import Group
+
+    K = max(1, a.contexts_per_gpu)
+    lanes = [Context(device=dev, compute_aux=not a.no_aux) for _ in range(K)]
+    ctx = lanes[0]
     Model(ctx).control(ModelCmd.LoadBlob(blob))
+    if K > 1:
+        with Group(lanes) as g:
+            g.weights_broadcast(0)
     H, Wd = frames_np[0].shape[:2]
-    sp = StreamPath(ctx, depth=3)
+    sp = StreamPath(ctx, depth=3 if K == 1 else 4)
+    for other in lanes[1:]:
+        sp.add_lane(other)  # consecutive frames on alternating contexts
     n = 48
     frames = [(i, frames_np[i % len(frames_np)]) for i in range(n)]
     list(sp.run(frames[:6], 0.5))  # warm-up: ring allocation, tile configurations
@@ -557,7 +566,8 @@ def stream_scale05_rate(a, dev, blob, frames_np):
     got = list(sp.run(frames, 0.5))
     dt = time.perf_counter() - t0
     sp.close()
-    ctx.close()
+    for c in lanes:
+        c.close()
     # the same per-frame work with the frames already in HBM
     import torch
 
@@ -569,7 +579,7 @@ def stream_scale05_rate(a, dev, blob, frames_np):
     fps = n / dt
     return {"value": fps, "unit": "frames/s", "dtype": "f32", "frames": n, "realtime_30fps_streams": fps / 30.0,
             "workload": f"{Wd}x{H} bgr24 frames from host memory -> scale 0.5 (nearest) -> {ow}x{oh} FCN-ResNet50 -> mask to host; "
-                        "infur_stream depth 3, PCIe inclusive",
+                        f"infur_stream ring, {K} compute lane(s), PCIe inclusive",
             "hbm_resident_frames_per_s": res_fps, "conv_gflop_per_frame": gflop,
             "roofline": {"bound": "mfma", "achieved": gflop * res_fps / 1e3, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": gflop * res_fps / 1e3 / PEAK_F32_MFMA_TFLOPS,

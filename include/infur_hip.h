@@ -230,6 +230,12 @@ int32_t infur_stream_create(infur_ctx* ctx, uint32_t depth, infur_stream** out);
  * alive and leaves them as empty handles (every call on them then returns INFUR_E_INVALID_ARG); such a handle
  * must still be passed to infur_stream_destroy.  Either destroy order is therefore safe. */
 void infur_stream_destroy(infur_stream* st);
+/* Optional second (third ...) compute lane: `other` is another context of the SAME device with a model loaded (e.g.
+ * replicated by infur_group_weights_broadcast).  Frame i then runs on lane i % n: frames are independent, so the
+ * kernels of consecutive frames overlap where one of them leaves CUs idle (+3..5 % frames/s with two lanes; results
+ * and their order are unchanged).  Call while nothing is pending.  Either context may be destroyed first (the stream
+ * is orphaned, see above). */
+int32_t infur_stream_add_lane(infur_stream* st, infur_ctx* other);
 /* INFUR_OK, or an error of infur_frame_advance; frame_id is returned by collect */
 int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor,
                             uint32_t scale_mode, uint64_t frame_id);

@@ -118,6 +118,7 @@ SIGNATURES = {
     "infur_frame_advance_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _f, _u32, _vp, _sz, _vp, _u32p, _u32p]),
     "infur_stream_create": (C.c_int32, [_vp, _u32, C.POINTER(_vp)]),
     "infur_stream_destroy": (None, [_vp]),
+    "infur_stream_add_lane": (C.c_int32, [_vp, _vp]),
     "infur_stream_submit": (C.c_int32, [_vp, _vp, _u32, _u32, _f, _u32, C.c_uint64]),
     "infur_stream_pending": (C.c_uint32, [_vp]),
     "infur_stream_next_dims": (C.c_int32, [_vp, C.POINTER(C.c_uint64), _u32p, _u32p]),

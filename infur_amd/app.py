@@ -308,6 +308,10 @@ class StreamPath:
         ctx.check(ctx.L.infur_stream_create(ctx.h, depth, C.byref(h)))
         self.h = h
 
+    def add_lane(self, other: Context) -> None:
+        """A second context of the same device takes every other frame (kernels of consecutive frames overlap)."""
+        self.ctx.check(self.ctx.L.infur_stream_add_lane(self.h, other.h))
+
     def pending(self) -> int:
         return self.ctx.L.infur_stream_pending(self.h)
 

@@ -1387,7 +1387,10 @@ struct infur_stream {
         int32_t status = INFUR_OK;
         bool busy = false;
     };
-    infur_ctx* ctx = nullptr;
+    infur_ctx* ctx = nullptr;  // owner: holds the copy streams' device, receives the error messages
+    // compute lanes: frame i runs on lanes[i % n] (lanes[0] == ctx).  Frames are independent, so a second context of
+    // the same device (infur_stream_add_lane) lets the kernels of consecutive frames overlap
+    std::vector<infur_ctx*> lanes;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::vector<Slot> slots;
     uint64_t head = 0, tail = 0;  // tail = next to collect, head = next to submit
@@ -1419,7 +1422,8 @@ static void stream_orphan(infur_stream* st) {
     infur_ctx* c = st->ctx;
     if (!c) return;
     enter(c);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (infur_ctx* l : st->lanes)
+        if (l->stream) (void)hipStreamSynchronize(l->stream);
     if (st->s_h2d) (void)hipStreamSynchronize(st->s_h2d);
     if (st->s_d2h) (void)hipStreamSynchronize(st->s_d2h);
     for (auto& sl : st->slots) {
@@ -1435,11 +1439,13 @@ static void stream_orphan(infur_stream* st) {
     if (st->s_d2h) (void)hipStreamDestroy(st->s_d2h);
     st->s_h2d = st->s_d2h = nullptr;
     st->head = st->tail = 0;
-    for (size_t i = 0; i < c->streams.size(); i++)
-        if (c->streams[i] == st) {
-            c->streams.erase(c->streams.begin() + (long)i);
-            break;
-        }
+    for (infur_ctx* l : st->lanes)  // the stream is registered with every lane's context: any of them may go first
+        for (size_t i = 0; i < l->streams.size(); i++)
+            if (l->streams[i] == st) {
+                l->streams.erase(l->streams.begin() + (long)i);
+                break;
+            }
+    st->lanes.clear();
     st->ctx = nullptr;
 }
 
@@ -1452,6 +1458,7 @@ int32_t infur_stream_create(infur_ctx* c, uint32_t depth, infur_stream** out) {
         *out = nullptr;
         infur_stream* st = new infur_stream();
         st->ctx = c;
+        st->lanes.push_back(c);
         c->streams.push_back(st);
         st->slots.resize(depth);
         bool ok = hipStreamCreateWithFlags(&st->s_h2d, hipStreamNonBlocking) == hipSuccess &&
@@ -1481,6 +1488,18 @@ void infur_stream_destroy(infur_stream* st) {
 
 uint32_t infur_stream_pending(const infur_stream* st) { return st ? (uint32_t)(st->head - st->tail) : 0; }
 
+int32_t infur_stream_add_lane(infur_stream* st, infur_ctx* other) {
+    if (!st || !st->ctx || !other) return INFUR_E_INVALID_ARG;
+    infur_ctx* c = st->ctx;
+    if (other->device != c->device) return fail(c, INFUR_E_INVALID_ARG, "a lane must be a context of the stream's device (%d), got device %d", c->device, other->device);
+    for (infur_ctx* l : st->lanes)
+        if (l == other) return fail(c, INFUR_E_INVALID_ARG, "that context already is a lane of this stream");
+    if (st->head != st->tail) return fail(c, INFUR_E_INVALID_ARG, "add lanes while no frame is pending");
+    st->lanes.push_back(other);
+    other->streams.push_back(st);
+    return INFUR_OK;
+}
+
 int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                             uint64_t frame_id) {
     try {
@@ -1492,7 +1511,8 @@ int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, ui
         uint32_t ow = 0, oh = 0;
         rc = infur_scale_out_dims(w, h, factor, &ow, &oh);
         if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-        if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
+        infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
+        if (!lane->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
         const size_t depth = st->slots.size();
         if (st->head - st->tail >= depth)
             return fail(c, INFUR_E_CAPACITY, "all %zu slots are in flight: collect before submitting more", depth);
@@ -1506,13 +1526,16 @@ int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, ui
         sl.oh = oh;
         HIPCHK(c, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
         HIPCHK(c, hipEventRecord(sl.ev_h2d, st->s_h2d));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_h2d, 0));
+        HIPCHK(c, hipStreamWaitEvent(lane->stream, sl.ev_h2d, 0));
         uint8_t* d_rgba = (uint8_t*)sl.d_out;
         uint8_t* d_sc = d_rgba + rgba_bytes;
         uint32_t a = 0, b = 0;
-        sl.status = infur_frame_advance_dev(c, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
-        if (sl.status != INFUR_OK) return sl.status;
-        HIPCHK(c, hipEventRecord(sl.ev_comp, c->stream));
+        sl.status = infur_frame_advance_dev(lane, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
+        if (sl.status != INFUR_OK) {
+            if (lane != c) c->err = lane->err;
+            return sl.status;
+        }
+        HIPCHK(c, hipEventRecord(sl.ev_comp, lane->stream));
         HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
         HIPCHK(c, hipMemcpyAsync(sl.h_out, sl.d_out, rgba_bytes + sc_bytes, hipMemcpyDeviceToHost, st->s_d2h));
         HIPCHK(c, hipEventRecord(sl.ev_done, st->s_d2h));

@@ -93,6 +93,7 @@ extern "C" {
 
     pub fn infur_stream_create(c: *mut infur_ctx, depth: u32, out: *mut *mut infur_stream) -> i32;
     pub fn infur_stream_destroy(s: *mut infur_stream);
+    pub fn infur_stream_add_lane(s: *mut infur_stream, other: *mut infur_ctx) -> i32;
     pub fn infur_stream_submit(s: *mut infur_stream, bgr: *const u8, w: u32, h: u32, factor: f32,
                                mode: u32, frame_id: u64) -> i32;
     pub fn infur_stream_pending(s: *const infur_stream) -> u32;

@@ -218,6 +218,31 @@ def test_group_rejects_mixed_dtypes_and_one_shot_forms(blob50):
         b.close()
 
 
+def test_stream_with_two_lanes_equals_direct(blob50):
+    """infur_stream_add_lane: consecutive frames run on alternating contexts of one device; masks and their order are
+    those of the single-context path, and the lane's context may be destroyed before the stream."""
+    frames = [(i + 10, W.synth_frame(96 + 8 * (i % 2), 160, index=i)) for i in range(9)]
+    a, b = Context(device=0), Context(device=0)
+    Model(a).control(ModelCmd.LoadBlob(blob50))
+    with Group([a, b]) as g:
+        g.weights_broadcast(0)
+    sp = StreamPath(a, depth=3)
+    sp.add_lane(b)
+    with pytest.raises(InfurError):
+        sp.add_lane(b)  # twice
+    got = list(sp.run(frames, 0.5))
+    assert [g_[0] for g_ in got] == [f[0] for f in frames]
+    fp = FramePath(a)
+    for (fid, rgba), (_, img) in zip(got, frames):
+        ref, _ = fp.advance(img, 0.5)
+        assert (rgba == ref).all(), fid
+    b.close()  # a lane goes first: the stream becomes an empty handle
+    assert a.L.infur_stream_pending(sp.h) == 0
+    assert a.L.infur_stream_submit(sp.h, frames[0][1].ctypes.data, 160, 96, 0.5, 0, 1) == _lib.E_INVALID_ARG
+    sp.close()
+    a.close()
+
+
 # ---------------------------------------------------------------- bench.py launches its own ranks
 def test_bench_self_launches_two_ranks_on_one_gpu(tmp_path):
     """`python bench.py --gpus 2` (exactly what the driver runs) must start its own two ranks.  On this 1-GPU box
