@@ -56,7 +56,7 @@ def parse():
                          "operands with f32 accumulation (configs[4]'s mode)")
     ap.add_argument("--winograd-min-cin", type=int, default=0,
                     help="f32 stride-1 3x3 convs with Cin >= this run as Winograd F(2x2,3x3); 0 = library default, -1 = never")
-    ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4], help="Winograd output tile (0 = default)")
+    ap.add_argument("--winograd-tile", type=int, default=0, choices=[0, 2, 4, 6], help="Winograd output tile (0 = default: 6)")
     ap.add_argument("--depth", type=int, default=50, choices=[50, 101], help="backbone: FCN-ResNet50 (default) / 101")
     ap.add_argument("--cpu-probe", default=None, help=argparse.SUPPRESS)  # internal: child process of cpu_baseline
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -251,7 +251,15 @@ uint32_t f32_as_u32(float v) {  // Rust `as u32`: saturating, NaN -> 0
 
 int conv_out(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
 
-inline int wino_mt(const infur_ctx* c) { return c->opt.winograd_tile == 2 ? 2 : 4; }
+// output tile of the Winograd convs: the caller's choice, else F(6x6): 5.06x fewer MFMA FLOPs than the direct 3x3 (F(4x4):
+// 4x) and 1.9x instead of 2.27x the tensor in transform traffic.  Measured against the f32 CPU oracle (scripts/
+// f6_split_check.py): per-layer worst 1.07e-5 (F(4x4): 1.12e-5), whole-network logits 6-7e-6 in the exact-f32 mode
+// (F(4x4): 4-5e-6) and 4-6e-6 in the split mode (3e-6) -- north_star's budget is 1e-3.
+inline int wino_mt(const infur_ctx* c) {
+    const uint32_t t = c->opt.winograd_tile;
+    if (t == 2 || t == 4 || t == 6) return (int)t;
+    return 6;
+}
 inline int wino_planes(const infur_ctx* c) { return (wino_mt(c) + 2) * (wino_mt(c) + 2); }
 
 // stride-1 3x3 convs whose direct form is MFMA-bound run in the Winograd domain (f32 mode only:
@@ -545,7 +553,8 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
 // the worst case.  FCN-ResNet activations are O(1..100); the precision floor of small values is absolute
 // (1e-8 of unit scale) and does not show in the logits (tests/test_gpu_split.py).
 constexpr float kSplitActScale = 4.0f;
-constexpr float kSplitWinoScaleF4 = 0.125f, kSplitWinoScaleF2 = 1.0f;
+constexpr float kSplitWinoScaleF4 = 0.125f, kSplitWinoScaleF2 = 1.0f, kSplitWinoScaleF6 = 0.0625f;  // F6 amplifies up to 225x
+inline float split_wino_scale(int mt) { return mt == 6 ? kSplitWinoScaleF6 : (mt == 4 ? kSplitWinoScaleF4 : kSplitWinoScaleF2); }
 
 // ---- one convolution on the implicit-GEMM kernel ----
 int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, Tensor* out) {
@@ -572,7 +581,7 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         g.batch = P;
         g.in_bs = (size_t)T * in.c * 4; g.wt_bs = (size_t)L.cout * L.cin * 4; g.out_bs = (size_t)T * L.cout * 4;
         if (mode == INFUR_DTYPE_F32_SPLIT) {
-            g.a_scale = mt == 4 ? kSplitWinoScaleF4 : kSplitWinoScaleF2;
+            g.a_scale = split_wino_scale(mt);
             g.acc_scale = 1.0f / (g.a_scale * L.u_scale);
         }
         int gcfg = -1;
@@ -1630,7 +1639,7 @@ int32_t infur_split_range(infur_ctx* c, float* act_amax, float* wino_amax, uint3
     if (act_amax) *act_amax = v[0];
     if (wino_amax) *wino_amax = v[1];
     // beyond 65504 the hi half clamps (MODE.FP16_OVFL) and the pair stops being exact
-    const float ws = wino_mt(c) == 4 ? kSplitWinoScaleF4 : kSplitWinoScaleF2;
+    const float ws = split_wino_scale(wino_mt(c));
     if (saturated) *saturated = (v[0] * kSplitActScale > 65504.0f || v[1] * ws > 65504.0f) ? 1u : 0u;
     return INFUR_OK;
 }

@@ -38,7 +38,7 @@ struct ConvLayer {
     char role = 0;        // s stem, 1 2 3 block convs, d downsample, h head3x3, c classifier
     void* d_w = nullptr;   // repacked weights (context dtype; the stem's stay f32)
     float* d_b = nullptr;  // bias, always f32
-    float* d_u = nullptr;  // Winograd-domain weights U[16][cout][cin] (f32 stride-1 3x3 convs only)
+    float* d_u = nullptr;  // Winograd-domain weights U[(mt+2)^2][cout][cin] (f32 stride-1 3x3 convs only)
     // INFUR_DTYPE_F32_SPLIT: d_w / d_u hold f16 (hi, lo) pairs of w * w_scale / u * u_scale (powers of two)
     float w_scale = 1.0f, u_scale = 1.0f;
     // conv3 of a stage's first block: its weights and the downsample branch's side by side ([cout][cin + ds.cin],

@@ -1,8 +1,8 @@
-// winograd.hip -- Winograd F(m x m, 3x3) transforms (m = 2 or 4) around the batched implicit-GEMM
+// winograd.hip -- Winograd F(m x m, 3x3) transforms (m = 2, 4 or 6) around the batched implicit-GEMM
 // kernel.
 //
 // A stride-1 3x3 convolution (any dilation d, pad = d) costs 9 multiplies per output in the direct
-// form, 4 with F(2x2,3x3) and 2.25 with F(4x4,3x3): 2.25x / 4x fewer MFMA FLOPs, still plain f32
+// form, 4 with F(2x2,3x3), 2.25 with F(4x4,3x3) and 1.78 with F(6x6,3x3): 2.25x / 4x / 5.06x fewer MFMA FLOPs, still plain f32
 // arithmetic.  The stride-1 3x3 conv nodes of FCN-ResNet that run inside `session.run`
 // (infur/src/predict_onnx.rs:138) and are MFMA-bound in the direct form take this route:
 //
@@ -49,6 +49,19 @@ __device__ __forceinline__ void bt_1d(const V* d, V* t) {  // B^T d : (MT+2) -> 
         t[1 * SO] = d1 + d2;
         t[2 * SO] = d2 - d1;
         t[3 * SO] = d1 - d3;
+    } else if constexpr (MT == 6) {  // points 0, +-1, +-2, +-1/2, inf
+        const V d0 = d[0 * S], d1 = d[1 * S], d2 = d[2 * S], d3 = d[3 * S], d4 = d[4 * S], d5 = d[5 * S], d6 = d[6 * S], d7 = d[7 * S];
+        const V a12 = d2 + d6 - 4.25f * d4, b12 = d1 + d5 - 4.25f * d3;
+        const V a34 = d6 + 0.25f * d2 - 1.25f * d4, b34 = 0.5f * d1 - 2.5f * d3 + 2.0f * d5;
+        const V a56 = d6 + 4.0f * d2 - 5.0f * d4, b56 = 2.0f * d1 - 2.5f * d3 + 0.5f * d5;
+        t[0 * SO] = d0 - d6 + 5.25f * (d4 - d2);
+        t[1 * SO] = a12 + b12;
+        t[2 * SO] = a12 - b12;
+        t[3 * SO] = a34 + b34;
+        t[4 * SO] = a34 - b34;
+        t[5 * SO] = a56 + b56;
+        t[6 * SO] = a56 - b56;
+        t[7 * SO] = d7 - d1 + 5.25f * (d3 - d5);
     } else {
         const V d0 = d[0 * S], d1 = d[1 * S], d2 = d[2 * S], d3 = d[3 * S], d4 = d[4 * S], d5 = d[5 * S];
         t[0 * SO] = 4.0f * d0 - 5.0f * d2 + d4;
@@ -66,6 +79,15 @@ __device__ __forceinline__ void at_1d(const V* m, V* y) {  // A^T m : (MT+2) -> 
         const V m0 = m[0 * S], m1 = m[1 * S], m2 = m[2 * S], m3 = m[3 * S];
         y[0 * SO] = m0 + m1 + m2;
         y[1 * SO] = m1 - m2 - m3;
+    } else if constexpr (MT == 6) {
+        const V m0 = m[0 * S], m1 = m[1 * S], m2 = m[2 * S], m3 = m[3 * S], m4 = m[4 * S], m5 = m[5 * S], m6 = m[6 * S], m7 = m[7 * S];
+        const V s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4, s56 = m5 + m6, d56 = m5 - m6;
+        y[0 * SO] = m0 + s12 + s34 + 32.0f * s56;
+        y[1 * SO] = d12 + 2.0f * d34 + 16.0f * d56;
+        y[2 * SO] = s12 + 4.0f * s34 + 8.0f * s56;
+        y[3 * SO] = d12 + 8.0f * d34 + 4.0f * d56;
+        y[4 * SO] = s12 + 16.0f * s34 + 2.0f * s56;
+        y[5 * SO] = m7 + d12 + 32.0f * d34 + d56;
     } else {
         const V m0 = m[0 * S], m1 = m[1 * S], m2 = m[2 * S], m3 = m[3 * S], m4 = m[4 * S], m5 = m[5 * S];
         y[0 * SO] = m0 + m1 + m2 + m3 + m4;
@@ -82,6 +104,15 @@ __device__ __forceinline__ void g_1d(float g0, float g1, float g2, float* u) {  
         u[1] = 0.5f * (g0 + g1 + g2);
         u[2] = 0.5f * (g0 - g1 + g2);
         u[3] = g2;
+    } else if constexpr (MT == 6) {
+        u[0] = g0;
+        u[1] = -(g0 + g1 + g2) * (2.0f / 9.0f);
+        u[2] = -(g0 - g1 + g2) * (2.0f / 9.0f);
+        u[3] = g0 * (1.0f / 90.0f) + g1 * (1.0f / 45.0f) + g2 * (2.0f / 45.0f);
+        u[4] = g0 * (1.0f / 90.0f) - g1 * (1.0f / 45.0f) + g2 * (2.0f / 45.0f);
+        u[5] = g0 * (1.0f / 45.0f) + g1 * (1.0f / 90.0f) + g2 * (1.0f / 180.0f);
+        u[6] = g0 * (1.0f / 45.0f) - g1 * (1.0f / 90.0f) + g2 * (1.0f / 180.0f);
+        u[7] = g2;
     } else {
         u[0] = 0.25f * g0;
         u[1] = -(g0 + g1 + g2) * (1.0f / 6.0f);
@@ -260,9 +291,11 @@ static bool wino_vec4(int C) {
 hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, unsigned* amax, hipStream_t s) {
     const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
-    const bool v4 = wino_vec4(C);
+    const bool v4 = wino_vec4(C) && mt != 6;  // F(6x6): 64 patch vectors per thread -- 8-byte vectors keep them in registers
     const unsigned blocks = grid_for((size_t)T * (C / (v4 ? 4 : 2)));
-    if (mt == 2 && v4)
+    if (mt == 6)
+        hipLaunchKernelGGL((wino_input_kernel<6, f32x2>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
+    else if (mt == 2 && v4)
         hipLaunchKernelGGL((wino_input_kernel<2, f32x4w>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
     else if (mt == 2)
         hipLaunchKernelGGL((wino_input_kernel<2, f32x2>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
@@ -277,9 +310,11 @@ hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int
                               float* out, unsigned* amax, hipStream_t s) {
     const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
-    const bool v4 = wino_vec4(Cout);
+    const bool v4 = wino_vec4(Cout) && mt != 6;
     const unsigned blocks = grid_for((size_t)T * (Cout / (v4 ? 4 : 2)));
-    if (mt == 2 && v4)
+    if (mt == 6)
+        hipLaunchKernelGGL((wino_output_kernel<6, f32x2>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
+    else if (mt == 2 && v4)
         hipLaunchKernelGGL((wino_output_kernel<2, f32x4w>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
     else if (mt == 2)
         hipLaunchKernelGGL((wino_output_kernel<2, f32x2>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
@@ -295,6 +330,8 @@ hipError_t launch_wino_weights(const float* w_oihw, int O, int I, int mt, float*
     if (blocks > 4096) blocks = 4096;
     if (mt == 2)
         hipLaunchKernelGGL(wino_weight_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, O, I, U);
+    else if (mt == 6)
+        hipLaunchKernelGGL(wino_weight_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, O, I, U);
     else
         hipLaunchKernelGGL(wino_weight_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, O, I, U);
     return hipGetLastError();

@@ -115,7 +115,7 @@ class Context:
         o.profile = 1 if profile else 0
         o.keep_activations = 1 if keep_activations else 0
         o.winograd_min_cin = winograd_min_cin  # 0 = default (256), 0xFFFFFFFF = direct convs only
-        o.winograd_tile = winograd_tile  # 0 = default F(4x4,3x3), 2 = F(2x2,3x3)
+        o.winograd_tile = winograd_tile  # 0 = default F(6x6,3x3); 2 / 4 / 6 = forced
         o.no_autotune = 0 if autotune else 1
         o.no_fuse_downsample = 0 if fuse_downsample else 1
         o.no_fuse_stem_pool = 0 if fuse_stem_pool else 1

@@ -431,9 +431,9 @@ def test_model_load_from_onnx_file(blob50, tmp_path, oracle_model):
     c2.close()
 
 
-@pytest.mark.parametrize("tile,min_cin", [(2, 64), (4, 64), (4, 0xFFFFFFFF)])
+@pytest.mark.parametrize("tile,min_cin", [(2, 64), (4, 64), (6, 64), (4, 0xFFFFFFFF)])
 def test_winograd_variants_per_layer(blob50, tile, min_cin):
-    """Every conv output with Winograd F(2x2) / F(4x4) forced onto ALL stride-1 3x3 convs (dilation 1, 2
+    """Every conv output with Winograd F(2x2) / F(4x4) / F(6x6) forced onto ALL stride-1 3x3 convs (dilation 1, 2
     and 4, ragged tile edges), and with Winograd disabled, against the torch-CPU restatement."""
     from oracle.infur_oracle import COracle, TorchModel
 
