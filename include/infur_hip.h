@@ -111,7 +111,7 @@ typedef struct infur_kernel_record {
     double flops;       /* FLOPs this launch executes (2 x MAC); 0 for byte kernels */
     double bytes;       /* compulsory HBM bytes of this launch */
     double algo_flops;  /* direct-convolution FLOPs of the layer this launch completes (== flops except
-                           for Winograd-domain GEMMs, where it is 2.25x larger; 0 for transforms) */
+                           for Winograd-domain GEMMs, where it is up to 5x larger; 0 for transforms) */
 } infur_kernel_record;
 
 /* ---- library ---- */
