@@ -357,6 +357,17 @@ def main():
         dist.all_gather_object(shas, sha)
         agree = len(set(shas)) == 1
 
+    # for reference: the same frames with strictly one frame at a time (context 0 only), outside the timed region
+    one_ctx_fps = None
+    if K > 1 and world == 1:
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            for i in range(B):
+                fp.advance_dev(d_frames[i].data_ptr(), Wd, H, a.scale, d_masks[i].data_ptr(), d_masks[i].numel())
+        ctx.synchronize()
+        one_ctx_fps = 2 * B / (time.perf_counter() - t1)
+
     frames_total = world * B * a.steps
     fps = frames_total / elapsed
     out = {
@@ -367,7 +378,7 @@ def main():
         "config": {
             "workload": f"{Wd}x{H} packed-BGR frame, FCN-ResNet{a.depth} {a.dtype} (aux head {'off' if a.no_aux else 'on'}), "
                         f"scale={a.scale}" + (" [BASELINE configs[1]]" if (Wd, H, a.scale, a.dtype, a.depth) == (1920, 1080, 1.0, "f32", 50) else ""),
-            "frames_per_step_per_gpu": B, "contexts_per_gpu": K, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if world > 1 else None,
+            "frames_per_step_per_gpu": B, "contexts_per_gpu": K, "frames_per_s_one_context": one_ctx_fps, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if world > 1 else None,
             "weights": f"synthetic seed {W.DEFAULT_SEED:#x}, {nbytes / 1e6:.1f} MB blob",
             "weights_load_ms": round(load_ms, 2), "weights_bcast_ms": round(bcast_ms, 3),
             "weights_note": "weights_load_ms = broadcast + per-rank repack into kernel layouts; weights_bcast_ms = the "
@@ -440,6 +451,10 @@ def main():
                 "traffic": traffic, "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes "
                                                     "(profiles/traffic_latest.json); null if not collected for this shape",
                 "launches": len(dom), "avg_launch_ms": ms(dom) / max(len(dom), 1),
+                "avg_launch_note": "HIP events around each launch of the LAST frame of the timed region, which runs alone (the other "
+                                   "context is drained on the GPU first): compare with profiles/rNN_solo_kernel_stats.csv (rocprofv3 of "
+                                   "`bench.py --contexts-per-gpu 1`); in the default two-frames-in-flight trace a kernel shares the chip "
+                                   "with the other frame's kernel and its wall time is longer",
                 "flops_per_launch": algo_dom / max(len(dom), 1),
                 "algorithmic_bytes_per_launch": sum(r["bytes"] for r in dom) / max(len(dom), 1),
                 "note": "achieved = ALGORITHMIC (direct-convolution, BASELINE.md section 4) FLOPs of the layers these launches "

@@ -72,6 +72,20 @@ def main():
         bj = os.path.join(d, "bench_trace.json")
         if os.path.exists(bj):
             shutil.copy(bj, os.path.join(out, f"{tag}_bench_under_rocprof.json"))
+    ks2 = find(os.path.join(d, "trace_solo"), "*kernel_stats.csv")
+    if ks2:
+        shutil.copy(ks2, os.path.join(out, f"{tag}_solo_kernel_stats.csv"))
+        md += ["## kernel trace, one context (`… bench.py --contexts-per-gpu 1`): one kernel at a time -- these average durations are the ones",
+               "that must agree with the HIP-event durations of bench.py's roofline frame (which runs alone); the table above is the",
+               "default command with two frames in flight, where kernels of the two streams time-share the chip", "",
+               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+        for r in csv.DictReader(open(ks2)):
+            md.append(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
+                      f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+        md.append("")
+        bj = os.path.join(d, "bench_trace_solo.json")
+        if os.path.exists(bj):
+            shutil.copy(bj, os.path.join(out, f"{tag}_solo_bench_under_rocprof.json"))
     traffic = {}
     fe, wr = pmc(os.path.join(d, "pmc_FETCH_SIZE")), pmc(os.path.join(d, "pmc_WRITE_SIZE"))
     if fe or wr:
