@@ -459,7 +459,7 @@ def main():
                 "algorithmic_bytes_per_launch": sum(r["bytes"] for r in dom) / max(len(dom), 1),
                 "note": "achieved = ALGORITHMIC (direct-convolution, BASELINE.md section 4) FLOPs of the layers these launches "
                         "compute / their HIP-event time; these launches run the convolution directly, so algorithmic == executed. "
-                        "Stride-1 3x3 convs with Cin >= 256 run as Winograd F(6x6,3x3)-domain GEMMs instead: see `winograd`",
+                        "Stride-1 3x3 convs with Cin >= 128 run as Winograd F(6x6,3x3)-domain GEMMs instead: see `winograd`",
                 "winograd": {"launches": len(wg), "gemm_ms": ms(wg), "transform_ms": ms(wino),
                              "executed_tflops": tf(wg), "executed_frac": tf(wg) / peak,
                              "algorithmic_tflops_incl_transforms": sum(r["algo_flops"] for r in wg) / max(ms(wg) + ms(wino), 1e-9) / 1e9,
@@ -548,7 +548,7 @@ def split_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H):
         ceil = PEAK_F16_MFMA_TFLOPS / 3.0
         out["roofline"] = {"bound": "mfma", "achieved": flops * fps / 1e12, "peak": ceil, "unit": "TFLOP/s", "frac": flops * fps / 1e12 / ceil,
                            "note": "whole-frame algorithmic (direct-conv) FLOPs x frames/s against a third of the dense f16 MFMA peak "
-                                   "(three f16 MFMAs per f32 product); 11 convs run as Winograd F(6x6)"}
+                                   "(three f16 MFMAs per f32 product); 14 convs run as Winograd F(6x6)"}
     return out
 
 
@@ -598,7 +598,7 @@ def stream_scale05_rate(a, dev, blob, frames_np):
             "hbm_resident_frames_per_s": res_fps, "conv_gflop_per_frame": gflop,
             "roofline": {"bound": "mfma", "achieved": gflop * res_fps / 1e3, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": gflop * res_fps / 1e3 / PEAK_F32_MFMA_TFLOPS,
-                         "note": "whole-frame algorithmic (direct-conv) FLOPs x HBM-resident frames/s; 11 convs run as Winograd F(6x6)"}}
+                         "note": "whole-frame algorithmic (direct-conv) FLOPs x HBM-resident frames/s; 14 convs run as Winograd F(6x6)"}}
 
 
 def r101_f16_4k_rate(a, dev):

@@ -79,7 +79,7 @@ typedef struct infur_options {
     uint32_t profile;      /* 1: bracket every kernel with HIP events (infur_profile_*) */
     uint32_t keep_activations; /* 1: debug -- every conv output keeps its own buffer */
     uint32_t winograd_min_cin; /* f32 stride-1 3x3 convs with Cin >= this run in the Winograd domain;
-                                  0 = default (256), 0xFFFFFFFF = never */
+                                  0 = default (128), 0xFFFFFFFF = never */
     uint32_t winograd_tile;    /* output tile: 2 = F(2x2,3x3), 4 = F(4x4,3x3), 6 = F(6x6,3x3); 0 = default (6) */
     uint32_t no_autotune;      /* 0 (default): the first advance at a new frame size times the tile
                                   configurations of the conv kernel per layer shape and keeps the fastest

@@ -366,13 +366,13 @@ def test_profile_records(blob50):
     recs = c2.profile()
     names = [r["name"] for r in recs]
     # 57 convs in 53 launches (conv3 and the downsample branch of each stage's first block are one two-source
-    # GEMM) + maxpool + fused post; the 11 stride-1 3x3 convs with Cin >= 256 (layer3 x6, layer4 x3, both
+    # GEMM) + maxpool + fused post; the 14 stride-1 3x3 convs with Cin >= 128 (layer2 x3, layer3 x6, layer4 x3, both
     # heads) run in the Winograd domain and add an input and an output transform each
     wino = [r for r in recs if r["kernel"] in ("wino_input", "wino_output")]
     # (the stem convolution and the max-pool are one kernel)
     assert names[0] == "backbone.conv1+maxpool" and names[-1] == "out.resize+colorcode"
     assert sum(n.endswith("conv3+downsample") for n in names) == 4
-    assert len(wino) == 22 and len(recs) == 53 + 1 + len(wino)
+    assert len(wino) == 28 and len(recs) == 53 + 1 + len(wino)
     algo = sum(r["algo_flops"] for r in recs)
     assert abs(algo - W.conv_flops(96, 128)["total"]) < 1e-6 * algo
     assert sum(r["flops"] for r in recs) < algo  # Winograd executes 2.25x - 4x fewer MACs on those layers
