@@ -483,6 +483,9 @@ def main():
         out["config"]["conv_gflop_per_frame"] = flops["total"] / 1e9
         out["config"]["effective_conv_tflops"] = flops["total"] * fps / world / 1e12
 
+        # the headline's contexts (streams, arenas, weights) are released before the side measurements start
+        for c in ctxs:
+            c.close()
         if world == 1 and a.dtype == "f32" and not a.no_split:
             out["f32_split_mode"] = split_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H)
         default_workload = (Wd, H, a.scale, a.dtype, a.depth) == (1920, 1080, 1.0, "f32", 50)
