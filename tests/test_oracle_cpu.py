@@ -164,3 +164,51 @@ def test_blob_roundtrip():
     blob = W.pack_blob(ts, 50, 21, True)
     meta, out = W.unpack_blob(blob)
     assert meta["depth"] == 50 and out[0][0] == "a" and (out[0][1] == ts[0][1]).all() and (out[0][2] == ts[0][2]).all()
+
+
+# ---- independent corroboration of two restated third-party rules (round 2) ----
+# Neither library below is the reference's; they are independent implementations of the same published conventions
+# that happen to be in the image.  They pin the RULE (which source pixel / which interpolation coordinates), not the
+# reference's bytes: DESIGN.md section 4 keeps those rows "unpinned".
+@pytest.mark.parametrize("wh", [(640, 480), (1280, 720), (97, 61), (33, 17)])
+def test_nearest_rule_matches_pillow_outside_exact_ties(oracle, wh):
+    """fast_image_resize's Nearest (processing.rs:189) samples the source pixel under the CENTRE of the destination
+    pixel: src = floor((dst + 0.5) * src_len / dst_len).  Pillow's NEAREST uses the same convention (in 16.16 fixed
+    point, so it may land one pixel lower where (dst + 0.5) * scale is an exact integer): everywhere else the two
+    must agree byte for byte."""
+    PIL = pytest.importorskip("PIL.Image")
+    w, h = wh
+    fr = W.synth_frame(h, w, index=5)
+    checked = 0
+    for f in (0.5, 0.3, 0.77, 1.5, 2.0, 0.123):
+        rc, out = oracle.scale(fr, f, 0)
+        if rc:
+            continue
+        oh, ow = out.shape[:2]
+        pil = np.asarray(PIL.fromarray(fr).resize((ow, oh), PIL.NEAREST))
+        px = (np.arange(ow) + 0.5) * (w / ow)
+        py = (np.arange(oh) + 0.5) * (h / oh)
+        ok = (np.abs(py - np.round(py)) > 1e-6)[:, None] & (np.abs(px - np.round(px)) > 1e-6)[None, :]
+        if ok.mean() < 0.05:  # integer ratios: every centre falls on a pixel boundary, nothing to compare
+            continue
+        checked += 1
+        assert (pil[ok] == out[ok]).all(), (wh, f)
+    assert checked >= 3
+
+
+@pytest.mark.parametrize("dims", [(135, 240, 1080, 1920), (17, 23, 135, 181), (68, 120, 540, 960), (3, 4, 24, 32), (1, 1, 5, 7)])
+def test_upsample_rule_matches_torch_interpolate(oracle, dims):
+    """The model's final node is what torch.onnx writes for F.interpolate(mode='bilinear', align_corners=False):
+    Resize(linear, pytorch_half_pixel).  torch's own CPU kernel is an independent implementation of that coordinate
+    rule; the oracle's restatement must agree to rounding (a wrong rule -- align_corners, asymmetric -- is off by
+    O(0.1) of the value range)."""
+    import torch
+
+    lh, lw, oh, ow = dims
+    x = np.random.default_rng(lh * 1000 + lw).standard_normal((21, lh, lw)).astype(np.float32)
+    a = oracle.upsample_bilinear(x, oh, ow)
+    b = torch.nn.functional.interpolate(torch.from_numpy(x)[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].numpy()
+    assert np.abs(a - b).max() < 2e-4
+    if lh > 1 and lw > 1:  # and the other conventions are measurably different, so the bound above means something
+        c = torch.nn.functional.interpolate(torch.from_numpy(x)[None], size=(oh, ow), mode="bilinear", align_corners=True)[0].numpy()
+        assert np.abs(a - c).max() > 1e-2
