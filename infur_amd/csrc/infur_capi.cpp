@@ -1504,6 +1504,7 @@ int32_t infur_stream_add_lane(infur_stream* st, infur_ctx* other) {
     for (infur_ctx* l : st->lanes)
         if (l == other) return fail(c, INFUR_E_INVALID_ARG, "that context already is a lane of this stream");
     if (st->head != st->tail) return fail(c, INFUR_E_INVALID_ARG, "add lanes while no frame is pending");
+    if (other->opt.compute_dtype != c->opt.compute_dtype) return fail(c, INFUR_E_INVALID_ARG, "a lane must use the stream's compute_dtype: its frames would otherwise differ");
     st->lanes.push_back(other);
     other->streams.push_back(st);
     return INFUR_OK;

@@ -343,16 +343,19 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
     auto transparent = [&](const Node& n) { return n.op == "Identity" || n.op == "Dropout"; };
     // the nodes that compute on tensor t, looking through Identity / Dropout; Shape readers (the Resize size
     // arithmetic) are not data consumers
-    std::function<void(const std::string&, std::vector<int>&)> users = [&](const std::string& t, std::vector<int>& out) {
+    // (depth-limited: a hostile file may chain Identity nodes into a cycle, which must end in a format error, not in
+    // unbounded recursion behind the C ABI)
+    std::function<void(const std::string&, std::vector<int>&, int)> users_d = [&](const std::string& t, std::vector<int>& out, int depth) {
         auto it = consumers.find(t);
-        if (it == consumers.end()) return;
+        if (it == consumers.end() || depth > 64) return;
         for (int i : it->second) {
             const Node& n = nodes[i];
             if (n.op == "Shape") continue;
-            if (transparent(n)) { if (!n.out.empty() && n.in[0] == t) users(n.out[0], out); }
+            if (transparent(n)) { if (!n.out.empty() && n.in[0] == t) users_d(n.out[0], out, depth + 1); }
             else out.push_back(i);
         }
     };
+    auto users = [&](const std::string& t, std::vector<int>& out) { users_d(t, out, 0); };
     // origin of a tensor, looking back through Identity / Dropout
     auto origin = [&](std::string t) {
         for (int guard = 0; guard < 64; guard++) {

@@ -171,3 +171,13 @@ def test_hostile_tensor_dims_do_not_reach_an_allocation(lib):
     for _ in range(50):
         junk = b"\x08\x06" + bytes(rng.integers(0, 256, int(rng.integers(1, 200)), dtype=np.uint8))
         assert convert(lib, junk)[0] == _lib.E_MODEL_FORMAT
+
+
+def test_identity_cycle_is_a_format_error_not_a_crash(lib):
+    """A (non-DAG) file whose Identity nodes feed each other must be rejected without unbounded recursion."""
+    n1 = OW.f_bytes(1, OW.node("Identity", ["input"], ["a"]))
+    n2 = OW.f_bytes(1, OW.node("Identity", ["a"], ["b"]))
+    n3 = OW.f_bytes(1, OW.node("Identity", ["b"], ["a"]))
+    g = n1 + n2 + n3 + OW.f_bytes(11, OW.value_info("input", 1, ("N", 3, "H", "W"))) + OW.f_bytes(12, OW.value_info("b", 1, ("N", 21, "H", "W")))
+    model = OW.f_varint(1, 6) + OW.f_bytes(7, g) + OW.f_bytes(8, OW.f_str(1, "") + OW.f_varint(2, 12))
+    assert convert(lib, model)[0] == _lib.E_MODEL_FORMAT
