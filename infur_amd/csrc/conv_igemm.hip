@@ -23,6 +23,7 @@
 // form (G1: 1x1 GEMM), the residual prefetch (RESPF) and the two-source form (DUAL: conv3 + downsample branch).
 // Every tile configuration accumulates k in the same order: they are bit-identical, the choice is a speed knob
 // (pick_cfg in infur_capi.cpp measures it per layer shape).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -711,15 +712,16 @@ static hipError_t launch_cfg_g(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)lds_bytes(BM, BN, WM, WN, NBUF);
     auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT, G1, RESPF, DUAL>;
     // > 64 KB of dynamic LDS needs the attribute once per kernel AND per device (a process may hold contexts on
-    // several GPUs); a context is driven from one thread, two contexts racing here only repeat the call
-    static bool attr_done[64] = {};
+    // several GPUs, each driven from its own thread -- infur_group): the flags are atomics, and two threads that both
+    // find a flag clear simply both make the (idempotent) call
+    static std::atomic<bool> attr_done[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63, attr_done[63] = false;
-    if (!attr_done[dev]) {
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (!known || !attr_done[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
+        if (known) attr_done[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(k, dim3(mtiles * ntiles * (a.batch > 1 ? a.batch : 1)), dim3(WM * WN * 64), lds, s, a, mtiles, ntiles);
     return hipGetLastError();
