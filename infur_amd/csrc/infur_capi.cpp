@@ -339,8 +339,8 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
     hipError_t e = hipMemsetAsync(d_max, 0, 2 * n * sizeof(float), c->stream);
     for (size_t i = 0; i < n && e == hipSuccess; i++) {
         const ConvLayer& L = g[i];
-        if (L.role == 's') continue;
         e = launch_absmax((const float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, d_max + 2 * i, c->stream);
+        if (L.role == 's') continue;  // the stem keeps f32 weights (its kernel splits them while it stages them): scale only
         if (e == hipSuccess && L.d_u) e = launch_absmax(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, d_max + 2 * i + 1, c->stream);
         // (a 1x1 conv has no Winograd weights: the second slot takes the conv3 ++ downsample matrix)
         if (e == hipSuccess && L.d_wcat)
@@ -357,8 +357,8 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
     };
     for (size_t i = 0; i < n; i++) {
         ConvLayer& L = g[i];
-        if (L.role == 's') continue;
         L.w_scale = pow2_for(mx[2 * i]);
+        if (L.role == 's') continue;
         HIPCHK(c, launch_split_weights((float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, L.w_scale, c->stream));
         if (L.d_u) {
             L.u_scale = pow2_for(mx[2 * i + 1]);
@@ -674,8 +674,9 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
         RETIF(talloc(c, ph, pw, 64, act_es(c), &x));
         ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes(),
                      2.0 * sh * sw * 64 * 147);
-        HIPCHK(c, launch_stem_pool(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, c->d_pre_lut, x.p, ctx_f16(c) ? 1 : 0, sh, sw, ph, pw,
-                                   c->d_range, c->stream));
+        // exact f32 MFMA in the f32 mode; in the f16-rate modes the stem runs on the f16 matrix cores as the conv stack does
+        HIPCHK(c, launch_stem_pool(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, c->d_pre_lut, x.p, ctx_mode(c), sh, sw, ph, pw,
+                                   kSplitActScale, stem.w_scale, c->d_range, c->stream));
     } else {
         {
             RETIF(talloc(c, sh, sw, 64, act_es(c), &s));

@@ -66,9 +66,11 @@ hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt
                                hipStream_t s);
 
 // stem + maxpool 3x3/2 pad 1 in one kernel: out = pooled [PH][PW][64]; the SH x SW stem tensor is never written.
-// Bit-identical to launch_stem_conv7x7 -> launch_maxpool3x3s2.
+// mode 0: exact f32 MFMA, bit-identical to launch_stem_conv7x7 -> launch_maxpool3x3s2 (f32 out).  mode 1 (f16 out): f16
+// operands on the f16 MFMA.  mode 2 (f32 out): operands as f16 hi + lo pairs of value * a_scale / weight * w_scale (powers
+// of two), three MFMAs per product, f32-grade.
 hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const float* bias, const float* lut, void* out,
-                            int f16, int SH, int SW, int PH, int PW, unsigned* amax, hipStream_t s);
+                            int mode, int SH, int SW, int PH, int PW, float a_scale, float w_scale, unsigned* amax, hipStream_t s);
 
 // maxpool 3x3 stride 2 pad 1, NHWC f32 / f16 (C % 4 == 0)
 hipError_t launch_maxpool3x3s2(const void* in, int H, int W, int C, void* out, int f16, int OH, int OW,

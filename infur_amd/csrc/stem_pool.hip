@@ -156,6 +156,71 @@ static_assert(SP_NPIX <= 256 && SP_NPIX > 224, "the stem tile must fill 8 M-bloc
 
 __host__ __device__ constexpr int sp_koff(int k) { return (k / 21) * (SP_IW * 3) + (k % 21); }
 
+// stem tile (+bias, ReLU, * acc_scale) -> LDS -> 3x3/2 max-pool -> global; shared by the f32 and the f16-rate stems.
+// `smem` is the whole (now idle) operand LDS; every wave has passed a barrier since its last operand read.
+template <typename OutT>
+__device__ __forceinline__ void stem_stage_and_pool(float* smem, const f32x16s (&acc)[2][2], const int (&pidx)[2], int half, float acc_scale,
+                                                    const float* __restrict__ bias, OutT* __restrict__ out, int py0, int px0, int sy0, int sx0,
+                                                    int SH, int SW, int PH, int PW, unsigned* __restrict__ amax) {
+    const int tid = threadIdx.x;
+    float* stage = smem;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float* o = stage + pidx[i] * SP_STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = j * 32 + 8 * g + 4 * half;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+                float4 v;
+                v.x = fmaxf(acc[i][j][4 * g + 0] * acc_scale + b4.x, 0.f);
+                v.y = fmaxf(acc[i][j][4 * g + 1] * acc_scale + b4.y, 0.f);
+                v.z = fmaxf(acc[i][j][4 * g + 2] * acc_scale + b4.z, 0.f);
+                v.w = fmaxf(acc[i][j][4 * g + 3] * acc_scale + b4.w, 0.f);
+                if constexpr (sizeof(OutT) == 2) {  // the unfused path stores the stem output as f16: round here, max after
+                    v.x = (float)(_Float16)v.x; v.y = (float)(_Float16)v.y; v.z = (float)(_Float16)v.z; v.w = (float)(_Float16)v.w;
+                }
+                *reinterpret_cast<float4*>(o + n) = v;
+            }
+    }
+    __syncthreads();
+
+    float vmax = 0.f;
+    for (int it = tid; it < SP_PR * SP_PC * 16; it += 256) {
+        const int c4 = it & 15, pp = it >> 4;
+        const int pr = pp / SP_PC, pc = pp - pr * SP_PC;
+        const int py = py0 + pr, pxo = px0 + pc;
+        if (py >= PH || pxo >= PW) continue;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const int sr = 2 * pr + dy;  // stem row inside the tile; absolute row sy0 + sr
+            if ((unsigned)(sy0 + sr) >= (unsigned)SH) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const int sc = 2 * pc + dx;
+                if ((unsigned)(sx0 + sc) >= (unsigned)SW) continue;
+                const float4 v = *reinterpret_cast<const float4*>(stage + (sr * SP_SC + sc) * SP_STAGE + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        OutT* o = out + ((size_t)py * PW + pxo) * 64 + c4 * 4;
+        if constexpr (sizeof(OutT) == 4) {
+            *reinterpret_cast<float4*>(o) = m;
+        } else {
+            f16x4 hv = {(_Float16)m.x, (_Float16)m.y, (_Float16)m.z, (_Float16)m.w};
+            *reinterpret_cast<f16x4*>(o) = hv;
+        }
+        vmax = fmaxf(vmax, fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w)));
+    }
+    if (amax) {  // range monitor of the split mode (pooled values are >= 0)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(vmax));
+    }
+}
+
 // ABL: timing ablations (INFUR_STEM_ABL, results wrong): 1 = no MFMA loop, 2 = no prologue loads (LDS left as is),
 // 3 = no stage/pool phase
 template <typename OutT, int ABL = 0>
@@ -260,69 +325,162 @@ __global__ void __launch_bounds__(256, 2)
         return;
     }
 
-    float* stage = smem;
+    stem_stage_and_pool<OutT>(smem, acc, pidx, half, 1.0f, bias, out, py0, px0, sy0, sx0, SH, SW, PH, PW, amax);
+}
+
+// ---------------------------------------------------------------------------------------
+// The same fused stem + max-pool on the f16 matrix cores, for the two f16-rate modes of the conv stack
+// (INFUR_DTYPE_F16: f16 operands; INFUR_DTYPE_F32_SPLIT: every operand value as an f16 hi + lo pair, three MFMAs per
+// product, f32-grade result -- conv_igemm.hip).  The exact-f32 stem costs 18.9k MFMA cycles per wave and was the largest
+// single item below its roofline in those modes (0.16 of 5.4 ms in the split mode); v_mfma_f32_32x32x16_f16 does the
+// same contraction in 1.4k (f16) / 4.2k (split) cycles.
+//
+// K is laid out so that a lane's 8 consecutive k are 8 consecutive halfs of one patch row: k = ky * 24 + j with
+// j = kx * 3 + c for j < 21 and three zero-weight pads per row; 7 rows = 168, padded to 176 = 11 slices of 16.  Group
+// g = k / 8 is (ky, jg) = (g / 3, 8 * (g % 3)); lanes 0-31 of slice s take group 2s, lanes 32-63 group 2s + 1.  A pixel's
+// fragment starts at an arbitrary 4-byte boundary (pixel stride 12 bytes), hence four ds_read_b32 (bank stride 3:
+// conflict-free); the weights sit in LDS as [n][184] halfs, one ds_read_b128 per fragment.  Pad positions read real
+// neighbouring patch values (finite) against zero weights.
+// ---------------------------------------------------------------------------------------
+constexpr int S16_PSTR = 160;  // halfs per patch row (51 px * 3 = 153, + room for the last pixel's 24-wide window)
+constexpr int S16_K = 176, S16_WSTR = 184, S16_GROUPS = 22;
+constexpr int S16_PATCH_H = SP_IH * S16_PSTR;  // halfs per patch plane
+constexpr int S16_W_H = 64 * S16_WSTR;         // halfs per weight plane
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
+template <typename OutT, bool SPLIT>
+__global__ void __launch_bounds__(256, 2)
+    stem_pool16_kernel(const uint8_t* __restrict__ bgr, int H, int W, const float* __restrict__ wt, const float* __restrict__ bias,
+                       const float* __restrict__ lut, OutT* __restrict__ out, int SH, int SW, int PH, int PW,
+                       float a_scale, float w_scale, float acc_scale, unsigned* __restrict__ amax) {
+    constexpr int NP = SPLIT ? 2 : 1;  // operand planes: hi (, lo)
+    __shared__ __attribute__((aligned(16))) float smem[SP_LDS_FLOATS];
+    _Float16* patch = reinterpret_cast<_Float16*>(smem);  // [NP][SP_IH][S16_PSTR]
+    _Float16* wsm = patch + NP * S16_PATCH_H;              // [NP][64][S16_WSTR]
+    float* slut = smem + SP_LDS_FLOATS - 768;
+    static_assert((NP * (S16_PATCH_H + S16_W_H)) * 2 <= (SP_LDS_FLOATS - 768) * 4, "operands + look-up table exceed the LDS allocation");
+    const int tid = threadIdx.x;
+    const int py0 = blockIdx.y * SP_PR, px0 = blockIdx.x * SP_PC;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;
+    if constexpr (SPLIT) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // MODE.FP16_OVFL: saturate, never inf
+
+    // all global loads first (frame bytes, table, weights), then the LDS fills
+    constexpr int NPX = (SP_IH * SP_IW + 255) / 256;
+    constexpr int NWT = (ST_K * 64 + 255) / 256;  // 37 weights per thread
+    uint8_t pb[NPX][3];
+    bool pin[NPX];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        float* o = stage + pidx[i] * SP_STAGE;
+    for (int j = 0; j < NPX; j++) {
+        const int i = tid + 256 * j;
+        const int r = i / SP_IW, q = i - r * SP_IW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        pin[j] = i < SP_IH * SP_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const uint8_t* p = bgr + ((size_t)(pin[j] ? iy : 0) * W + (pin[j] ? ix : 0)) * 3;
+        pb[j][0] = p[0];
+        pb[j][1] = p[1];
+        pb[j][2] = p[2];
+    }
+    const float l0 = lut[tid], l1 = lut[tid + 256], l2 = lut[tid + 512];
+    // zero the operand planes (row / K pads must be finite zeros), publish the table
+    for (int i = tid; i < NP * (S16_PATCH_H + S16_W_H) / 2; i += 256) reinterpret_cast<unsigned*>(patch)[i] = 0u;
+    slut[tid] = l0;
+    slut[tid + 256] = l1;
+    slut[tid + 512] = l2;
+    __syncthreads();
+    auto put = [&](_Float16* plane0, int plane_halfs, int idx, float x) {  // x -> f16 (, hi + lo)
+        const _Float16 hi = (_Float16)x;
+        plane0[idx] = hi;
+        if constexpr (SPLIT) plane0[plane_halfs + idx] = (_Float16)(x - (float)hi);
+    };
+#pragma unroll 4
+    for (int j = 0; j < NWT; j++) {  // wt[k][n] f32, k = ky * 21 + (kx * 3 + c)  ->  wsm[n][ky * 24 + (kx * 3 + c)]
+        const int i = tid + 256 * j;
+        if (i < ST_K * 64) {
+            const int k = i >> 6, n = i & 63;
+            const int ky = k / 21, jj = k - ky * 21;
+            put(wsm, S16_W_H, n * S16_WSTR + ky * 24 + jj, wt[i] * w_scale);
+        }
+    }
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int n = j * 32 + 8 * g + 4 * half;
-                const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-                float4 v;
-                v.x = fmaxf(acc[i][j][4 * g + 0] + b4.x, 0.f);
-                v.y = fmaxf(acc[i][j][4 * g + 1] + b4.y, 0.f);
-                v.z = fmaxf(acc[i][j][4 * g + 2] + b4.z, 0.f);
-                v.w = fmaxf(acc[i][j][4 * g + 3] + b4.w, 0.f);
-                if constexpr (sizeof(OutT) == 2) {  // the unfused path stores the stem output as f16: round here, max after
-                    v.x = (float)(_Float16)v.x; v.y = (float)(_Float16)v.y; v.z = (float)(_Float16)v.z; v.w = (float)(_Float16)v.w;
-                }
-                *reinterpret_cast<float4*>(o + n) = v;
-            }
+    for (int j = 0; j < NPX; j++) {
+        const int i = tid + 256 * j;
+        if (i >= SP_IH * SP_IW || !pin[j]) continue;  // outside the frame: the zero padding of the NORMALISED tensor
+        const int r = i / SP_IW, q = i - r * SP_IW;
+        const int o = r * S16_PSTR + q * 3;
+        put(patch, S16_PATCH_H, o + 0, slut[0 * 256 + pb[j][2]] * a_scale);  // R
+        put(patch, S16_PATCH_H, o + 1, slut[1 * 256 + pb[j][1]] * a_scale);  // G
+        put(patch, S16_PATCH_H, o + 2, slut[2 * 256 + pb[j][0]] * a_scale);  // B
     }
     __syncthreads();
 
-    float vmax = 0.f;
-    for (int it = tid; it < SP_PR * SP_PC * 16; it += 256) {
-        const int c4 = it & 15, pp = it >> 4;
-        const int pr = pp / SP_PC, pc = pp - pr * SP_PC;
-        const int py = py0 + pr, pxo = px0 + pc;
-        if (py >= PH || pxo >= PW) continue;
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int px = lane & 31, half = lane >> 5;
+    f32x16s acc[2][2];
 #pragma unroll
-        for (int dy = 0; dy < 3; dy++) {
-            const int sr = 2 * pr + dy;  // stem row inside the tile; absolute row sy0 + sr
-            if ((unsigned)(sy0 + sr) >= (unsigned)SH) continue;
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int dx = 0; dx < 3; dx++) {
-                const int sc = 2 * pc + dx;
-                if ((unsigned)(sx0 + sc) >= (unsigned)SW) continue;
-                const float4 v = *reinterpret_cast<const float4*>(stage + (sr * SP_SC + sc) * SP_STAGE + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    int pidx[2];
+    const char* pa[2];  // byte address of the pixel's patch origin (plane 0)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        pidx[i] = (2 * wave + i) * 32 + px;
+        const int p = pidx[i] < SP_NPIX ? pidx[i] : SP_NPIX - 1;
+        const int r = p / SP_SC, c = p - r * SP_SC;
+        pa[i] = reinterpret_cast<const char*>(patch) + ((2 * r) * S16_PSTR + 6 * c) * 2;
+    }
+    const char* pw = reinterpret_cast<const char*>(wsm) + px * S16_WSTR * 2;
+#pragma unroll
+    for (int s = 0; s < S16_K / 16; s++) {
+        // this lane's group: 2s (lanes 0-31) or 2s + 1 (lanes 32-63); both are compile-time per half
+        const int g0 = 2 * s, g1 = 2 * s + 1 < S16_GROUPS - 1 ? 2 * s + 1 : S16_GROUPS - 1;
+        const int ga = (g0 < 21 ? g0 : 20), gb = (g1 < 21 ? g1 : 20);  // groups 21+ are K padding: weights are zero there
+        const int aoff = half ? ((gb / 3) * S16_PSTR * 2 + (gb % 3) * 16) : ((ga / 3) * S16_PSTR * 2 + (ga % 3) * 16);
+        const int boff = (half ? g1 : g0) * 16;
+        f16x8 a[2][NP], b[2][NP];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                const unsigned* q = reinterpret_cast<const unsigned*>(pa[i] + pl * S16_PATCH_H * 2 + aoff);
+                const u32x4s v = {q[0], q[1], q[2], q[3]};
+                a[i][pl] = __builtin_bit_cast(f16x8, v);
             }
-        }
-        OutT* o = out + ((size_t)py * PW + pxo) * 64 + c4 * 4;
-        if constexpr (sizeof(OutT) == 4) {
-            *reinterpret_cast<float4*>(o) = m;
-        } else {
-            f16x4 hv = {(_Float16)m.x, (_Float16)m.y, (_Float16)m.z, (_Float16)m.w};
-            *reinterpret_cast<f16x4*>(o) = hv;
-        }
-        vmax = fmaxf(vmax, fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w)));
-    }
-    if (amax) {  // range monitor of the split mode (pooled values are >= 0)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(vmax));
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++)
+                b[jn][pl] = *reinterpret_cast<const f16x8*>(pw + pl * S16_W_H * 2 + jn * 32 * S16_WSTR * 2 + boff);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++) {
+                if constexpr (SPLIT) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[jn][0], a[i][1], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[jn][1], a[i][0], acc[i][jn], 0, 0, 0);
+                }
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[jn][0], a[i][0], acc[i][jn], 0, 0, 0);
+            }
     }
+    __syncthreads();  // every wave is done with the operands: their LDS becomes the stem tile
+    stem_stage_and_pool<OutT>(smem, acc, pidx, half, acc_scale, bias, out, py0, px0, sy0, sx0, SH, SW, PH, PW, amax);
 }
 
 hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const float* bias, const float* lut, void* out,
-                            int f16, int SH, int SW, int PH, int PW, unsigned* amax, hipStream_t s) {
+                            int mode, int SH, int SW, int PH, int PW, float a_scale, float w_scale, unsigned* amax, hipStream_t s) {
     dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
     static const int abl = getenv("INFUR_STEM_ABL") ? atoi(getenv("INFUR_STEM_ABL")) : 0;
-    if (f16)
+    static const int exact = getenv("INFUR_STEM_F32") ? atoi(getenv("INFUR_STEM_F32")) : 0;  // measurement hook: f32 MFMA stem in every mode
+    if (mode == 1 && !exact)
+        hipLaunchKernelGGL((stem_pool16_kernel<_Float16, false>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (_Float16*)out, SH, SW, PH,
+                           PW, 1.0f, 1.0f, 1.0f, amax);
+    else if (mode == 2 && !exact)
+        hipLaunchKernelGGL((stem_pool16_kernel<float, true>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW,
+                           a_scale, w_scale, 1.0f / (a_scale * w_scale), amax);
+    else if (mode == 1)
         hipLaunchKernelGGL(stem_pool_kernel<_Float16>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (_Float16*)out, SH, SW, PH, PW, amax);
     else if (abl == 1)
         hipLaunchKernelGGL((stem_pool_kernel<float, 1>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW, amax);

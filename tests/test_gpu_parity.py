@@ -477,9 +477,12 @@ def test_tiny_and_ragged_frames(ctx, model, oracle_model, wh):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16", "f32s"])
-def test_fused_stem_pool_is_bit_identical(blob50, dtype):
-    """stem 7x7/2 + max-pool 3x3/2 as one kernel (the 132.7 MB stem tensor is never written) == the two-kernel form,
-    bit for bit, at sizes that exercise ragged pooled tiles, odd stem extents and 1-pixel maps."""
+def test_fused_stem_pool_matches_the_two_kernel_form(blob50, dtype):
+    """stem 7x7/2 + max-pool 3x3/2 as one kernel (the 132.7 MB stem tensor is never written) against the two-kernel form
+    at sizes that exercise ragged pooled tiles, odd stem extents and 1-pixel maps.  In the f32 mode both use the exact
+    f32 MFMA with the same k order: bit-identical.  In the f16-rate modes the fused stem runs on the f16 matrix cores
+    (f16 operands / f16 hi+lo pairs) while the two-kernel debug form stays exact f32: the logits agree within the
+    mode's own tolerance."""
     lows = {}
     sizes = [(64, 48), (97, 61), (5, 3), (1, 1), (130, 66), (320, 240), (175, 93)]
     for fuse in (True, False):
@@ -491,6 +494,11 @@ def test_fused_stem_pool_is_bit_identical(blob50, dtype):
                 m.advance(W.synth_frame(h, w, index=w), out)
                 res.append([x.copy() for x in m.lowres()])
             lows[fuse] = res
+    tol = {"f32": 0.0, "f16": 5e-3, "f32s": 2e-5}[dtype]
     for (w, h), a, b in zip(sizes, lows[True], lows[False]):
         for x, y in zip(a, b):
-            assert (x.view(np.uint32) == y.view(np.uint32)).all(), (dtype, w, h)
+            if tol == 0.0:
+                assert (x.view(np.uint32) == y.view(np.uint32)).all(), (dtype, w, h)
+            else:
+                e = rel_err(x, y)
+                assert e < tol, (dtype, w, h, e)
