@@ -786,6 +786,8 @@ constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
 int conv_igemm_num_configs() { return kNumCfgs; }
 
+int conv_igemm_config_tile_area(int cfg) { return cfg < 0 || cfg >= kNumCfgs ? 0 : kCfgs[cfg].bm * kCfgs[cfg].bn; }
+
 const char* conv_igemm_config_name(int cfg, int mode) {
     if (cfg < 0 || cfg >= kNumCfgs || mode < 0 || mode > 2) return "conv_igemm<?>";
     return kCfgs[cfg].name[mode];

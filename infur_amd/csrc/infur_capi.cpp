@@ -522,6 +522,7 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
         c->tune_warm = true;
     }
     float best = 1e30f;
+    std::vector<std::pair<int, float>> timed;
     for (int k = 0; k < conv_igemm_num_configs(); k++) {
         if (!conv_igemm_config_valid(a, k, mode)) continue;
         HIPCHK(c, launch_conv_igemm(a, mode, out_f32, k, c->stream));  // warm-up (attributes, caches)
@@ -535,11 +536,17 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
             HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
             if (ms < fastest) fastest = ms;
         }
+        timed.emplace_back(k, fastest);
         if (fastest < best) {
             best = fastest;
             *cfg = k;
         }
     }
+    // Tie-break towards the larger tile: among the configurations within 2 % of the fastest, the one with the largest
+    // BM x BN re-reads its operands least (A once per N tile, B once per M tile) -- the same speed for less L2 / Infinity
+    // Cache / HBM traffic, which is also what leaves room for a second frame in flight
+    for (const auto& kt : timed)
+        if (kt.second <= best * 1.02f && conv_igemm_config_tile_area(kt.first) > conv_igemm_config_tile_area(*cfg)) *cfg = kt.first;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     c->tuned[key] = *cfg;

@@ -45,6 +45,7 @@ struct ConvArgs {
 // configuration produces bit-identical results; only the speed differs.
 hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, hipStream_t s);
 int conv_igemm_num_configs();
+int conv_igemm_config_tile_area(int cfg);  // BM * BN of a configuration (operand re-reads fall with it)
 int conv_igemm_default_config(const ConvArgs& a);
 bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode);
 const char* conv_igemm_config_name(int cfg, int mode);
