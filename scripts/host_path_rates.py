@@ -22,3 +22,17 @@ for depth in (2, 3):
 m = fp.advance_batch([frames[i % 4] for i in range(16)], 1.0)
 t = time.perf_counter(); m = fp.advance_batch([frames[i % 4] for i in range(32)], 1.0)
 print(f"infur_batch_advance 32 x 1080p: {32 / (time.perf_counter() - t):.1f} frames/s")
+# two contexts of the device: a second compute lane for the stream, a 2-context group for the batch
+from infur_amd.processors import Group
+c2 = Context(device=0, dtype=dtype)
+with Group([c, c2]) as g:
+    g.weights_broadcast(0)
+    sp = StreamPath(c, depth=4); sp.add_lane(c2)
+    list(sp.run([(i, frames[i % 4]) for i in range(8)], 1.0))
+    t = time.perf_counter(); n = 64
+    out = list(sp.run([(i, frames[i % 4]) for i in range(n)], 1.0))
+    print(f"infur_stream depth 4, two lanes, 1080p scale 1.0: {n / (time.perf_counter() - t):.1f} frames/s")
+    sp.close()
+    g.advance_batch([frames[i % 4] for i in range(16)], 1.0)
+    t = time.perf_counter(); g.advance_batch([frames[i % 4] for i in range(64)], 1.0)
+    print(f"infur_group_batch_advance (2 contexts on one GPU) 64 x 1080p: {64 / (time.perf_counter() - t):.1f} frames/s")
