@@ -774,6 +774,10 @@ static const CfgInfo kCfgs[] = {
     // LDS-DMA staging (f16 operands only, conv_igemm_config_valid_mode)
     {256, 256, {"conv_igemm_f32<256,256,dma>", "conv_igemm_f16<256,256,dma>", "conv_igemm_f32s<256,256,dma>"}},
     {256, 128, {"conv_igemm_f32<256,128,dma>", "conv_igemm_f16<256,128,dma>", "conv_igemm_f32s<256,128,dma>"}},
+    // (a RING OF THREE LDS images with a counted vmcnt -- two K steps of DMA in flight across the barrier -- was measured on
+    // 256x128, 128x256 and 128x128 tiles for the HBM-bound 1x1 convs: better than the two-image form of the same tile
+    // (layer3 conv1 at 4K: 0.123 -> 0.100 ms) but never better than 256x256 with two images (0.087) or the register form
+    // (conv3: 0.170 vs 0.202); 256x256 x 3 images does not fit the 160 KB.  The tuner picked none of them: not shipped.)
     // (a two-group PING-PONG schedule on top of the DMA form -- waves 0-3 load while waves 4-7 compute, 4 barriers per K
     // step, raised priority on the MFMA clusters -- was built, is bit-identical, and is NOT faster: 1143 vs 1183 TFLOP/s on
     // the 4K classifier.0.  The matrix pipe is not waiting for a better schedule: MfmaUtil is 57.5 % in cycle terms and the
