@@ -774,6 +774,8 @@ static const CfgInfo kCfgs[] = {
     // LDS-DMA staging (f16 operands only, conv_igemm_config_valid_mode)
     {256, 256, {"conv_igemm_f32<256,256,dma>", "conv_igemm_f16<256,256,dma>", "conv_igemm_f32s<256,256,dma>"}},
     {256, 128, {"conv_igemm_f32<256,128,dma>", "conv_igemm_f16<256,128,dma>", "conv_igemm_f32s<256,128,dma>"}},
+    // short-K 1x1 convs, f16: activation tile in registers, all N tiles walked by one workgroup (conv1x1_areg.hip)
+    {256, 128, {"conv1x1_f32<256,areg>", "conv1x1_f16<256,areg>", "conv1x1_f32s<256,areg>"}},
     // (a RING OF THREE LDS images with a counted vmcnt -- two K steps of DMA in flight across the barrier -- was measured on
     // 256x128, 128x256 and 128x128 tiles for the HBM-bound 1x1 convs: better than the two-image form of the same tile
     // (layer3 conv1 at 4K: 0.123 -> 0.100 ms) but never better than 256x256 with two images (0.087) or the register form
@@ -808,6 +810,7 @@ int conv_igemm_default_config(const ConvArgs& a) {
 bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode) {
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     if (cfg >= 13 && mode != 1) return false;
+    if (cfg == 15) return conv1x1_areg_valid(a, mode, 0);
     const int bn = kCfgs[cfg].bn;
     if (a.Cout <= 32) return bn == 32;
     if (bn == 32) return false;
@@ -841,6 +844,11 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
             if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {  // LDS-DMA staging
                 if (cfg == 13) return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 4>(a, s);
                 return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 4>(a, s);
+            }
+            return hipErrorInvalidValue;
+        case 15:
+            if constexpr (std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value && !SPLIT) {
+                if (conv1x1_areg_valid(a, 1, 0)) return launch_conv1x1_areg(a, s);
             }
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;

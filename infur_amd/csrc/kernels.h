@@ -50,6 +50,11 @@ int conv_igemm_default_config(const ConvArgs& a);
 bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode);
 const char* conv_igemm_config_name(int cfg, int mode);
 
+// 1x1 convolution with Cin in {64, 128, 256}, f16 operands (mode 1), f16 output: the activation tile stays in registers
+// while the workgroup walks all N tiles (conv1x1_areg.hip).  Reached through launch_conv_igemm as one more configuration.
+bool conv1x1_areg_valid(const ConvArgs& a, int mode, int out_f32);
+hipError_t launch_conv1x1_areg(const ConvArgs& a, hipStream_t s);
+
 // Winograd F(mt x mt, 3x3), mt = 2 or 4, for stride-1 3x3 convs (f32, any dilation d with pad = d);
 // (mt+2)^2 transform planes; see winograd.hip
 int wino_num_tiles(int H, int W, int d, int mt);
