@@ -38,7 +38,7 @@ def short(name):
             except (OSError, subprocess.SubprocessError):
                 _DEMANGLED[name] = name
         name = _DEMANGLED[name]
-    n = name.replace("void infur::", "").replace("infur::", "")
+    n = name.replace("(anonymous namespace)::", "").replace("void infur::", "").replace("infur::", "")
     return n.split("(")[0]
 
 
