@@ -239,7 +239,8 @@ hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
 
 bool conv1x1_areg_valid(const ConvArgs& a, int mode, int out_f32) {
     return mode == 1 && !out_f32 && a.KH == 1 && a.KW == 1 && a.pad == 0 && !a.in2 && a.batch <= 1 &&
-           (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.Cout >= 256 && (a.Cout & 3) == 0 &&
+           (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.Cout >= 256 && (a.Cout & (AR_BN - 1)) == 0 &&
+           // (whole N tiles only: every conv3 of a ResNet; the ragged-N guards in the kernel are untested)
            (size_t)a.H * a.W * a.Cin * 2 < 0x80000000ull && (size_t)a.OH * a.OW * a.Cout * 2 < 0x80000000ull && (size_t)a.Cout * a.Cin * 2 < 0x80000000ull;
 }
 
