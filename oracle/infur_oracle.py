@@ -14,7 +14,9 @@ may import this module, and only as the checker -- never the product path
 PARITY STATUS: ColorCode KATs and Scale dims/errors are pinned by the reference's
 tests; the network forward, nearest sampling rule, epaint premultiply and Resize
 coordinate rule are restatements of third-party code and are "parity unpinned"
-(see oracle/infur_oracle.h and DESIGN.md).
+against ONNX Runtime (see oracle/infur_oracle.h and DESIGN.md); the network is
+corroborated against torch's own module graph of the exported model
+(tests/test_onnx_exporter_cpu.py).
 """
 from __future__ import annotations
 

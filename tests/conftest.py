@@ -78,3 +78,14 @@ def model(ctx, blob50):
 def oracle_model(oracle, blob50):
     assert oracle.model_load(blob50) == 0
     return oracle
+
+
+@pytest.fixture(scope="session")
+def exported50():
+    """torchvision-shaped FCN-ResNet50 as torch.nn modules with the synthetic parameters UNFOLDED, and the same module
+    through PyTorch's own ONNX exporter (tests/tv_fcn.py): -> (module, folded reference tensors, ModelProto bytes)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tv_fcn
+
+    m, folded = tv_fcn.synth_fcn(50)
+    return m, folded, tv_fcn.export_onnx(m)

@@ -1,0 +1,175 @@
+"""torchvision's `fcn_resnet50` / `fcn_resnet101` restated as plain torch.nn modules (torchvision is not in the image),
+with torchvision's module names so that the state dict and the EXPORTED graph look like the model the reference loads:
+`fcn-resnet50-12.onnx` of the ONNX model zoo is this module through `torch.onnx.export(opset_version=12)`
+(infur-test-gen/build.rs:88-93 downloads it, infur/src/predict_onnx.rs:288-309 loads it).
+
+Used by tests only: (1) as a CPU reference that is torch's OWN module graph (Conv2d / BatchNorm2d / MaxPool2d /
+F.interpolate), independent of the functional restatements under oracle/; (2) as the source of REAL exporter output for
+the ONNX reader -- `export_onnx` drives PyTorch's TorchScript ONNX exporter (the C++ serialiser writes the ModelProto;
+only a Python post-processing hook of the exporter needs the absent `onnx` package and is bypassed).
+"""
+import io
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from infur_amd import weights as W
+
+
+class Bottleneck(nn.Module):  # torchvision.models.resnet.Bottleneck (v1.5: the stride sits on conv2)
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+class ResNetBackbone(nn.Module):  # torchvision ResNet(replace_stride_with_dilation=[False, True, True]) without avgpool / fc
+    def __init__(self, blocks):
+        super().__init__()
+        self.inplanes, self.dilation = 64, 1
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, blocks[0])
+        self.layer2 = self._make_layer(128, blocks[1], stride=2)
+        self.layer3 = self._make_layer(256, blocks[2], stride=2, dilate=True)
+        self.layer4 = self._make_layer(512, blocks[3], stride=2, dilate=True)
+
+    def _make_layer(self, planes, n, stride=1, dilate=False):
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample, previous_dilation)]
+        self.inplanes = planes * 4
+        for _ in range(1, n):
+            layers.append(Bottleneck(self.inplanes, planes, dilation=self.dilation))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):  # IntermediateLayerGetter({"layer4": "out", "layer3": "aux"})
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer2(self.layer1(x))
+        aux = self.layer3(x)
+        return OrderedDict(out=self.layer4(aux), aux=aux)
+
+
+class FCNHead(nn.Sequential):  # torchvision.models.segmentation.fcn.FCNHead
+    def __init__(self, in_channels, channels):
+        inter = in_channels // 4
+        super().__init__(nn.Conv2d(in_channels, inter, 3, padding=1, bias=False), nn.BatchNorm2d(inter), nn.ReLU(), nn.Dropout(0.1),
+                         nn.Conv2d(inter, channels, 1))
+
+
+class FCN(nn.Module):  # torchvision.models.segmentation._utils._SimpleSegmentationModel
+    def __init__(self, depth=50, num_classes=21, aux=True):
+        super().__init__()
+        self.backbone = ResNetBackbone(W.LAYER_BLOCKS[depth])
+        self.classifier = FCNHead(2048, num_classes)
+        self.aux_classifier = FCNHead(1024, num_classes) if aux else None
+
+    def forward(self, x):
+        input_shape = x.shape[-2:]
+        features = self.backbone(x)
+        result = OrderedDict()
+        result["out"] = F.interpolate(self.classifier(features["out"]), size=input_shape, mode="bilinear", align_corners=False)
+        if self.aux_classifier is not None:
+            result["aux"] = F.interpolate(self.aux_classifier(features["aux"]), size=input_shape, mode="bilinear", align_corners=False)
+        return result
+
+
+def synth_fcn(depth=50, num_classes=21, aux=True, seed=W.DEFAULT_SEED):
+    """-> (module in eval mode with UNFOLDED synthetic parameters, [(spec, W' f32, b' f32)] = the same parameters folded in
+    float64 the way infur_amd.weights.synth_tensors folds them).  Same PRNG streams as synth_tensors, so the folded
+    tensors ARE synth_blob's."""
+    m = FCN(depth, num_classes, aux)
+    sd = m.state_dict()
+    folded = []
+    for idx, c in enumerate(W.graph(depth, num_classes, aux)):
+        fan_in = c.cin * c.k * c.k
+        a = np.sqrt(6.0 / fan_in)
+        w = ((W.uniform01(seed, 4 * idx + 0, c.cout * fan_in).astype(np.float64) * 2.0 - 1.0) * a).reshape(c.cout, c.cin, c.k, c.k)
+        if c.has_bn:
+            u = W.uniform01(seed, 4 * idx + 1, 4 * c.cout).astype(np.float64).reshape(4, c.cout)
+            gamma, beta, mean, var = 0.5 + u[0], (u[1] - 0.5) * 0.2, (u[2] - 0.5) * 0.2, 0.5 + u[3]
+            if c.role == "conv3":
+                gamma = gamma * 0.25
+            # torchvision names: X.convN -> X.bnN; backbone.conv1 -> backbone.bn1; downsample.0 -> downsample.1; head .0 -> .1
+            head, _, leaf = c.name.rpartition(".")
+            bn = f"{head}.bn{leaf[4:]}" if leaf.startswith("conv") else f"{head}.1"
+            sd[c.name + ".weight"].copy_(torch.from_numpy(w.astype(np.float32)))
+            for key, val in (("weight", gamma), ("bias", beta), ("running_mean", mean), ("running_var", var)):
+                sd[f"{bn}.{key}"].copy_(torch.from_numpy(val.astype(np.float32)))
+            # fold what the MODULE holds (f32-rounded parameters), in float64
+            w32, g32, b32, m32, v32 = (x.astype(np.float32).astype(np.float64) for x in (w, gamma, beta, mean, var))
+            s = g32 / np.sqrt(v32 + 1e-5)
+            folded.append((c, (w32 * s[:, None, None, None]).astype(np.float32), (b32 - m32 * s).astype(np.float32)))
+        else:
+            u = W.uniform01(seed, 4 * idx + 1, c.cout).astype(np.float64)
+            b = (u - 0.5) * 0.5 + 0.01 * np.arange(c.cout)
+            w = w * 0.05
+            sd[c.name + ".weight"].copy_(torch.from_numpy(w.astype(np.float32)))
+            sd[c.name + ".bias"].copy_(torch.from_numpy(b.astype(np.float32)))
+            folded.append((c, w.astype(np.float32), b.astype(np.float32)))
+    m.load_state_dict(sd)
+    return m.eval(), folded
+
+
+class _TwoOutputs(nn.Module):  # the exporter flattens the OrderedDict the same way; this only fixes the output order
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x):
+        r = self.m(x)
+        return tuple(r.values())
+
+
+def export_onnx(model, h=64, w=64, opset=12, dynamic=True) -> bytes:
+    """PyTorch's TorchScript ONNX exporter on `model` -> serialized ModelProto (input "input", outputs "out"[, "aux"],
+    dynamic batch / height / width like the zoo file)."""
+    import warnings
+
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+
+    names = ["out", "aux"] if model.aux_classifier is not None else ["out"]
+    axes = {n: {0: "batch", 2: "height", 3: "width"} for n in ["input"] + names} if dynamic else None
+    keep = onnx_proto_utils._add_onnxscript_fn
+    # the hook splices onnxscript functions into the proto through the `onnx` package; there are none in this model
+    onnx_proto_utils._add_onnxscript_fn = lambda proto, custom_opsets: proto
+    try:
+        f = io.BytesIO()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            # (.eval(): the exporter restores the wrapper's mode afterwards -- recursively; a wrapper left in training mode would
+            #  switch `model` to training and its next forward would update the BatchNorm statistics)
+            torch.onnx.export(_TwoOutputs(model).eval(), (torch.zeros(1, 3, h, w),), f, opset_version=opset, dynamo=False, input_names=["input"],
+                              output_names=names, dynamic_axes=axes, do_constant_folding=True)
+        assert not model.training
+        return f.getvalue()
+    finally:
+        onnx_proto_utils._add_onnxscript_fn = keep
