@@ -75,7 +75,7 @@ __device__ __forceinline__ void store_split(char* dst, const u32x4 r, const floa
 // (32 pixel rows of BN / WN f32 channels + 16 bytes) if those need more
 // NBUF == 4 (the LDS-DMA form): rows are the bare 128 bytes -- a DMA piece lands lane-linear, so there is no room for
 // padding; bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index instead (lds_swz)
-constexpr int lds_row_bytes(int nbuf) { return nbuf == 4 ? ROW_BYTES : LDS_ROW; }
+constexpr int lds_row_bytes(int nbuf) { return nbuf >= 4 ? ROW_BYTES : LDS_ROW; }
 __host__ __device__ constexpr int lds_swz(int row) { return (row >> 1) & 7; }
 
 constexpr int lds_bytes(int bm, int bn, int wm, int wn, int nbuf) {
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     // NBUF == 4: operand tiles travel HBM/L2 -> LDS by DMA (dma16), two images, one barrier per K step; rows are the
     // bare 128 bytes with the 16-byte chunk index XOR-swizzled by lds_swz(row) -- applied to the SOURCE address of the
     // DMA (a piece lands lane-linear) and to the fragment reads.  No staging registers, no ds_write pass.
-    constexpr bool GLDS = NBUF == 4;
+    constexpr bool GLDS = NBUF >= 4;  // 4: DMA pieces of the next K step issued up front, 5: between the slices
     static_assert(!GLDS || (!F32 && !SPLIT), "the LDS-DMA form is built for the f16 operands");
     constexpr int LR = lds_row_bytes(NBUF);  // LDS row stride
     char* As = smem;                        // [NIMG][BM][LR]
@@ -526,6 +526,8 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             for (int kk = 0; kk < NSL; kk++) {
                 read_frags(buf, kk, fa, fb);
                 mma_slice();
+                // (staging the activations at slice 0 and the weights at slice 1 instead measured the same: these are
+                //  ordinary loads and stores, the compiler spreads them either way)
                 if (kk == 0 && ks + 1 < ksteps) {
                     store_step(buf ^ 1);
                     if (ks + 2 < ksteps) load_step(ks + 2);
@@ -534,22 +536,35 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-    } else if constexpr (NBUF == 4) {
-        // LDS-DMA form: the DMA of K step ks + 1 into the other image is issued first and lands while this step's
-        // 32 MFMAs per wave run; every wave waits for its own pieces (vmcnt) and its fragment reads (lgkmcnt) before
-        // the barrier that ends the step -- after it the other image is complete and this one may be overwritten.
+    } else if constexpr (NBUF >= 4) {
+        // LDS-DMA form: the DMA of K step ks + 1 goes into the other image and lands while this step's 32 MFMAs per
+        // wave run; every wave waits for its own pieces (vmcnt) and its fragment reads (lgkmcnt) before the barrier that
+        // ends the step -- after it the other image is complete and this one may be overwritten.
+        // WHERE the pieces are issued is the NBUF 4 / 5 difference:
+        //   4: all of them before slice 0.  Most bytes in flight for the longest time: best for the HBM-bound 1x1 convs.
+        //   5: the activation pieces after the fragment reads of slice 0, the weight pieces after those of slice 1.  An
+        //      LDS-DMA instruction costs its wave 60-180 issue cycles (MI355X_MICROARCH.md); issued up front, the eight
+        //      of them keep the wave -- and, the waves of a workgroup running in step, the whole SIMD -- off the matrix
+        //      pipe at the top of every K step.  Behind a slice's ds_reads they issue in the shadow of MFMAs that already
+        //      have their operands.  4K FCN-ResNet101: classifier.0 1241 -> 1338 TFLOP/s, layer4 conv2 1244 -> 1321,
+        //      layer3 conv2 1053-1092 -> 1150; the HBM-bound conv1 (1024 -> 256) gets SLOWER (0.084-0.089 -> 0.092 ms),
+        //      so both forms are configurations and the tuner picks per shape.  (Other placements measured: one slice
+        //      later, or after each slice's MFMAs instead of before: +2-4 % only; the weight pieces after slice 0's MFMAs,
+        //      or s_setprio(1) around the MFMAs of a slice: 4 % slower than this form.)
         // (Reading the next slice's fragments ahead of this slice's MFMAs -- the register path's prefetch -- was
         // measured here and is slower: 1187 vs 1225 TFLOP/s on the 4K classifier.0; the second wave on the SIMD already
         // covers the ds_read latency and the extra register set costs more than it hides.)
+        constexpr bool SPREAD = NBUF == 5;
         for (int ks = 0; ks < ksteps; ks++) {
             const int buf = ks & 1;
-            if (ks + 1 < ksteps) {
-                ld_buf = buf ^ 1;
-                load_step(ks + 1);
-            }
+            const bool more = ks + 1 < ksteps;
+            ld_buf = buf ^ 1;
+            if (!SPREAD && more) load_step(ks + 1);
 #pragma unroll
             for (int kk = 0; kk < NSL; kk++) {
                 read_frags(buf, kk, fa, fb);
+                if (SPREAD && more && kk == 0) load_a();
+                if (SPREAD && more && kk == 1) load_b(ks + 1);
                 mma_slice();
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -776,15 +791,18 @@ static const CfgInfo kCfgs[] = {
     {256, 128, {"conv_igemm_f32<256,128,dma>", "conv_igemm_f16<256,128,dma>", "conv_igemm_f32s<256,128,dma>"}},
     // short-K 1x1 convs, f16: activation tile in registers, all N tiles walked by one workgroup (conv1x1_areg.hip)
     {256, 128, {"conv1x1_f32<256,areg>", "conv1x1_f16<256,areg>", "conv1x1_f32s<256,areg>"}},
+    // LDS-DMA staging with the DMA instructions issued between the slices (NBUF == 5: the MFMA-bound layers)
+    {256, 256, {"conv_igemm_f32<256,256,dmai>", "conv_igemm_f16<256,256,dmai>", "conv_igemm_f32s<256,256,dmai>"}},
+    {256, 128, {"conv_igemm_f32<256,128,dmai>", "conv_igemm_f16<256,128,dmai>", "conv_igemm_f32s<256,128,dmai>"}},
     // (a RING OF THREE LDS images with a counted vmcnt -- two K steps of DMA in flight across the barrier -- was measured on
     // 256x128, 128x256 and 128x128 tiles for the HBM-bound 1x1 convs: better than the two-image form of the same tile
     // (layer3 conv1 at 4K: 0.123 -> 0.100 ms) but never better than 256x256 with two images (0.087) or the register form
     // (conv3: 0.170 vs 0.202); 256x256 x 3 images does not fit the 160 KB.  The tuner picked none of them: not shipped.)
     // (a two-group PING-PONG schedule on top of the DMA form -- waves 0-3 load while waves 4-7 compute, 4 barriers per K
     // step, raised priority on the MFMA clusters -- was built, is bit-identical, and is NOT faster: 1143 vs 1183 TFLOP/s on
-    // the 4K classifier.0.  The matrix pipe is not waiting for a better schedule: MfmaUtil is 57.5 % in cycle terms and the
-    // rest of the gap is the package clock, 1.99 GHz on real data against 2.38 GHz on all-zero operands for the SAME
-    // binary -- scripts/zero_data_probe.py, profiles/r02_dvfs_probe.md.)
+    // the 4K classifier.0.  What did help is WHERE the DMA instructions are issued inside the step: the `dmai` form above,
+    // +6-8 % on the MFMA-bound layers.  Beyond that the gap to the peak is mostly the package clock: 1.99 GHz on real data
+    // against 2.38 GHz on all-zero operands for the SAME binary -- scripts/zero_data_probe.py, profiles/r02_dvfs_probe.md.)
     // (128x128 and 128x256 DMA tiles were measured too: slower than the register-staged forms on every layer of the 4K
     // FCN-ResNet101, including the HBM-bound 1x1 convs they were meant for -- 0.199 / 0.208 ms vs 0.170 on layer3 conv3)
 };
@@ -844,6 +862,13 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
             if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {  // LDS-DMA staging
                 if (cfg == 13) return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 4>(a, s);
                 return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 4>(a, s);
+            }
+            return hipErrorInvalidValue;
+        case 16:
+        case 17:
+            if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {
+                if (cfg == 16) return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 5>(a, s);
+                return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 5>(a, s);
             }
             return hipErrorInvalidValue;
         case 15:
