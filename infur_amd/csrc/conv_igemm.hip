@@ -550,7 +550,8 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         //      layer3 conv2 1053-1092 -> 1150; the HBM-bound conv1 (1024 -> 256) gets SLOWER (0.084-0.089 -> 0.092 ms),
         //      so both forms are configurations and the tuner picks per shape.  (Other placements measured: one slice
         //      later, or after each slice's MFMAs instead of before: +2-4 % only; the weight pieces after slice 0's MFMAs,
-        //      or s_setprio(1) around the MFMAs of a slice: 4 % slower than this form.)
+        //      or s_setprio(1) around the MFMAs of a slice: 4 % slower than this form; 3 + 3 + 2 or 2 + 4 + 2 pieces over
+        //      slices 0-2: the same within noise; all eight after the reads of slice 0: as slow as up front.)
         // (Reading the next slice's fragments ahead of this slice's MFMAs -- the register path's prefetch -- was
         // measured here and is slower: 1187 vs 1225 TFLOP/s on the 4K classifier.0; the second wave on the SIMD already
         // covers the ds_read latency and the extra register set costs more than it hides.)
