@@ -227,7 +227,7 @@ const char* infur_group_last_error(const infur_group* g) { return g ? g->err.c_s
 uint32_t infur_group_size(const infur_group* g) { return g ? (uint32_t)g->ctxs.size() : 0; }
 uint32_t infur_group_uses_rccl(const infur_group* g) { return g && !g->comms.empty() ? 1u : 0u; }
 
-int32_t infur_group_weights_broadcast(infur_group* g, uint32_t root) {
+static int32_t group_weights_broadcast_impl(infur_group* g, uint32_t root) {
     if (!g || root >= g->ctxs.size()) return INFUR_E_INVALID_ARG;
     infur_ctx* rc = g->ctxs[root];
     if (!rc->loaded || !rc->d_weights) return gfail(g, INFUR_E_MODEL_NOT_LOADED, "root context %u has no model to broadcast", root);
@@ -321,9 +321,9 @@ int32_t infur_group_weights_broadcast(infur_group* g, uint32_t root) {
     return INFUR_OK;
 }
 
-int32_t infur_group_batch_advance(infur_group* g, const uint8_t* const* frames, const uint32_t* ws, const uint32_t* hs,
-                                  uint32_t n, float factor, uint32_t mode, uint8_t* const* rgba, const size_t* caps,
-                                  uint32_t* ows, uint32_t* ohs) {
+static int32_t group_batch_advance_impl(infur_group* g, const uint8_t* const* frames, const uint32_t* ws, const uint32_t* hs,
+                                       uint32_t n, float factor, uint32_t mode, uint8_t* const* rgba, const size_t* caps,
+                                       uint32_t* ows, uint32_t* ohs) {
     if (!g || (n && (!frames || !ws || !hs || !rgba || !caps))) return INFUR_E_INVALID_ARG;
     if (n == 0) return INFUR_OK;
     const uint32_t world = (uint32_t)g->ctxs.size();
@@ -351,6 +351,28 @@ int32_t infur_group_batch_advance(infur_group* g, const uint8_t* const* frames, 
         }
     }
     return status;
+}
+
+// nothing may unwind through the C boundary (std::vector / std::function allocate)
+int32_t infur_group_weights_broadcast(infur_group* g, uint32_t root) {
+    try {
+        return group_weights_broadcast_impl(g, root);
+    } catch (...) {
+        return gfail(g, INFUR_E_INVALID_ARG, "infur_group_weights_broadcast: out of host memory");
+    }
+}
+
+int32_t infur_group_batch_advance(infur_group* g, const uint8_t* const* frames, const uint32_t* ws, const uint32_t* hs,
+                                  uint32_t n, float factor, uint32_t mode, uint8_t* const* rgba, const size_t* caps,
+                                  uint32_t* ows, uint32_t* ohs) {
+    try {
+        return group_batch_advance_impl(g, frames, ws, hs, n, factor, mode, rgba, caps, ows, ohs);
+    } catch (...) {
+        // a slice may already be running on a worker: wait for all of them before the caller's buffers go away
+        if (g)
+            for (Worker* w : g->workers) (void)w->wait();
+        return gfail(g, INFUR_E_INVALID_ARG, "infur_group_batch_advance: out of host memory");
+    }
 }
 
 int32_t infur_weights_broadcast(infur_ctx* const* ctxs, uint32_t n_ctx) {
