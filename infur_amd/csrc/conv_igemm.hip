@@ -648,6 +648,22 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             const int mb = m0 + wm * TM * 32 + i * 32;
+            // Tiles too big for RESPF (256x256: 128 accumulators per lane): all residual loads of this 32-row block are
+            // issued here, before the first of them is needed -- inside the loop below each one would wait out its full
+            // latency behind the branch, with one workgroup per CU and nothing else to run (what made the first version
+            // of conv1x1_areg.hip twice as slow).  The accumulators of block i are already in LDS: their registers are free.
+            ResV rlate[RESPF ? 1 : 32 / RPI];
+            if constexpr (!RESPF) {
+                if (res) {
+#pragma unroll
+                    for (int it = 0; it < 32 / RPI; it++) {
+                        const int m = mb + it * RPI + rrow;
+                        ResV r = {};
+                        if (m < M && n_ok) r = *reinterpret_cast<const ResV*>(res + (size_t)m * a.Cout + n);
+                        rlate[it] = r;
+                    }
+                }
+            }
 #pragma unroll
             for (int it = 0; it < 32 / RPI; it++) {
                 const int row = it * RPI + rrow;
@@ -661,7 +677,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                         if constexpr (RESPF)
                             rv = rres[i][it];
                         else
-                            rv = *reinterpret_cast<const ResV*>(res + o);
+                            rv = rlate[it];
                         if constexpr (std::is_same<T, float>::value) {
                             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                         } else {
