@@ -182,6 +182,8 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
         if (has_bias && n_ok) bv = *reinterpret_cast<const float4*>(a.bias + n);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
+            // (Fetching the first block's residual before the K loop of the N tile, so that it lands behind the MFMAs, was
+            //  measured too: no change -- 0.134-0.136 ms on layer3 conv3 at 4K either way; the kernel is at 0.9 of copy speed.)
             // All eight residual loads of this 32-row block are in flight before the accumulators are staged: with one
             // workgroup per CU nothing else hides their latency (two at a time made the whole kernel latency-bound,
             // 1.8 TB/s of stores).
