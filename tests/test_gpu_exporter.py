@@ -37,7 +37,8 @@ def module_logits(m, oracle, frame):
     return r["out"][0].numpy(), r["aux"][0].numpy()
 
 
-@pytest.mark.parametrize("dtype,wh", [("f32", (320, 240)), ("f32", (161, 97)), ("f32", (640, 480)), ("f32s", (320, 240)), ("f16", (320, 240))])
+@pytest.mark.parametrize("dtype,wh", [("f32", (320, 240)), ("f32", (161, 97)), ("f32", (640, 480)), ("f32s", (320, 240)), ("f16", (320, 240)),
+                                      ("f32", (1920, 1080)), ("f32s", (1920, 1080))])  # the last two: BASELINE configs[1] at full size
 def test_exported_file_through_hip_matches_torch_modules(exported50, onnx_path, oracle, dtype, wh):
     m = exported50[0]
     w, h = wh
