@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Race screen for the kernels whose LDS traffic is ordered by hand (LDS-DMA with counted vmcnt + raw barriers:
+conv_igemm `dma` / `dmai`, conv1x1_areg): the same frame N times on K contexts AT THE SAME TIME (so that timing varies),
+every run's stride-8 logits hashed -- one distinct hash per (dtype, size) or the schedule has a race.
+    python scripts/race_screen.py [runs]        (run on an MI355X)"""
+import hashlib
+import os
+import sys
+import threading
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from infur_amd import processors as P
+from infur_amd import weights as W
+
+RUNS = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+JOBS = [("f16", 101, 3840, 2160), ("f16", 50, 1920, 1080), ("f16", 50, 961, 541), ("f32s", 50, 1920, 1080), ("f32", 50, 1920, 1080)]
+bad = 0
+for dtype, depth, w, h in JOBS:
+    blob = W.synth_blob(depth=depth)
+    fr = W.synth_frame(h, w, index=7)
+    K = 3
+    hashes = [[] for _ in range(K)]
+
+    def work(k):
+        c = P.Context(device=0, dtype=dtype)
+        m = P.Model(c).control(P.ModelCmd.LoadBlob(blob))
+        fp = P.FramePath(c)
+        n = max(6, RUNS // (4 if w > 2000 else 1))
+        for _ in range(n):
+            rgba, _ = fp.advance(fr, 1.0)
+            lo, la = m.lowres()
+            hashes[k].append(hashlib.sha1(lo.tobytes() + la.tobytes() + np.ascontiguousarray(rgba).tobytes()).hexdigest())
+        c.close()
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(K)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    allh = [x for hs in hashes for x in hs]
+    distinct = len(set(allh))
+    bad += distinct != 1
+    print(f"{dtype} R{depth} {w}x{h}: {len(allh)} runs on {K} concurrent contexts, {distinct} distinct result(s)")
+print("RACE SCREEN", "CLEAN" if not bad else "FAILED")
+sys.exit(1 if bad else 0)
