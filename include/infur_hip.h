@@ -63,10 +63,14 @@ enum {
     INFUR_DTYPE_F32 = 0, /* exact f32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode */
     INFUR_DTYPE_F16 = 1, /* f16 activations/weights on v_mfma_f32_32x32x16_f16, f32 accumulation,
                             bias/residual/ReLU in f32, logits f32 (BASELINE configs[4]) */
-    INFUR_DTYPE_F32_SPLIT = 2 /* f32 tensors everywhere; inside the conv GEMMs every operand value is
+    INFUR_DTYPE_F32_SPLIT = 2, /* f32 tensors everywhere; inside the conv GEMMs every operand value is
                             split into an f16 pair hi + lo (22 significand bits) and the product is
                             accumulated in f32 from three f16 MFMAs (lo*hi + hi*lo + hi*hi).  f32-grade
                             logits (tests: <= 2e-5 of the f32 oracle) at a multiple of the f32 MFMA rate */
+    INFUR_DTYPE_F32_SPLIT_FP8 = 3 /* as INFUR_DTYPE_F32_SPLIT, but only hi*hi runs on the f16 MFMA; the two cross terms
+                            hi*lo + lo*hi run on the fp8 (OCP e4m3) MX MFMA at twice the f16 rate: 2 MFMA units per
+                            product instead of 3.  Products are exact to ~2^-14: logits within 1e-4 of the f32 oracle
+                            (tests), i.e. inside north_star's 1e-3 with a 10x margin, 25x closer than INFUR_DTYPE_F16 */
 };
 
 typedef struct infur_ctx infur_ctx;

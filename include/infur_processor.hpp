@@ -50,7 +50,7 @@ struct Tensor3 {
 /// RAII owner of an infur_ctx (one GPU, one stream; not thread-safe)
 class Context {
 public:
-    /// compute_dtype: INFUR_DTYPE_F32 (exact f32 MFMA), INFUR_DTYPE_F32_SPLIT (f32 tensors, f16 matrix cores with
+    /// compute_dtype: INFUR_DTYPE_F32 (exact f32 MFMA), INFUR_DTYPE_F32_SPLIT_FP8 (see infur_hip.h), INFUR_DTYPE_F32_SPLIT (f32 tensors, f16 matrix cores with
     /// hi+lo operand pairs: f32-grade logits at ~1.9x the rate) or INFUR_DTYPE_F16
     explicit Context(int device = 0, bool compute_aux = true, uint32_t compute_dtype = INFUR_DTYPE_F32) {
         infur_options o;

@@ -31,6 +31,7 @@ SCALE_NEAREST, SCALE_BILINEAR = 0, 1
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 DTYPE_F32_SPLIT = 2
+DTYPE_F32_SPLIT_FP8 = 3  # split mode with the cross terms on the fp8 MX MFMA ("f32x")
 
 
 class Options(C.Structure):

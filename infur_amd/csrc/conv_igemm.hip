@@ -24,6 +24,8 @@
 // Every tile configuration accumulates k in the same order: they are bit-identical, the choice is a speed knob
 // (pick_cfg in infur_capi.cpp measures it per layer shape).
 #include <atomic>
+#include <mutex>
+#include <string>
 #include <cstdlib>
 #include <type_traits>
 
@@ -69,6 +71,29 @@ __device__ __forceinline__ void store_split(char* dst, const u32x4 r, const floa
     const f16x4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), f16x4);
     *reinterpret_cast<f16x4*>(dst) = hi;
     *reinterpret_cast<f16x4*>(dst + 64) = lo;
+}
+
+// FP8X (f16 + fp8 cross terms): four f32 * scale -> 4 x f16 hi at dst, 4 x e4m3 of hi at row + 64 + 4 * chunk,
+// 4 x e4m3 of (x - hi) * 2^11 at row + 96 + 4 * chunk.  The conversion does not saturate (beyond +-448 it gives NaN): clamp.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int pack_fp8x4(const f32x4 v) {
+    const float lim = 448.0f;
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[0], -lim, lim), __builtin_amdgcn_fmed3f(v[1], -lim, lim), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[2], -lim, lim), __builtin_amdgcn_fmed3f(v[3], -lim, lim), w, true);
+    return w;
+}
+// activations: hi as it is (hi = x * a_scale: the e4m3 range +-448 covers |x| <= 112 at a_scale = 4; beyond it the fp8 copy is
+// CLAMPED, which only costs that element the weight-lo correction, 2^-11 of its product), lo * 2^11 (same range as hi)
+constexpr float kFp8HiScale = 1.0f, kFp8LoScale = 2048.0f;
+constexpr int kFp8CrossScaleA = 127 - 5;  // E8M0: both halves of the fp8 dot product carry 2^0 * 2^5 = 2^11 * 2^-6
+__device__ __forceinline__ void store_split_fp8(char* row, const int chunk, const u32x4 r, const float scale) {
+    const f32x4 x = __builtin_bit_cast(f32x4, r) * scale;
+    const f16x4 hi = __builtin_convertvector(x, f16x4);
+    const f32x4 hf = __builtin_convertvector(hi, f32x4);
+    *reinterpret_cast<f16x4*>(row + chunk * 8) = hi;
+    *reinterpret_cast<int*>(row + 64 + chunk * 4) = pack_fp8x4(hf * kFp8HiScale);
+    *reinterpret_cast<int*>(row + 96 + chunk * 4) = pack_fp8x4((x - hf) * kFp8LoScale);
 }
 
 // dynamic LDS of a workgroup: the operand images, or the epilogue's per-wave staging slices
@@ -141,7 +166,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // with stride2) against one weight matrix whose rows are the two 1x1 kernels side by side: conv3 and the
 // downsample branch of a bottleneck's first block in one launch, without writing and re-reading the branch.
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF, bool SPLIT = false, bool G1 = false, bool RESPF = false,
-          bool DUAL = false>
+          bool DUAL = false, bool FP8X = false>
 __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN, NBUF))
     conv_igemm_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
     constexpr bool F32 = std::is_same<T, float>::value && !SPLIT;
@@ -149,7 +174,9 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     constexpr int ES = sizeof(T);              // operand element size
     constexpr int BK = ROW_BYTES / ES;         // channels per K step
     constexpr int NSL = SPLIT ? 2 : 4;         // slices per K step (32 bytes of k each; SPLIT: 16 k as hi + lo)
-    constexpr int NF = SPLIT ? 2 : 1;          // fragment planes per row block (SPLIT: hi, lo)
+    // FP8X (with SPLIT): the cross terms ah*bl + al*bh run on the fp8 MX MFMA (one 32x32x64 per K step)
+    static_assert(!FP8X || SPLIT, "FP8X is a form of the split mode");
+    constexpr int NF = (SPLIT && !FP8X) ? 2 : 1;  // f16 fragment planes per row block (SPLIT: hi, lo)
     constexpr int NT = WM * WN * 64;           // threads
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -344,7 +371,9 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
 #pragma unroll
         for (int i = 0; i < A_IT; i++) {
             const int row = (tid >> 3) + i * (NT / 8);
-            if constexpr (SPLIT)
+            if constexpr (FP8X)
+                store_split_fp8(Ab + row * LR, c4, ra[i], a.a_scale);
+            else if constexpr (SPLIT)
                 store_split(Ab + row * LR + c4 * 8, ra[i], a.a_scale);
             else
                 *reinterpret_cast<u32x4*>(Ab + row * LR + c4 * 16) = ra[i];
@@ -384,14 +413,44 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     };
 
     float4 fa[TM * NF], fb[TN * NF], fa_n[TM * NF], fb_n[TN * NF];
+    // FP8X: the e4m3 planes of the K step -- lane (row r, half h) takes the 32 bytes [64 + 32 h, 96 + 32 h) of its row:
+    // h = 0 the hi plane (weights: lo * 2^5), h = 1 the lo * 2^11 plane (weights: hi * 2^-6), so that the 64-deep fp8
+    // dot product is sum_k ah bl + al bh, scaled by 2^5 in both halves (undone by the instruction's 2^-5 block scale)
+    float4 fa8[FP8X ? TM : 1][2], fb8[FP8X ? TN : 1][2];
+    const int a_lds8 = (wm * TM * 32 + (lane & 31)) * LR + 64 + (lane >> 5) * 32;
+    const int b_lds8 = (wn * TN * 32 + (lane & 31)) * LR + 64 + (lane >> 5) * 32;
+    auto read_frags8 = [&](int buf) {
+        if constexpr (FP8X) {
+            const char* Ab = As + buf * BM * LR + a_lds8;
+            const char* Bb = Bs + buf * BN * LR + b_lds8;
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                fa8[i][0] = *reinterpret_cast<const float4*>(Ab + i * 32 * LR);
+                fa8[i][1] = *reinterpret_cast<const float4*>(Ab + i * 32 * LR + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                fb8[j][0] = *reinterpret_cast<const float4*>(Bb + j * 32 * LR);
+                fb8[j][1] = *reinterpret_cast<const float4*>(Bb + j * 32 * LR + 16);
+            }
+        }
+    };
 
     // the MFMAs of one slice.  D rows = output channels, D cols = pixels (operands swapped on purpose)
-    auto mma_slice = [&]() {
+    auto mma_slice = [&](const int kk) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++) {
-                if constexpr (F32) {
+                if constexpr (FP8X) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
+                    if (kk == 0) {
+                        struct F2 { float4 lo, hi; };
+                        const i32x8 a8 = __builtin_bit_cast(i32x8, (F2{fa8[i][0], fa8[i][1]}));
+                        const i32x8 b8 = __builtin_bit_cast(i32x8, (F2{fb8[j][0], fb8[j][1]}));
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc[i][j], 0, 0, 0, kFp8CrossScaleA, 0, 127);
+                    }
+                } else if constexpr (F32) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].z, fa[i].z, acc[i][j], 0, 0, 0);
@@ -428,7 +487,8 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                 read_frags(buf, kk + 1, fa_n, fb_n);
             else if (NEXT)
                 read_frags(buf ^ 1, 0, fa_n, fb_n);
-            mma_slice();
+            if (kk == 0) read_frags8(buf);
+            mma_slice(kk);
             // staging spread over two slices: activations at slice 0, weights at slice 1
             if (kk == 0 && STORE) {
                 store_a(buf ^ 1);
@@ -525,7 +585,8 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
 #pragma unroll
             for (int kk = 0; kk < NSL; kk++) {
                 read_frags(buf, kk, fa, fb);
-                mma_slice();
+                if (kk == 0) read_frags8(buf);
+                mma_slice(kk);
                 // (staging the activations at slice 0 and the weights at slice 1 instead measured the same: these are
                 //  ordinary loads and stores, the compiler spreads them either way)
                 if (kk == 0 && ks + 1 < ksteps) {
@@ -566,7 +627,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                 read_frags(buf, kk, fa, fb);
                 if (SPREAD && more && kk == 0) load_a();
                 if (SPREAD && more && kk == 1) load_b(ks + 1);
-                mma_slice();
+                mma_slice(kk);
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -585,7 +646,8 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
 #pragma unroll
             for (int kk = 0; kk < NSL; kk++) {
                 if (kk < NSL - 1) read_frags(0, kk + 1, fa_n, fb_n);
-                mma_slice();
+                if (kk == 0) read_frags8(0);
+                mma_slice(kk);
 #pragma unroll
                 for (int i = 0; i < TM * NF; i++) fa[i] = fa_n[i];
 #pragma unroll
@@ -736,13 +798,13 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     }
 }
 
-template <typename T, typename OutT, bool SPLIT, bool G1, bool RESPF, bool DUAL, int BM, int BN, int WM, int WN, int NBUF>
+template <typename T, typename OutT, bool SPLIT, bool FP8X, bool G1, bool RESPF, bool DUAL, int BM, int BN, int WM, int WN, int NBUF>
 static hipError_t launch_cfg_g(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM;
     const int ntiles = (a.Cout + BN - 1) / BN;
     const size_t lds = (size_t)lds_bytes(BM, BN, WM, WN, NBUF);
-    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT, G1, RESPF, DUAL>;
+    auto k = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NBUF, SPLIT, G1, RESPF, DUAL, FP8X>;
     // > 64 KB of dynamic LDS needs the attribute once per kernel AND per device (a process may hold contexts on
     // several GPUs, each driven from its own thread -- infur_group): the flags are atomics, and two threads that both
     // find a flag clear simply both make the (idempotent) call
@@ -759,27 +821,27 @@ static hipError_t launch_cfg_g(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <typename T, typename OutT, bool SPLIT, int BM, int BN, int WM, int WN, int NBUF = 2>
+template <typename T, typename OutT, bool SPLIT, bool FP8X, int BM, int BN, int WM, int WN, int NBUF = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     const bool g1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
     constexpr bool kSameType = std::is_same<T, OutT>::value;  // the f16 -> f32 kernel only ever runs the classifier
     if constexpr (kSameType) {
         if (a.in2) {
             if (!g1 || a.stride != 1 || a.res) return hipErrorInvalidValue;
-            return launch_cfg_g<T, OutT, SPLIT, true, false, true, BM, BN, WM, WN, NBUF>(a, s);
+            return launch_cfg_g<T, OutT, SPLIT, FP8X, true, false, true, BM, BN, WM, WN, NBUF>(a, s);
         }
         // residual prefetch: only where a lane holds <= 64 accumulators (room for 64 more registers) -- a
         // residual only ever enters a 1x1 conv, so this is a G1 form
         constexpr bool kCanPf = (BM / WM) * (BN / WN) <= 64 * 64;
         if constexpr (kCanPf) {
-            if (a.res && g1 && (a.Cout & 3) == 0) return launch_cfg_g<T, OutT, SPLIT, true, true, false, BM, BN, WM, WN, NBUF>(a, s);
+            if (a.res && g1 && (a.Cout & 3) == 0) return launch_cfg_g<T, OutT, SPLIT, FP8X, true, true, false, BM, BN, WM, WN, NBUF>(a, s);
         }
     } else if (a.in2) {
         return hipErrorInvalidValue;
     }
     // 1x1 without padding: the plain-GEMM addressing form (no vector address arithmetic in the K loop)
-    if (g1) return launch_cfg_g<T, OutT, SPLIT, true, false, false, BM, BN, WM, WN, NBUF>(a, s);
-    return launch_cfg_g<T, OutT, SPLIT, false, false, false, BM, BN, WM, WN, NBUF>(a, s);
+    if (g1) return launch_cfg_g<T, OutT, SPLIT, FP8X, true, false, false, BM, BN, WM, WN, NBUF>(a, s);
+    return launch_cfg_g<T, OutT, SPLIT, FP8X, false, false, false, BM, BN, WM, WN, NBUF>(a, s);
 }
 
 // ---- tile configurations ----
@@ -832,7 +894,19 @@ int conv_igemm_num_configs() { return kNumCfgs; }
 int conv_igemm_config_tile_area(int cfg) { return cfg < 0 || cfg >= kNumCfgs ? 0 : kCfgs[cfg].bm * kCfgs[cfg].bn; }
 
 const char* conv_igemm_config_name(int cfg, int mode) {
-    if (cfg < 0 || cfg >= kNumCfgs || mode < 0 || mode > 2) return "conv_igemm<?>";
+    if (cfg < 0 || cfg >= kNumCfgs || mode < 0 || mode > 3) return "conv_igemm<?>";
+    if (mode == 3) {  // "conv_igemm_f32s<...>" -> "conv_igemm_f32x<...>"
+        static std::string names[64];
+        static std::once_flag once;
+        std::call_once(once, [] {
+            for (int k = 0; k < kNumCfgs && k < 64; k++) {
+                names[k] = kCfgs[k].name[2];
+                const size_t p = names[k].find("f32s");
+                if (p != std::string::npos) names[k][p + 3] = 'x';
+            }
+        });
+        return names[cfg].c_str();
+    }
     return kCfgs[cfg].name[mode];
 }
 
@@ -846,6 +920,7 @@ int conv_igemm_default_config(const ConvArgs& a) {
 // a configuration is a candidate when its N tile is not mostly padding (and, for the LDS-DMA forms, in the f16 mode)
 bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode) {
     if (cfg < 0 || cfg >= kNumCfgs) return false;
+    if (mode == 3) mode = 2;  // the fp8 cross-term form stages like the split mode
     if (cfg >= 13 && mode != 1) return false;
     if (cfg == 15) return conv1x1_areg_valid(a, mode, 0);
     const int bn = kCfgs[cfg].bn;
@@ -854,7 +929,7 @@ bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode) {
     return bn <= a.Cout || bn == 64;  // Cout = 64 -> BN 64 only; Cout >= 128 -> 64 and 128 (and 256 when Cout >= 256)
 }
 
-template <typename T, typename OutT, bool SPLIT = false>
+template <typename T, typename OutT, bool SPLIT = false, bool FP8X = false>
 static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
     constexpr size_t ES = sizeof(T);
     if (a.Cin % (int)(ROW_BYTES / ES) != 0 || (a.in2 && a.Cin2 % (int)(ROW_BYTES / ES) != 0)) return hipErrorInvalidValue;
@@ -863,31 +938,31 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         return hipErrorInvalidValue;
     if (cfg < 0) cfg = conv_igemm_default_config(a);
     switch (cfg) {
-        case 0: return launch_cfg<T, OutT, SPLIT, 128, 128, 2, 2>(a, s);
-        case 1: return launch_cfg<T, OutT, SPLIT, 64, 128, 2, 2>(a, s);
-        case 2: return launch_cfg<T, OutT, SPLIT, 128, 64, 2, 2>(a, s);
-        case 3: return launch_cfg<T, OutT, SPLIT, 64, 64, 2, 2>(a, s);
-        case 4: return launch_cfg<T, OutT, SPLIT, 256, 32, 4, 1>(a, s);
-        case 5: return launch_cfg<T, OutT, SPLIT, 128, 256, 2, 4>(a, s);
-        case 6: return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2>(a, s);
-        case 7: return launch_cfg<T, OutT, SPLIT, 128, 128, 2, 2, 1>(a, s);
-        case 8: return launch_cfg<T, OutT, SPLIT, 128, 64, 2, 2, 1>(a, s);
-        case 9: return launch_cfg<T, OutT, SPLIT, 64, 128, 2, 2, 1>(a, s);
-        case 10: return launch_cfg<T, OutT, SPLIT, 64, 64, 2, 2, 1>(a, s);
-        case 11: return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 3>(a, s);  // 8 waves of 128x64, one fragment set
-        case 12: return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 3>(a, s);  // 8 waves of 64x64, one fragment set
+        case 0: return launch_cfg<T, OutT, SPLIT, FP8X, 128, 128, 2, 2>(a, s);
+        case 1: return launch_cfg<T, OutT, SPLIT, FP8X, 64, 128, 2, 2>(a, s);
+        case 2: return launch_cfg<T, OutT, SPLIT, FP8X, 128, 64, 2, 2>(a, s);
+        case 3: return launch_cfg<T, OutT, SPLIT, FP8X, 64, 64, 2, 2>(a, s);
+        case 4: return launch_cfg<T, OutT, SPLIT, FP8X, 256, 32, 4, 1>(a, s);
+        case 5: return launch_cfg<T, OutT, SPLIT, FP8X, 128, 256, 2, 4>(a, s);
+        case 6: return launch_cfg<T, OutT, SPLIT, FP8X, 256, 128, 4, 2>(a, s);
+        case 7: return launch_cfg<T, OutT, SPLIT, FP8X, 128, 128, 2, 2, 1>(a, s);
+        case 8: return launch_cfg<T, OutT, SPLIT, FP8X, 128, 64, 2, 2, 1>(a, s);
+        case 9: return launch_cfg<T, OutT, SPLIT, FP8X, 64, 128, 2, 2, 1>(a, s);
+        case 10: return launch_cfg<T, OutT, SPLIT, FP8X, 64, 64, 2, 2, 1>(a, s);
+        case 11: return launch_cfg<T, OutT, SPLIT, FP8X, 256, 256, 2, 4, 3>(a, s);  // 8 waves of 128x64, one fragment set
+        case 12: return launch_cfg<T, OutT, SPLIT, FP8X, 256, 128, 4, 2, 3>(a, s);  // 8 waves of 64x64, one fragment set
         case 13:
         case 14:
             if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {  // LDS-DMA staging
-                if (cfg == 13) return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 4>(a, s);
-                return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 4>(a, s);
+                if (cfg == 13) return launch_cfg<T, OutT, SPLIT, FP8X, 256, 256, 2, 4, 4>(a, s);
+                return launch_cfg<T, OutT, SPLIT, FP8X, 256, 128, 4, 2, 4>(a, s);
             }
             return hipErrorInvalidValue;
         case 16:
         case 17:
             if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {
-                if (cfg == 16) return launch_cfg<T, OutT, SPLIT, 256, 256, 2, 4, 5>(a, s);
-                return launch_cfg<T, OutT, SPLIT, 256, 128, 4, 2, 5>(a, s);
+                if (cfg == 16) return launch_cfg<T, OutT, SPLIT, FP8X, 256, 256, 2, 4, 5>(a, s);
+                return launch_cfg<T, OutT, SPLIT, FP8X, 256, 128, 4, 2, 5>(a, s);
             }
             return hipErrorInvalidValue;
         case 15:
@@ -902,6 +977,7 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
 hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, hipStream_t s) {
     if (mode == 0) return launch_t<float, float>(a, cfg, s);
     if (mode == 2) return launch_t<float, float, true>(a, cfg, s);
+    if (mode == 3) return launch_t<float, float, true, true>(a, cfg, s);  // f32 tensors, f16 MFMA + fp8 MX MFMA for the cross terms
     return out_f32 ? launch_t<_Float16, float>(a, cfg, s) : launch_t<_Float16, _Float16>(a, cfg, s);
 }
 

@@ -140,7 +140,11 @@ int32_t talloc(infur_ctx* c, int h, int w, int ch, int es, Tensor* t) {
 
 inline bool ctx_f16(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F16; }
 // GEMM arithmetic of launch_conv_igemm: 0 f32 MFMA, 1 f16, 2 f32 tensors split into f16 pairs
-inline int ctx_mode(const infur_ctx* c) { return (int)c->opt.compute_dtype; }
+// (INFUR_DTYPE_F32_SPLIT_FP8 is the split mode everywhere except inside the GEMM: conv_mode() = 3 selects its MFMA sequence,
+//  its weight rows and its own tuning entries)
+inline bool ctx_fp8x(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F32_SPLIT_FP8; }
+inline int ctx_mode(const infur_ctx* c) { return ctx_fp8x(c) ? (int)INFUR_DTYPE_F32_SPLIT : (int)c->opt.compute_dtype; }
+inline int conv_mode(const infur_ctx* c) { return ctx_fp8x(c) ? 3 : ctx_mode(c); }
 inline int act_es(const infur_ctx* c) { return ctx_f16(c) ? 2 : 4; }
 
 // ---- profiling ----
@@ -359,14 +363,14 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         ConvLayer& L = g[i];
         L.w_scale = pow2_for(mx[2 * i]);
         if (L.role == 's') continue;
-        HIPCHK(c, launch_split_weights((float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, L.w_scale, c->stream));
+        HIPCHK(c, launch_split_weights((float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, L.w_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         if (L.d_u) {
             L.u_scale = pow2_for(mx[2 * i + 1]);
-            HIPCHK(c, launch_split_weights(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, L.u_scale, c->stream));
+            HIPCHK(c, launch_split_weights(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, L.u_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         }
         if (L.d_wcat) {
             L.wcat_scale = pow2_for(mx[2 * i + 1]);
-            HIPCHK(c, launch_split_weights((float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), L.wcat_scale, c->stream));
+            HIPCHK(c, launch_split_weights((float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), L.wcat_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         }
     }
     return INFUR_OK;
@@ -592,11 +596,11 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
             g.acc_scale = 1.0f / (g.a_scale * L.u_scale);
         }
         int gcfg = -1;
-        RETIF(pick_cfg(c, g, mode, 1, &gcfg));
+        RETIF(pick_cfg(c, g, conv_mode(c), 1, &gcfg));
         {
-            ProfScope ps(c, L.name, conv_igemm_config_name(gcfg, mode), 2.0 * P * T * (double)L.cout * L.cin,
+            ProfScope ps(c, L.name, conv_igemm_config_name(gcfg, conv_mode(c)), 2.0 * P * T * (double)L.cout * L.cin,
                          (double)V.bytes() + (double)M.bytes() + (double)P * L.cout * L.cin * 4, direct);
-            HIPCHK(c, launch_conv_igemm(g, mode, 1, gcfg, c->stream));
+            HIPCHK(c, launch_conv_igemm(g, conv_mode(c), 1, gcfg, c->stream));
         }
         pool_release(c, V);
         {
@@ -621,10 +625,10 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         a.amax = L.role == 'c' ? nullptr : c->d_range;  // the logits feed no GEMM
     }
     int cfg = -1;
-    RETIF(pick_cfg(c, a, mode, out_f32, &cfg));
+    RETIF(pick_cfg(c, a, conv_mode(c), out_f32, &cfg));
     {
-        ProfScope ps(c, L.name, conv_igemm_config_name(cfg, mode), flops, bytes);
-        HIPCHK(c, launch_conv_igemm(a, mode, out_f32, cfg, c->stream));
+        ProfScope ps(c, L.name, conv_igemm_config_name(cfg, conv_mode(c)), flops, bytes);
+        HIPCHK(c, launch_conv_igemm(a, conv_mode(c), out_f32, cfg, c->stream));
     }
     if (c->opt.keep_activations) c->kept.push_back(*out);
     return INFUR_OK;
@@ -652,10 +656,10 @@ int32_t run_conv_dual(infur_ctx* c, const ConvLayer& L3, const ConvLayer& D, con
     const double flops = 2.0 * oh * ow * (double)L3.cout * (L3.cin + D.cin);
     const double bytes = (double)t2.bytes() + (double)oh * ow * x.c * x.es + (double)out->bytes() + (double)L3.cout * (L3.cin + D.cin) * t2.es;
     int cfg = -1;
-    RETIF(pick_cfg(c, a, mode, mode != 1 ? 1 : 0, &cfg));
+    RETIF(pick_cfg(c, a, conv_mode(c), mode != 1 ? 1 : 0, &cfg));
     {
-        ProfScope ps(c, L3.name + "+downsample", conv_igemm_config_name(cfg, mode), flops, bytes);
-        HIPCHK(c, launch_conv_igemm(a, mode, mode != 1 ? 1 : 0, cfg, c->stream));
+        ProfScope ps(c, L3.name + "+downsample", conv_igemm_config_name(cfg, conv_mode(c)), flops, bytes);
+        HIPCHK(c, launch_conv_igemm(a, conv_mode(c), mode != 1 ? 1 : 0, cfg, c->stream));
     }
     return INFUR_OK;
 }
@@ -812,7 +816,7 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
             if (opts->struct_size != sizeof(infur_options)) return INFUR_E_INVALID_ARG;
             o = *opts;
         }
-        if (o.compute_dtype > INFUR_DTYPE_F32_SPLIT) return INFUR_E_INVALID_ARG;
+        if (o.compute_dtype > INFUR_DTYPE_F32_SPLIT_FP8) return INFUR_E_INVALID_ARG;
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || o.device < 0 || o.device >= n) return INFUR_E_HIP;
         if (hipSetDevice(o.device) != hipSuccess) return INFUR_E_HIP;
@@ -836,7 +840,7 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
                   hipMalloc((void**)&c->d_color_lut, col.size() * 4) == hipSuccess &&
                   hipMemcpy(c->d_pre_lut, pre.data(), pre.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemcpy(c->d_color_lut, col.data(), col.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-                  (o.compute_dtype != INFUR_DTYPE_F32_SPLIT ||
+                  ((o.compute_dtype != INFUR_DTYPE_F32_SPLIT && o.compute_dtype != INFUR_DTYPE_F32_SPLIT_FP8) ||
                    (hipMalloc((void**)&c->d_range, 2 * sizeof(unsigned)) == hipSuccess && hipMemset(c->d_range, 0, 2 * sizeof(unsigned)) == hipSuccess));
         if (!ok) {
             infur_ctx_destroy(c);

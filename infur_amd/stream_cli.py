@@ -25,8 +25,8 @@ def main(argv=None) -> int:
     ap.add_argument("--bilinear", action="store_true", help="bilinear Scale instead of the reference's nearest")
     ap.add_argument("--model", default="")
     ap.add_argument("--synthetic-weights", action="store_true")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f32s", "f16"],
-                    help="f32: exact f32 MFMA; f32s: f32 tensors on the f16 matrix cores (hi+lo pairs), same logits, ~1.9x; f16")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32s", "f32x", "f16"],
+                    help="f32: exact f32 MFMA; f32s: f32 tensors on the f16 matrix cores (hi+lo pairs), same logits, ~1.9x; f32x: f32s with the cross terms on the fp8 MFMA, logits 1.5e-4, ~2.1x; f16")
     ap.add_argument("--depth", type=int, default=2, help="frames in flight")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--input", default="-", help="raw bgr24 file (default stdin)")

@@ -15,7 +15,7 @@ from infur_amd import processors as P
 from infur_amd import weights as W
 
 RUNS = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-JOBS = [("f16", 101, 3840, 2160), ("f16", 50, 1920, 1080), ("f16", 50, 961, 541), ("f32s", 50, 1920, 1080), ("f32", 50, 1920, 1080)]
+JOBS = [("f16", 101, 3840, 2160), ("f16", 50, 1920, 1080), ("f16", 50, 961, 541), ("f32s", 50, 1920, 1080), ("f32x", 50, 1920, 1080), ("f32", 50, 1920, 1080)]
 bad = 0
 for dtype, depth, w, h in JOBS:
     blob = W.synth_blob(depth=depth)

@@ -15,8 +15,9 @@ JOBS = [  # (dtype, depth, (w, h), factor)
     ("f32", 50, (1920, 1080), 1.0), ("f32", 50, (1920, 1080), 0.5), ("f32", 50, (640, 480), 1.0), ("f32", 50, (320, 240), 1.0),
     ("f16", 50, (1920, 1080), 1.0), ("f16", 101, (3840, 2160), 1.0),
     ("f32s", 50, (1920, 1080), 1.0), ("f32s", 50, (1920, 1080), 0.5), ("f32s", 50, (640, 480), 1.0),
+    ("f32x", 50, (1920, 1080), 1.0), ("f32x", 50, (1920, 1080), 0.5),
 ]
-MODE = {"f32": "0", "f16": "1", "f32s": "2"}  # the `mode` column of the database
+MODE = {"f32": "0", "f16": "1", "f32s": "2", "f32x": "3"}  # the `mode` column of the database
 
 
 def main():

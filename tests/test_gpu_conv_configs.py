@@ -17,7 +17,7 @@ from infur_amd import weights as W
 from infur_amd.processors import Context, FramePath, Model, ModelCmd
 blob = W.synth_blob()
 out = {}
-for dt in ("f32", "f16"):
+for dt in ("f32", "f16", "f32x"):
     c = Context(device=0, dtype=dt)
     m = Model(c).control(ModelCmd.LoadBlob(blob))
     fr = W.synth_frame(135, 241, index=4)

@@ -14,26 +14,31 @@ from infur_amd.processors import Context, FramePath, Model, ModelCmd
 pytestmark = pytest.mark.gpu
 
 SPLIT_TOL = 3e-5  # relative to the largest logit; the native f32 MFMA mode measures ~4e-6, f16 ~2e-3
+# INFUR_DTYPE_F32_SPLIT_FP8 ("f32x"): hi*hi on the f16 MFMA, the cross terms hi*lo on the fp8 (e4m3) MX MFMA -- products exact
+# to ~2^-14.  Measured 1.2-1.5e-4 with Winograd F(6x6) (its output transform amplifies the product error), 4.5e-5 with
+# direct convs; north_star's bar is 1e-3.
+FP8X_TOL = 3e-4
 
 
 def rel_err(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+@pytest.mark.parametrize("dtype,SPLIT_TOL", [("f32s", SPLIT_TOL), ("f32x", FP8X_TOL)])
 @pytest.mark.parametrize("shape", [(48, 64), (270, 480), (540, 960)])
-def test_split_logits_and_mask(oracle, blob50, shape):
+def test_split_logits_and_mask(oracle, blob50, shape, dtype, SPLIT_TOL):
     from oracle.infur_oracle import TorchModel
 
     tm = TorchModel(blob50)
     h, w = shape
     fr = W.synth_frame(h, w, index=3)
-    c = Context(device=0, dtype="f32s")
+    c = Context(device=0, dtype=dtype)
     m = Model(c).control(ModelCmd.LoadBlob(blob50))
     rgba, _ = FramePath(c).advance(fr, 1.0)
     lo, la = m.lowres()
     tl, ta = tm.forward_lowres(oracle.pack_normalize(fr))
     e_out, e_aux = rel_err(lo, tl.numpy()), rel_err(la, ta.numpy())
-    print(f"f32s R50 {w}x{h}: logits rel err out={e_out:.2e} aux={e_aux:.2e}")
+    print(f"{dtype} R50 {w}x{h}: logits rel err out={e_out:.2e} aux={e_aux:.2e}")
     assert e_out < SPLIT_TOL and e_aux < SPLIT_TOL
     # post stage bit-exact given the logits this mode produced
     assert (rgba == oracle.colorcode(oracle.upsample_bilinear(lo, h, w))).all()
@@ -46,7 +51,7 @@ def test_split_logits_and_mask(oracle, blob50, shape):
     bad = kr != kg
     print(f"   class map differs on {bad.mean():.5%} of pixels")
     assert not (bad & (gap >= SPLIT_TOL * np.abs(ref).max())).any()
-    assert bad.mean() < 1e-3
+    assert bad.mean() < (1e-3 if dtype == "f32s" else 1e-2)
     c.close()
 
 
@@ -221,3 +226,22 @@ def test_split_range_only_in_split_mode(blob50):
     act, wino, saturated = c.split_range()
     assert 0 < act < 1e3 and 0 < wino < 1e5 and not saturated
     c.close()
+
+
+def test_fp8_cross_terms_without_winograd(oracle, blob50):
+    """f32x with direct 3x3 convs: the product error alone (no Winograd output transform amplifying it)"""
+    from oracle.infur_oracle import TorchModel
+
+    tm = TorchModel(blob50)
+    fr = W.synth_frame(270, 480, index=3)
+    tl, ta = tm.forward_lowres(oracle.pack_normalize(fr))
+    errs = {}
+    for name, kw in (("F(6x6)", {}), ("direct", {"winograd_min_cin": 0xFFFFFFFF})):
+        c = Context(device=0, dtype="f32x", **kw)
+        m = Model(c).control(ModelCmd.LoadBlob(blob50))
+        FramePath(c).advance(fr, 1.0)
+        lo, la = m.lowres()
+        errs[name] = max(rel_err(lo, tl.numpy()), rel_err(la, ta.numpy()))
+        c.close()
+    print("f32x logits rel err:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["direct"] < 1e-4 and errs["F(6x6)"] < FP8X_TOL

@@ -30,7 +30,7 @@ struct Args {
 
 int usage(const char* msg) {
     std::fprintf(stderr,
-                 "%s\nusage: infur_pipeline --width W --height H --model PATH [--scale F] [--bilinear] [--dtype f32|f32s|f16]\n"
+                 "%s\nusage: infur_pipeline --width W --height H --model PATH [--scale F] [--bilinear] [--dtype f32|f32s|f32x|f16]\n"
                  "       [--depth N] [--lanes N] [--device D] [--input FILE|-] [--output FILE|-|none] [--synthetic N] [--app] [--quiet]\n",
                  msg);
     return 2;
@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
             const std::string d = val();
             if (d == "f32") a.dtype = INFUR_DTYPE_F32;
             else if (d == "f32s") a.dtype = INFUR_DTYPE_F32_SPLIT;
+            else if (d == "f32x") a.dtype = INFUR_DTYPE_F32_SPLIT_FP8;
             else if (d == "f16") a.dtype = INFUR_DTYPE_F16;
             else return usage("unknown --dtype");
         } else return usage(("unknown argument " + k).c_str());
