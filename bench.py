@@ -424,7 +424,7 @@ def main():
                 nbuf = {"1buf": "1", "1frag": "3"}.get(parts[2], "2") if len(parts) > 2 else "2"
                 waves = {"128,256": "2, 4", "256,128": "4, 2", "256,32": "4, 1", "256,256": "2, 4"}.get(f"{bm},{bn}", "2, 2")
                 el = "_Float16, _Float16" if a.dtype == "f16" else "float, float"
-                split = {"f32": "false", "f16": "false", "f32s": "true"}[a.dtype]
+                split = {"f32": "false", "f16": "false", "f32s": "true", "f32x": "true"}[a.dtype]
                 # all instantiations of this tile (plain / 1x1-GEMM addressing / residual prefetch), launch-weighted
                 pre = f"conv_igemm_kernel<{el}, {bm}, {bn}, {waves}, {nbuf}, {split}"
                 ts = [t for k, t in json.load(open(tj))["kernels"].items() if k.startswith(pre)]

@@ -74,13 +74,14 @@ __device__ __forceinline__ void store_split(char* dst, const u32x4 r, const floa
 }
 
 // FP8X (f16 + fp8 cross terms): four f32 * scale -> 4 x f16 hi at dst, 4 x e4m3 of hi at row + 64 + 4 * chunk,
-// 4 x e4m3 of (x - hi) * 2^11 at row + 96 + 4 * chunk.  The conversion does not saturate (beyond +-448 it gives NaN): clamp.
+// 4 x e4m3 of (x - hi) * 2^11 at row + 96 + 4 * chunk.  Beyond +-448 the conversion saturates (FP16_OVFL mode, set by the kernel).
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+// (no clamp: the kernel runs with MODE.FP16_OVFL = 1, under which v_cvt_pk_fp8_f32 saturates to +-448 instead of producing
+//  NaN -- experiments/fp8x/fp8_ovfl_check.hip; eight v_med3 per 16-byte chunk less in the staging path)
 __device__ __forceinline__ int pack_fp8x4(const f32x4 v) {
-    const float lim = 448.0f;
     int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[0], -lim, lim), __builtin_amdgcn_fmed3f(v[1], -lim, lim), w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v[2], -lim, lim), __builtin_amdgcn_fmed3f(v[3], -lim, lim), w, true);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
     return w;
 }
 // activations: hi as it is (hi = x * a_scale: the e4m3 range +-448 covers |x| <= 112 at a_scale = 4; beyond it the fp8 copy is
