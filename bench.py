@@ -421,7 +421,7 @@ def main():
             if os.path.exists(tj) and (Wd, H, a.scale, a.depth) == (1920, 1080, 1.0, 50):
                 parts = dom_name.split("<")[1].rstrip(">").split(",")  # "64,64" or "64,64,1buf" / "256,256,1frag"
                 bm, bn = parts[0], parts[1]
-                nbuf = {"1buf": "1", "1frag": "3"}.get(parts[2], "2") if len(parts) > 2 else "2"
+                nbuf = {"1buf": "1", "1frag": "3", "dma": "4", "dmai": "5"}.get(parts[2], "2") if len(parts) > 2 else "2"
                 waves = {"128,256": "2, 4", "256,128": "4, 2", "256,32": "4, 1", "256,256": "2, 4"}.get(f"{bm},{bn}", "2, 2")
                 el = "_Float16, _Float16" if a.dtype == "f16" else "float, float"
                 split = {"f32": "false", "f16": "false", "f32s": "true", "f32x": "true"}[a.dtype]
