@@ -261,11 +261,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # INFUR_BENCH_FORCE_COLLECTIVES=1 under a launcher with ONE rank: the process group is initialised and every
+    # collective of the N > 1 path (broadcast of the blob, barrier, max-reduce, all-gather of the mask hashes) runs
+    # over a one-rank communicator -- this is how the RCCL branch executes on a 1-GPU box (tests/test_gpu_multi.py)
+    multi = world > 1 or (os.environ.get("INFUR_BENCH_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
     ndev = torch.cuda.device_count()
     dev = local_rank if a.backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev)
     coll_dev = f"cuda:{dev}" if a.backend == "nccl" else "cpu"
-    if world > 1:
+    if multi:
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
         else:
@@ -282,7 +286,7 @@ def main():
     # ---- weights: rank 0 synthesises, RCCL broadcast over xGMI, every rank repacks locally; the rank's other
     #      contexts get the repacked arena through the C ABI's group call (device-to-device on one GPU) ----
     blob = W.synth_blob(depth=a.depth) if rank == 0 else None
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -326,7 +330,7 @@ def main():
         step()
     sync_all()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -338,17 +342,17 @@ def main():
         step(profile_last=(not a.no_profile) and k == a.steps - 1)
     sync_all()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # every rank decodes the SAME frame once more (outside the timed region): replicas must agree bit for bit
     agree = None
-    if world > 1:
+    if multi:
         f0 = torch.from_numpy(W.synth_frame(H, Wd, index=0)).cuda()
         fps_[K - 1].advance_dev(f0.data_ptr(), Wd, H, a.scale, d_masks[0].data_ptr(), d_masks[0].numel())
         sync_all()
@@ -378,7 +382,7 @@ def main():
         "config": {
             "workload": f"{Wd}x{H} packed-BGR frame, FCN-ResNet{a.depth} {a.dtype} (aux head {'off' if a.no_aux else 'on'}), "
                         f"scale={a.scale}" + (" [BASELINE configs[1]]" if (Wd, H, a.scale, a.dtype, a.depth) == (1920, 1080, 1.0, "f32", 50) else ""),
-            "frames_per_step_per_gpu": B, "contexts_per_gpu": K, "frames_per_s_one_context": one_ctx_fps, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if world > 1 else None,
+            "frames_per_step_per_gpu": B, "contexts_per_gpu": K, "frames_per_s_one_context": one_ctx_fps, "sharding": f"frames x{world}, no data-path collective", "backend": a.backend if multi else None,
             "weights": f"synthetic seed {W.DEFAULT_SEED:#x}, {nbytes / 1e6:.1f} MB blob",
             "weights_load_ms": round(load_ms, 2), "weights_bcast_ms": round(bcast_ms, 3),
             "weights_note": "weights_load_ms = broadcast + per-rank repack into kernel layouts; weights_bcast_ms = the "
@@ -500,7 +504,7 @@ def main():
 
     for c in ctxs:
         c.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -9,6 +9,7 @@ every rank repacks it locally (``infur_model_load_blob_dev``).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -69,7 +70,10 @@ def load_model_everywhere(ctx, blob: Optional[bytes], src: int = 0, coll_device:
     import torch.distributed as dist
 
     gpu = f"cuda:{ctx.device}"
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # a one-rank group counts when INFUR_BENCH_FORCE_COLLECTIVES=1: the collective calls then execute (on RCCL for
+    # backend nccl) although there is nobody to talk to -- how the nccl branch is exercised on a 1-GPU box
+    forced = os.environ.get("INFUR_BENCH_FORCE_COLLECTIVES") == "1"
+    multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced)
     bcast_ms = 0.0
     if not multi:
         t = broadcast_blob(blob, device=gpu, src=src)

@@ -259,3 +259,28 @@ def test_bench_self_launches_two_ranks_on_one_gpu(tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
     assert j["config"]["weights_bcast_ms"] >= 0 and j["config"]["ranks_agree_on_frame0_mask"] is True
+
+
+def test_bench_rccl_branch_executes_on_one_rank(tmp_path):
+    """The `nccl` (= RCCL) branch of bench.py's N > 1 path on the 1-GPU box: RCCL refuses two ranks on one device, so
+    the launcher starts ONE rank and INFUR_BENCH_FORCE_COLLECTIVES=1 makes bench.py initialise the nccl process group
+    and run every collective of the multi-rank path (blob broadcast from a device buffer, barrier, MAX all-reduce of
+    the elapsed time, all-gather of the mask hashes) over that one-rank communicator."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env["INFUR_BENCH_FORCE_COLLECTIVES"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend",
+                        "nccl", "--steps", "2", "--warmup", "1", "--frames-per-step", "2", "--width", "320", "--height",
+                        "240", "--no-cpu-baseline", "--no-split", "--no-side"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["backend"] == "nccl"
+    assert j["config"]["weights_bcast_ms"] > 0 and j["config"]["ranks_agree_on_frame0_mask"] is True
