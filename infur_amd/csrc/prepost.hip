@@ -358,6 +358,38 @@ __device__ __forceinline__ UpTile stage_lowres_tile(const float* __restrict__ lo
     return t;
 }
 
+// Both kernels: a wave owns FOUR CONSECUTIVE output rows of the tile.  At the network's 8x ratio consecutive rows
+// nearly always share their pair of source rows, so the 4 x NQ neighbour quads (ds_read_b128) stay in registers and are
+// re-read only when the (wave-uniform) row pair changes: a quarter of the LDS traffic of the round-2 first form.  NQ =
+// ceil(K / 4) is a template argument and every quad is evaluated whole -- the pad classes of a staged slot are zeros,
+// their value is +0 and can never pass the strict '>' against c_max >= 0 -- so the body is straight-line code (the
+// run-time `k < K` guards of the first form compiled to ds_read_b32 + a branch per class: 22 us at 1080p).  Class pairs
+// go through 2-vectors so that the multiplies AND the adds are v_pk_*_f32; per class the expression tree is unchanged.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NQ>
+__device__ __forceinline__ void load_quads(const float* ra, const float* rb, int ca, int cb, float4 (&v11)[NQ],
+                                           float4 (&v21)[NQ], float4 (&v12)[NQ], float4 (&v22)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        v11[q] = *reinterpret_cast<const float4*>(ra + ca + 4 * q);
+        v21[q] = *reinterpret_cast<const float4*>(ra + cb + 4 * q);
+        v12[q] = *reinterpret_cast<const float4*>(rb + ca + 4 * q);
+        v22[q] = *reinterpret_cast<const float4*>(rb + cb + 4 * q);
+    }
+}
+
+// classes (k, k+1) of one pixel: ((w11*X11 + w21*X21) + w12*X12) + w22*X22 with w11 = dx2*dy2 ... exactly bilerp()
+__device__ __forceinline__ f32x2 bilerp2(f32x2 X11, f32x2 X21, f32x2 X12, f32x2 X22, float w11, float w21, float w12,
+                                         float w22) {
+    f32x2 v = w11 * X11;
+    v = v + w21 * X21;
+    v = v + w12 * X12;
+    v = v + w22 * X22;
+    return v;
+}
+
+template <int NQ>
 __global__ void __launch_bounds__(256)
     upsample_argmax_shade_lds_kernel(const float* __restrict__ low, int LH, int LW, int K,
                                      const uint32_t* __restrict__ lut, uint32_t* __restrict__ rgba, int OH, int OW) {
@@ -368,34 +400,35 @@ __global__ void __launch_bounds__(256)
     if (x >= OW) return;
     const Lerp tx = t.tx[xl];
     const int ca = (tx.i1 - t.c0) * UP_KP, cb = (tx.i2 - t.c0) * UP_KP;
+    float4 v11[NQ], v21[NQ], v12[NQ], v22[NQ];
+    int pi1 = -1, pi2 = -1;
 #pragma unroll
     for (int rr = 0; rr < UP_TH / 4; rr++) {
-        const int yl = (threadIdx.x >> 6) + 4 * rr;
+        const int yl = 4 * (threadIdx.x >> 6) + rr;
         const int y = blockIdx.y * UP_TH + yl;
-        if (y >= OH) continue;
+        if (y >= OH) break;
         const Lerp ty = t.ty[yl];
-        const float* ra = t.pix + (ty.i1 - t.r0) * t.nc * UP_KP;
-        const float* rb = t.pix + (ty.i2 - t.r0) * t.nc * UP_KP;
+        const int i1 = __builtin_amdgcn_readfirstlane(ty.i1), i2 = __builtin_amdgcn_readfirstlane(ty.i2);
+        if (i1 != pi1 || i2 != pi2) {
+            load_quads<NQ>(t.pix + (i1 - t.r0) * t.nc * UP_KP, t.pix + (i2 - t.r0) * t.nc * UP_KP, ca, cb, v11, v21, v12, v22);
+            pi1 = i1;
+            pi2 = i2;
+        }
+        const float w11 = tx.d2 * ty.d2, w21 = tx.d1 * ty.d2, w12 = tx.d2 * ty.d1, w22 = tx.d1 * ty.d1;
         int k_max = 0;
         float c_max = 0.0f;
 #pragma unroll
-        for (int q = 0; q < UP_KP / 4; q++) {
-            if (4 * q >= K) break;
-            const float4 v11 = *reinterpret_cast<const float4*>(ra + ca + 4 * q);
-            const float4 v21 = *reinterpret_cast<const float4*>(ra + cb + 4 * q);
-            const float4 v12 = *reinterpret_cast<const float4*>(rb + ca + 4 * q);
-            const float4 v22 = *reinterpret_cast<const float4*>(rb + cb + 4 * q);
-            const float a11[4] = {v11.x, v11.y, v11.z, v11.w}, a21[4] = {v21.x, v21.y, v21.z, v21.w};
-            const float a12[4] = {v12.x, v12.y, v12.z, v12.w}, a22[4] = {v22.x, v22.y, v22.z, v22.w};
+        for (int q = 0; q < NQ; q++) {
+            const f32x2 lo = bilerp2(f32x2{v11[q].x, v11[q].y}, f32x2{v21[q].x, v21[q].y}, f32x2{v12[q].x, v12[q].y},
+                                     f32x2{v22[q].x, v22[q].y}, w11, w21, w12, w22);
+            const f32x2 hi = bilerp2(f32x2{v11[q].z, v11[q].w}, f32x2{v21[q].z, v21[q].w}, f32x2{v12[q].z, v12[q].w},
+                                     f32x2{v22[q].z, v22[q].w}, w11, w21, w12, w22);
+            const float c[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int k = 4 * q + e;
-                if (k < K) {
-                    const float c = bilerp(a11[e], a21[e], a12[e], a22[e], tx.d1, tx.d2, ty.d1, ty.d2);
-                    if (c > c_max) {
-                        k_max = k;
-                        c_max = c;
-                    }
+                if (c[e] > c_max) {
+                    k_max = 4 * q + e;
+                    c_max = c[e];
                 }
             }
         }
@@ -403,6 +436,7 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+template <int NQ>
 __global__ void __launch_bounds__(256)
     upsample_planar_lds_kernel(const float* __restrict__ low, int LH, int LW, int K, float* __restrict__ out, int OH, int OW) {
     extern __shared__ __attribute__((aligned(16))) float up_smem[];
@@ -413,32 +447,46 @@ __global__ void __launch_bounds__(256)
     const Lerp tx = t.tx[xl];
     const int ca = (tx.i1 - t.c0) * UP_KP, cb = (tx.i2 - t.c0) * UP_KP;
     const size_t plane = (size_t)OH * OW;
+    float4 v11[NQ], v21[NQ], v12[NQ], v22[NQ];
+    int pi1 = -1, pi2 = -1;
 #pragma unroll
     for (int rr = 0; rr < UP_TH / 4; rr++) {
-        const int yl = (threadIdx.x >> 6) + 4 * rr;
+        const int yl = 4 * (threadIdx.x >> 6) + rr;
         const int y = blockIdx.y * UP_TH + yl;
-        if (y >= OH) continue;
+        if (y >= OH) break;
         const Lerp ty = t.ty[yl];
-        const float* ra = t.pix + (ty.i1 - t.r0) * t.nc * UP_KP;
-        const float* rb = t.pix + (ty.i2 - t.r0) * t.nc * UP_KP;
+        const int i1 = __builtin_amdgcn_readfirstlane(ty.i1), i2 = __builtin_amdgcn_readfirstlane(ty.i2);
+        if (i1 != pi1 || i2 != pi2) {
+            load_quads<NQ>(t.pix + (i1 - t.r0) * t.nc * UP_KP, t.pix + (i2 - t.r0) * t.nc * UP_KP, ca, cb, v11, v21, v12, v22);
+            pi1 = i1;
+            pi2 = i2;
+        }
+        const float w11 = tx.d2 * ty.d2, w21 = tx.d1 * ty.d2, w12 = tx.d2 * ty.d1, w22 = tx.d1 * ty.d1;
         float* o = out + (size_t)y * OW + x;
 #pragma unroll
-        for (int q = 0; q < UP_KP / 4; q++) {
-            if (4 * q >= K) break;
-            const float4 v11 = *reinterpret_cast<const float4*>(ra + ca + 4 * q);
-            const float4 v21 = *reinterpret_cast<const float4*>(ra + cb + 4 * q);
-            const float4 v12 = *reinterpret_cast<const float4*>(rb + ca + 4 * q);
-            const float4 v22 = *reinterpret_cast<const float4*>(rb + cb + 4 * q);
-            const float a11[4] = {v11.x, v11.y, v11.z, v11.w}, a21[4] = {v21.x, v21.y, v21.z, v21.w};
-            const float a12[4] = {v12.x, v12.y, v12.z, v12.w}, a22[4] = {v22.x, v22.y, v22.z, v22.w};
+        for (int q = 0; q < NQ; q++) {
+            const f32x2 lo = bilerp2(f32x2{v11[q].x, v11[q].y}, f32x2{v21[q].x, v21[q].y}, f32x2{v12[q].x, v12[q].y},
+                                     f32x2{v22[q].x, v22[q].y}, w11, w21, w12, w22);
+            const f32x2 hi = bilerp2(f32x2{v11[q].z, v11[q].w}, f32x2{v21[q].z, v21[q].w}, f32x2{v12[q].z, v12[q].w},
+                                     f32x2{v22[q].z, v22[q].w}, w11, w21, w12, w22);
+            const float c[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int k = 4 * q + e;
-                if (k < K) o[(size_t)k * plane] = bilerp(a11[e], a21[e], a12[e], a22[e], tx.d1, tx.d2, ty.d1, ty.d2);
-            }
+            for (int e = 0; e < 4; e++)
+                if (4 * q + e < K) o[(size_t)(4 * q + e) * plane] = c[e];
         }
     }
 }
+
+// NQ = ceil(K / 4) -> the instantiation (K <= UP_KP = 24 is checked by up_tile_lds_bytes)
+#define UP_DISPATCH_NQ(KERNEL, K, ...)                                              \
+    switch (((K) + 3) / 4) {                                                        \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                  \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                  \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                  \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                  \
+        case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                  \
+        default: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                 \
+    }
 
 // LDS bytes of the staged rectangle for this geometry, or 0 when the scalar fallback must run (more classes than
 // the padded pixel slot holds, or a ratio whose footprint is too big to be worth staging)
@@ -455,7 +503,7 @@ hipError_t launch_upsample_planar(const float* low, int LH, int LW, int K, float
     const size_t lds = up_tile_lds_bytes(LH, LW, K, OH, OW);
     if (lds) {
         dim3 grid((OW + UP_TW - 1) / UP_TW, (OH + UP_TH - 1) / UP_TH);
-        hipLaunchKernelGGL(upsample_planar_lds_kernel, grid, dim3(256), lds, s, low, LH, LW, K, out, OH, OW);
+        UP_DISPATCH_NQ(upsample_planar_lds_kernel, K, grid, dim3(256), lds, s, low, LH, LW, K, out, OH, OW)
     } else {
         dim3 grid((OW + 63) / 64, (OH + 3) / 4);
         hipLaunchKernelGGL(upsample_planar_kernel, grid, dim3(256), 0, s, low, LH, LW, K, out, OH, OW);
@@ -492,7 +540,7 @@ hipError_t launch_upsample_argmax_shade(const float* low, int LH, int LW, int K,
     const size_t lds = up_tile_lds_bytes(LH, LW, K, OH, OW);
     if (lds) {
         dim3 grid((OW + UP_TW - 1) / UP_TW, (OH + UP_TH - 1) / UP_TH);
-        hipLaunchKernelGGL(upsample_argmax_shade_lds_kernel, grid, dim3(256), lds, s, low, LH, LW, K, lut, rgba, OH, OW);
+        UP_DISPATCH_NQ(upsample_argmax_shade_lds_kernel, K, grid, dim3(256), lds, s, low, LH, LW, K, lut, rgba, OH, OW)
     } else {
         dim3 grid((OW + 63) / 64, (OH + 3) / 4);
         hipLaunchKernelGGL(upsample_argmax_shade_kernel, grid, dim3(256), 0, s, low, LH, LW, K, lut, rgba, OH, OW);

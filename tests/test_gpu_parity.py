@@ -502,3 +502,27 @@ def test_fused_stem_pool_matches_the_two_kernel_form(blob50, dtype):
             else:
                 e = rel_err(x, y)
                 assert e < tol, (dtype, w, h, e)
+
+
+@pytest.mark.parametrize("ncls", [1, 3, 4, 7, 12, 13, 17, 20, 24, 25, 31])
+def test_post_kernels_for_other_class_counts(oracle, ncls):
+    """The LDS-staged up-sample kernels are instantiated per ceil(K / 4) class quads and evaluate whole quads (the
+    pad classes of a staged pixel are zeros); K > 24 takes the scalar fallback.  Every instantiation, at a ragged
+    size: fused up-sample + argmax + shade == oracle up-sample -> ColorCode on the same low-res logits, and the
+    planar up-sample of Model::advance == the oracle's, bit for bit."""
+    blob = W.synth_blob(num_classes=ncls, aux=False)
+    c = Context(device=0)
+    m = Model(c).control(ModelCmd.LoadBlob(blob))
+    assert m.get_info().num_classes == ncls
+    fr = W.synth_frame(70, 131, index=ncls)
+    h, w = fr.shape[:2]
+    rgba, _ = FramePath(c).advance(fr, 1.0)
+    lo, _ = m.lowres()
+    up = oracle.upsample_bilinear(lo, h, w)
+    assert (rgba == oracle.colorcode(up)).all()
+    out = []
+    m.advance(fr, out)
+    lo2, _ = m.lowres()
+    assert (lo2 == lo).all()
+    assert out[0].shape == (ncls, h, w) and (out[0] == up).all()
+    c.close()
