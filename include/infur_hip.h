@@ -98,7 +98,7 @@ typedef struct infur_options {
 /* ModelInfo, predict_onnx.rs:56-62 */
 typedef struct infur_model_info {
     char input_name[32];    /* "input" */
-    char input0_dtype[16];  /* "Float" */
+    char input0_dtype[16];  /* "Float" | "Uint8": the model's declared image input (predict_onnx.rs:90,255) */
     char output_names[2][32]; /* "out", "aux" */
     uint32_t n_outputs;     /* 2, or 1 when the file has no aux head or options.compute_aux == 0 */
     uint32_t num_classes;
@@ -147,7 +147,10 @@ int32_t infur_scale_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t 
 
 /* ---- Model (predict_onnx.rs:283-345) ---- */
 /* ModelCmd::Load(path) (predict_onnx.rs:288-312): empty path unloads.  The file is an
- * INFURW01 weight blob (infur_amd/weights.py). */
+ * INFURW01 weight blob (infur_amd/weights.py) or an ONNX model.  What the model is fed follows the
+ * reference (predict_onnx.rs:103-139,296-301): a Float image input gets RGB planes normalised with
+ * the torchvision constants; a Uint8 image input gets the frame's bytes themselves, BGR kept;
+ * NCHW / NHWC is the file's own business (a Transpose in front of its stem). */
 int32_t infur_model_load(infur_ctx* ctx, const char* path);
 /* Host-only converter behind infur_model_load's .onnx support (no context, no GPU): parses an
  * ONNX ModelProto (float FCN-ResNet50/101 as exported by torchvision, BN folded or not) with the
@@ -189,8 +192,9 @@ int32_t infur_debug_read_activation(infur_ctx* ctx, uint32_t index, float* host_
                                     size_t cap_floats, uint32_t* c, uint32_t* h, uint32_t* w);
 
 /* pre-proc on its own (predict_onnx.rs:103-137): packed BGR u8 -> [3,h,w] f32, RGB planar,
- * ((v*1)/255 - mean) * (1/std).  The fused path folds this into the stem convolution; it is
- * exported so this stage can be parity-checked (and used) in isolation. */
+ * ((v*1)/255 - mean) * (1/std): the ColorRange::Float32 arm.  The fused path folds this into the
+ * stem convolution (for Uint8-input models: the identity table); it is exported so this stage can
+ * be parity-checked (and used) in isolation. */
 int32_t infur_pack_normalize(infur_ctx* ctx, const uint8_t* bgr, uint32_t w, uint32_t h,
                              float* chw);
 int32_t infur_pack_normalize_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t h,

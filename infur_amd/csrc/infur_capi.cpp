@@ -189,6 +189,9 @@ void prof_reset(infur_ctx* c) {
 // ---- lookup tables (host side, exact reference operation order) ----
 // predict_onnx.rs:128 `f32::from(v) * 1f32 / 255f32`, :131-136 `(x - mean) * (1/std)`;
 // ColorNorm::new_torchvision_rgb :175-180.  volatile keeps every rounding step.
+// the table the stem kernels index with a pixel's bytes: the Float pre-proc, or the identity for Uint8-input models
+inline const float* stem_lut(const infur_ctx* c) { return c->input_u8 ? c->d_u8_lut : c->d_pre_lut; }
+
 void build_pre_lut(float* lut) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     for (int ch = 0; ch < 3; ch++) {
@@ -389,6 +392,10 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     const int depth = (int)h32[0], ncls = (int)h32[1];
     const bool aux = h32[2] != 0;
     const uint32_t n = h32[3];
+    // input kind: 0 = Float image input (RGB planes normalised with the torchvision constants), 1 = Uint8 (the bytes
+    // themselves, BGR kept) -- the two ColorRange arms of ImageSession::forward (predict_onnx.rs:114-139)
+    if (h32[4] > 1) return fail(c, INFUR_E_MODEL_FORMAT, "unknown input kind %u in the weight blob (0 = Float, 1 = Uint8)", h32[4]);
+    const bool input_u8 = h32[4] == 1;
     int lb[4];
     if (!layer_blocks(depth, lb)) return fail(c, INFUR_E_MODEL_FORMAT, "unsupported backbone depth %d (50 or 101)", depth);
     if (ncls <= 0 || ncls > 256) return fail(c, INFUR_E_MODEL_FORMAT, "unsupported class count %d", ncls);
@@ -444,7 +451,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         off += align_up(bn, 256);
         const float* src_w = (const float*)((const uint8_t*)d_blob + ents[i].w_off);
         if (L.role == 's')
-            HIPCHK(c, launch_repack_stem(src_w, (float*)L.d_w, c->stream));
+            HIPCHK(c, launch_repack_stem(src_w, (float*)L.d_w, input_u8 ? 1 : 0, c->stream));
         else if (L.k == 1 && !ctx_f16(c))
             HIPCHK(c, hipMemcpyAsync(L.d_w, src_w, wn, hipMemcpyDeviceToDevice, c->stream));  // OI11 == O11I
         else
@@ -478,13 +485,14 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     c->depth = depth;
     c->num_classes = ncls;
     c->has_aux = aux;
+    c->input_u8 = input_u8;
     c->weight_bytes = total;
     c->loaded = true;
     infur_model_info& mi = c->info;
     memset(&mi, 0, sizeof mi);
     // names as the reference prints them: "input -> out,aux" (predict_onnx.rs:378-380)
     snprintf(mi.input_name, sizeof mi.input_name, "input");
-    snprintf(mi.input0_dtype, sizeof mi.input0_dtype, "Float");  // the model's declared input type (predict_onnx.rs:90)
+    snprintf(mi.input0_dtype, sizeof mi.input0_dtype, input_u8 ? "Uint8" : "Float");  // the model's declared input type (predict_onnx.rs:90)
     snprintf(mi.output_names[0], 32, "out");
     // the aux output exists when the file has the head AND this context evaluates it (options.compute_aux)
     mi.n_outputs = 1 + ((aux && c->opt.compute_aux) ? 1 : 0);
@@ -686,13 +694,13 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
         ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes(),
                      2.0 * sh * sw * 64 * 147);
         // exact f32 MFMA in the f32 mode; in the f16-rate modes the stem runs on the f16 matrix cores as the conv stack does
-        HIPCHK(c, launch_stem_pool(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, c->d_pre_lut, x.p, ctx_mode(c), sh, sw, ph, pw,
+        HIPCHK(c, launch_stem_pool(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, stem_lut(c), x.p, ctx_mode(c), sh, sw, ph, pw,
                                    kSplitActScale, stem.w_scale, c->d_range, c->stream));
     } else {
         {
             RETIF(talloc(c, sh, sw, 64, act_es(c), &s));
             ProfScope ps(c, stem.name, "stem_conv7x7", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)s.bytes());
-            HIPCHK(c, launch_stem_conv7x7(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, c->d_pre_lut, s.p, ctx_f16(c) ? 1 : 0, sh, sw, c->stream));
+            HIPCHK(c, launch_stem_conv7x7(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, stem_lut(c), s.p, ctx_f16(c) ? 1 : 0, sh, sw, c->stream));
         }
         if (c->opt.keep_activations) c->kept.push_back(s);
         {
@@ -836,7 +844,11 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
         std::vector<uint32_t> col(20 * 256);
         build_pre_lut(pre.data());
         build_color_lut(col.data());
+        std::vector<float> ident(768);
+        for (int i = 0; i < 768; i++) ident[i] = (float)(i & 255);
         bool ok = hipMalloc((void**)&c->d_pre_lut, pre.size() * 4) == hipSuccess &&
+                  hipMalloc((void**)&c->d_u8_lut, ident.size() * 4) == hipSuccess &&
+                  hipMemcpy(c->d_u8_lut, ident.data(), ident.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                   hipMalloc((void**)&c->d_color_lut, col.size() * 4) == hipSuccess &&
                   hipMemcpy(c->d_pre_lut, pre.data(), pre.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemcpy(c->d_color_lut, col.data(), col.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -868,6 +880,7 @@ void infur_ctx_destroy(infur_ctx* c) {
     prof_reset(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     if (c->d_pre_lut) (void)hipFree(c->d_pre_lut);
+    if (c->d_u8_lut) (void)hipFree(c->d_u8_lut);
     if (c->d_color_lut) (void)hipFree(c->d_color_lut);
     if (c->d_range) (void)hipFree(c->d_range);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

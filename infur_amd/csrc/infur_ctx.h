@@ -65,7 +65,8 @@ struct infur_ctx {
     std::string err;
 
     // lookup tables
-    float* d_pre_lut = nullptr;     // [3][256] f32, RGB order
+    float* d_pre_lut = nullptr;     // [3][256] f32, RGB order: Float-input models (predict_onnx.rs:126-137)
+    float* d_u8_lut = nullptr;      // [3][256] f32, lut[c][v] = v: Uint8-input models get the bytes themselves (:116-122)
     uint32_t* d_color_lut = nullptr;  // [20][256] premultiplied RGBA
 
     // model
@@ -73,6 +74,7 @@ struct infur_ctx {
     infur_model_info info{};
     int depth = 0, num_classes = 0;
     bool has_aux = false;
+    bool input_u8 = false;  // the model declares a Uint8 image input: raw BGR bytes, no normalisation
     std::vector<infur::ConvLayer> convs;
     void* d_weights = nullptr;  // single allocation holding every repacked tensor
     size_t weight_bytes = 0;

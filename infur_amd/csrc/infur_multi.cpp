@@ -161,6 +161,7 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
     dst->depth = root->depth;
     dst->num_classes = root->num_classes;
     dst->has_aux = root->has_aux;
+    dst->input_u8 = root->input_u8;
     dst->info = root->info;
     dst->info.n_outputs = 1 + ((root->has_aux && dst->opt.compute_aux) ? 1 : 0);
     if (dst->info.n_outputs < 2) dst->info.output_names[1][0] = 0;

@@ -98,7 +98,9 @@ hipError_t launch_split_weights(float* w, size_t n, float scale, int fp8_cross, 
 hipError_t launch_concat_rows(const void* a, size_t a_bytes, const void* b, size_t b_bytes, void* out, int rows, hipStream_t s);
 hipError_t launch_add_f32(const float* x, const float* y, float* sum, int n, hipStream_t s);
 // OIHW (O=64,I=3,7x7) -> [ky][kx][c][o] for the stem kernel
-hipError_t launch_repack_stem(const float* src, float* dst, hipStream_t s);
+// reverse_c: the kernels read a pixel's channels as (p[2], p[1], p[0]); a model whose channel 0 is B (Uint8 input:
+// BGR kept, predict_onnx.rs:296-301) gets its stem weights stored with the input-channel axis reversed instead
+hipError_t launch_repack_stem(const float* src, float* dst, int reverse_c, hipStream_t s);
 
 // Scale: packed BGR u8 resize.  mode 0 nearest, 1 bilinear (definitions: oracle/infur_oracle.c)
 hipError_t launch_scale_bgr(const uint8_t* in, int W, int H, uint8_t* out, int OW, int OH,

@@ -301,9 +301,15 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
     if (in0->dims.size() != 4) { err = "only 4 dimensions supported got " + std::to_string(in0->dims.size()); return 2; }
     if (col != 1 && col != 3) { err = "color dimension only at NCHW or NHWC but not in position " + std::to_string(col) + " supported"; return 2; }
     if (in0->elem_type != 1 && in0->elem_type != 2) { err = "only Float (f32) and Uint8 (u8) input supported, got elem_type " + std::to_string(in0->elem_type); return 2; }
-    if (col != 1 || in0->elem_type != 1) { err = "this build runs NCHW Float segmentation models only (fcn-resnet50/101); got a different input layout/dtype"; return 2; }
+    // (DimSeq, ColorRange) exactly as the reference infers them: NCHW / NHWC by the position of the 3, Float32 / Uint8
+    // by the element type.  What they mean for the path (predict_onnx.rs:103-138,296-301): a Float input gets RGB planes
+    // normalised with the torchvision constants; a Uint8 input gets the raw bytes in BGR order; NHWC inputs get the
+    // frame's own layout.  The graph side of a non-default input is checked below ("front").
+    const bool in_nhwc = col == 3, in_u8 = in0->elem_type == 2;
     info.input_name = in0->name;
-    info.input_dtype = "Float";
+    info.input_dtype = in_u8 ? "Uint8" : "Float";
+    info.input_u8 = in_u8;
+    info.input_nhwc = in_nhwc;
     for (auto& o : outputs) info.output_names.push_back(o.name);
 
     // ---- opset: Resize's coordinate rule is only spelled out from opset 11 on ----
@@ -465,6 +471,34 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
     };
 
     std::string t = in0->name, t3;
+    // ---- front: what a Uint8 and / or NHWC image input must pass on its way to the stem ----
+    // The session is handed bytes (Uint8) and / or the frame's own H x W x 3 layout (NHWC); the convolution needs NCHW
+    // floats, so such a file carries exactly one Cast(to = FLOAT) and / or one Transpose(perm = 0,3,1,2) in front of the
+    // stem, in either order.  Anything else there (in-graph arithmetic on the pixels) is not a model this path runs.
+    {
+        bool seen_cast = false, seen_tr = false;
+        for (int hop = 0; hop < 2; hop++) {
+            std::vector<int> u;
+            users(t, u);
+            if (u.size() != 1 || nodes[u[0]].out.empty()) break;
+            const Node& n = nodes[u[0]];
+            if (n.op == "Cast" && in_u8 && !seen_cast) {
+                auto it = n.ints.find("to");
+                if (it == n.ints.end() || it->second.empty() || it->second[0] != 1) { err = "the Cast after the Uint8 image input must produce FLOAT"; return 2; }
+                seen_cast = true;
+            } else if (n.op == "Transpose" && in_nhwc && !seen_tr) {
+                auto it = n.ints.find("perm");
+                const std::vector<int64_t> want = {0, 3, 1, 2};
+                if (it == n.ints.end() || it->second != want) { err = "the Transpose after the NHWC image input must be perm = [0,3,1,2]"; return 2; }
+                seen_tr = true;
+            } else {
+                break;
+            }
+            t = n.out[0];
+        }
+        if (in_u8 && !seen_cast) { err = "a Uint8 image input must reach the stem convolution through one Cast to FLOAT"; return 2; }
+        if (in_nhwc && !seen_tr) { err = "an NHWC image input must reach the stem convolution through one Transpose(perm = [0,3,1,2])"; return 2; }
+    }
     if (!sole_user(t, "Conv", "the image input", idx)) return 2;
     if ((rc = take(idx))) return rc;
     if (!relu_after(convs[slot - 1].out, "the stem convolution", t)) return 2;
@@ -623,6 +657,7 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
     put_u32(blob, 12, (uint32_t)ncls);
     put_u32(blob, 16, aux ? 1u : 0u);
     put_u32(blob, 20, (uint32_t)n);
+    put_u32(blob, 24, in_u8 ? 1u : 0u);  // input kind: 0 = Float (normalised RGB planes), 1 = Uint8 (raw BGR bytes)
     for (size_t i = 0; i < n; i++) {
         const size_t e = 32 + i * 80;
         memcpy(blob.data() + e, exp[i].name.c_str(), exp[i].name.size() < 39 ? exp[i].name.size() : 39);

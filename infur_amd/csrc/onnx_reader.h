@@ -12,6 +12,7 @@ struct OnnxInfo {
     std::vector<std::string> output_names;
     int depth = 0, num_classes = 0;
     bool aux = false;
+    bool input_u8 = false, input_nhwc = false;  // the declared image input (predict_onnx.rs:223-265)
 };
 
 bool looks_like_onnx(const uint8_t* data, size_t len);

@@ -580,7 +580,7 @@ hipError_t launch_repack_oihw_to_ohwi(const float* src, void* dst, int f16, int 
     return hipGetLastError();
 }
 
-__global__ void repack_stem_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+__global__ void repack_stem_kernel(const float* __restrict__ src, float* __restrict__ dst, int reverse_c) {
     // dst [ky][kx][c][o]  <-  src [o][c][ky][kx]   (O=64, C=3, 7x7)
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= 7 * 7 * 3 * 64) return;
@@ -589,11 +589,11 @@ __global__ void repack_stem_kernel(const float* __restrict__ src, float* __restr
     const int c = r % 3;
     r /= 3;
     const int kx = r % 7, ky = r / 7;
-    dst[d] = src[((o * 3 + c) * 7 + ky) * 7 + kx];
+    dst[d] = src[((o * 3 + (reverse_c ? 2 - c : c)) * 7 + ky) * 7 + kx];
 }
 
-hipError_t launch_repack_stem(const float* src, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(repack_stem_kernel, dim3((7 * 7 * 3 * 64 + 255) / 256), dim3(256), 0, s, src, dst);
+hipError_t launch_repack_stem(const float* src, float* dst, int reverse_c, hipStream_t s) {
+    hipLaunchKernelGGL(repack_stem_kernel, dim3((7 * 7 * 3 * 64 + 255) / 256), dim3(256), 0, s, src, dst, reverse_c);
     return hipGetLastError();
 }
 

@@ -39,6 +39,7 @@ __device__ __forceinline__ void tile_coords(const WinoGeom& g, int t, int& ry, i
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4w __attribute__((ext_vector_type(4)));
+typedef float f32x1 __attribute__((ext_vector_type(1)));
 
 // 1-D transforms on strided arrays of vectors (all loops unrolled; S = element stride)
 template <int MT, int S, int SO = S, typename V>
@@ -282,18 +283,21 @@ static unsigned grid_for(size_t work) {
     return (unsigned)blocks;
 }
 
-// test/measurement hook: INFUR_WINO_VEC=2 forces the 8-byte form
-static bool wino_vec4(int C) {
+// test/measurement hook: INFUR_WINO_VEC=2 forces the 8-byte form, INFUR_WINO_VEC=1 the 4-byte form of F(6x6)
+static int wino_forced() {
     static const int forced = getenv("INFUR_WINO_VEC") ? atoi(getenv("INFUR_WINO_VEC")) : 0;
-    return (C & 3) == 0 && forced != 2;
+    return forced;
 }
+static bool wino_vec4(int C) { return (C & 3) == 0 && wino_forced() != 2; }
 
 hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, unsigned* amax, hipStream_t s) {
     const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
     const bool v4 = wino_vec4(C) && mt != 6;  // F(6x6): 64 patch vectors per thread -- 8-byte vectors keep them in registers
     const unsigned blocks = grid_for((size_t)T * (C / (v4 ? 4 : 2)));
-    if (mt == 6)
+    if (mt == 6 && wino_forced() == 1)
+        hipLaunchKernelGGL((wino_input_kernel<6, f32x1>), dim3(grid_for((size_t)T * C)), dim3(256), 0, s, in, g, C, T, V, amax);
+    else if (mt == 6)
         hipLaunchKernelGGL((wino_input_kernel<6, f32x2>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
     else if (mt == 2 && v4)
         hipLaunchKernelGGL((wino_input_kernel<2, f32x4w>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
@@ -312,7 +316,9 @@ hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int
     const int T = d * d * g.TY * g.TX;
     const bool v4 = wino_vec4(Cout) && mt != 6;
     const unsigned blocks = grid_for((size_t)T * (Cout / (v4 ? 4 : 2)));
-    if (mt == 6)
+    if (mt == 6 && wino_forced() == 1)
+        hipLaunchKernelGGL((wino_output_kernel<6, f32x1>), dim3(grid_for((size_t)T * Cout)), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
+    else if (mt == 6)
         hipLaunchKernelGGL((wino_output_kernel<6, f32x2>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
     else if (mt == 2 && v4)
         hipLaunchKernelGGL((wino_output_kernel<2, f32x4w>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);

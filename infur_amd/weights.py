@@ -16,7 +16,9 @@ oracle (oracle/infur_oracle.py):
     12  u32      num_classes
     16  u32      has_aux
     20  u32      n_convs
-    24  u32[2]   reserved
+    24  u32      input kind: 0 = Float image input (RGB planes, torchvision normalisation: predict_onnx.rs:126-137),
+                 1 = Uint8 image input (the frame's bytes as they are, BGR kept: predict_onnx.rs:116-122,296-301)
+    28  u32      reserved
     32  n_convs x 80-byte entries: char name[40]; u32 cout, cin, kh, kw;
                  u64 w_off; u64 b_off; u8 reserved[8]
     ... f32 data, 64-byte aligned: weights OIHW (BN already folded), bias [cout]
@@ -207,7 +209,7 @@ def synth_tensors(
         yield c, w.astype(np.float32), b.astype(np.float32)
 
 
-def pack_blob(tensors, depth: int, num_classes: int, aux: bool) -> bytes:
+def pack_blob(tensors, depth: int, num_classes: int, aux: bool, input_u8: bool = False) -> bytes:
     """Serialise (spec-or-name, W OIHW f32, b f32) triples into the INFURW01 blob."""
     items = []
     for spec, w, b in tensors:
@@ -232,7 +234,7 @@ def pack_blob(tensors, depth: int, num_classes: int, aux: bool) -> bytes:
         table += struct.pack("<4I2Q8x", w.shape[0], w.shape[1], w.shape[2], w.shape[3], w_off, b_off)
         chunks.append((w_off, w, b_off, b))
     buf = bytearray(off)
-    buf[0:HDR] = MAGIC + struct.pack("<6I", depth, num_classes, 1 if aux else 0, n, 0, 0)
+    buf[0:HDR] = MAGIC + struct.pack("<6I", depth, num_classes, 1 if aux else 0, n, 1 if input_u8 else 0, 0)
     buf[HDR : HDR + len(table)] = table
     for w_off, w, b_off, b in chunks:
         buf[w_off : w_off + w.nbytes] = w.tobytes()
@@ -240,15 +242,21 @@ def pack_blob(tensors, depth: int, num_classes: int, aux: bool) -> bytes:
     return bytes(buf)
 
 
-def synth_blob(depth: int = 50, num_classes: int = NUM_CLASSES, aux: bool = True, seed: int = DEFAULT_SEED) -> bytes:
-    return pack_blob(synth_tensors(depth, num_classes, aux, seed), depth, num_classes, aux)
+def synth_blob(depth: int = 50, num_classes: int = NUM_CLASSES, aux: bool = True, seed: int = DEFAULT_SEED,
+               input_u8: bool = False) -> bytes:
+    """``input_u8``: a model that declares a Uint8 image input -- the stem sees the raw BGR bytes (0..255), so its
+    synthetic weights are scaled by 1/64 to keep the activations in the range the Float-input model has."""
+    if not input_u8:
+        return pack_blob(synth_tensors(depth, num_classes, aux, seed), depth, num_classes, aux)
+    ts = [(c, w * np.float32(1.0 / 64.0) if c.name == "backbone.conv1" else w, b) for c, w, b in synth_tensors(depth, num_classes, aux, seed)]
+    return pack_blob(ts, depth, num_classes, aux, input_u8=True)
 
 
 def unpack_blob(blob: bytes):
     """Parse a blob -> (meta dict, [(name, W OIHW f32 view, b f32 view), ...])."""
     if len(blob) < HDR or blob[:8] != MAGIC:
         raise ValueError("not an INFURW01 weight blob")
-    depth, ncls, aux, n, _, _ = struct.unpack_from("<6I", blob, 8)
+    depth, ncls, aux, n, kind, _ = struct.unpack_from("<6I", blob, 8)
     out = []
     for i in range(n):
         e = HDR + i * ENTRY
@@ -257,4 +265,4 @@ def unpack_blob(blob: bytes):
         w = np.frombuffer(blob, dtype=np.float32, count=cout * cin * kh * kw, offset=w_off).reshape(cout, cin, kh, kw)
         b = np.frombuffer(blob, dtype=np.float32, count=cout, offset=b_off)
         out.append((name, w, b))
-    return {"depth": depth, "num_classes": ncls, "aux": bool(aux), "n_convs": n}, out
+    return {"depth": depth, "num_classes": ncls, "aux": bool(aux), "n_convs": n, "input_u8": kind == 1}, out

@@ -189,6 +189,18 @@ void oracle_pack_normalize(const uint8_t* bgr, uint32_t w, uint32_t h, float* ch
     }
 }
 
+/* predict_onnx.rs:114-122, the ColorRange::Uint8 arm (a model that declares a Uint8 image input, :255): the session
+ * gets the frame's bytes themselves -- color_seq stays BGR (:296-301), no scaling, no normalisation.  What such a
+ * model's first convolution then sees, as the channel-planar f32 tensor this oracle's forward takes:
+ * plane c = input byte c (0 = B), value = the byte. */
+void oracle_pack_u8(const uint8_t* bgr, uint32_t w, uint32_t h, float* chw) {
+    size_t hw = (size_t)w * h;
+    for (int c = 0; c < 3; c++) {
+        float* dst = chw + c * hw;
+        for (size_t i = 0; i < hw; i++) dst[i] = (float)bgr[3 * i + c];
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* ColorCode  (infur/src/decode_predict.rs:9-79)                              */
 /* ------------------------------------------------------------------------- */
@@ -312,6 +324,7 @@ typedef struct {
 
 struct oracle_model {
     uint32_t depth, num_classes, has_aux, n_convs;
+    uint32_t input_u8; /* blob header offset 24: 1 = the model declares a Uint8 image input */
     oconv* convs;
     void* blob_copy;
 };
@@ -341,6 +354,7 @@ int oracle_model_load(const void* blob, size_t len, oracle_model** out) {
     m->num_classes = rd_u32(p + 12);
     m->has_aux = rd_u32(p + 16);
     m->n_convs = rd_u32(p + 20);
+    m->input_u8 = rd_u32(p + 24);
     int lb[4];
     if (layer_blocks(m->depth, lb) != 0 || (size_t)BLOB_HDR + (size_t)m->n_convs * BLOB_ENTRY > len) {
         free(m);
@@ -649,7 +663,10 @@ int oracle_frame_advance(const oracle_model* m, const uint8_t* bgr, uint32_t w, 
         return rc;
     }
     float* chw = (float*)malloc(sizeof(float) * 3 * (size_t)nw * nh);
-    oracle_pack_normalize(scaled, nw, nh, chw);
+    if (m->input_u8)
+        oracle_pack_u8(scaled, nw, nh, chw);
+    else
+        oracle_pack_normalize(scaled, nw, nh, chw);
     float* logits = (float*)malloc(sizeof(float) * (size_t)m->num_classes * nw * nh);
     rc = oracle_model_forward(m, chw, nh, nw, logits, NULL, NULL, NULL);
     if (!rc) oracle_colorcode(logits, m->num_classes, nh, nw, rgba);

@@ -52,6 +52,8 @@ int oracle_scale(const uint8_t* bgr, uint32_t w, uint32_t h, float factor, int m
 void oracle_preproc_lut(float* lut /*768*/);
 /* packed BGR u8 HWC -> planar RGB f32 CHW, torchvision normalisation */
 void oracle_pack_normalize(const uint8_t* bgr, uint32_t w, uint32_t h, float* chw);
+/* predict_onnx.rs:114-122: what a Uint8-input model is fed -- BGR kept, bytes as they are (as planar f32) */
+void oracle_pack_u8(const uint8_t* bgr, uint32_t w, uint32_t h, float* chw);
 
 /* ---- ColorCode (infur/src/decode_predict.rs:9-79) ---- */
 void oracle_palette(uint8_t* rgb /*60*/);

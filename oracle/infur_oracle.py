@@ -60,6 +60,7 @@ class COracle:
         L.oracle_scale.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, _u8p, _u32p, _u32p]
         L.oracle_preproc_lut.argtypes = [_f32p]
         L.oracle_pack_normalize.argtypes = [_u8p, C.c_uint32, C.c_uint32, _f32p]
+        L.oracle_pack_u8.argtypes = [_u8p, C.c_uint32, C.c_uint32, _f32p]
         L.oracle_palette.argtypes = [_u8p]
         L.oracle_color32_from_rgba_unmultiplied.argtypes = [C.c_uint8] * 4 + [_u8p]
         L.oracle_color_code.argtypes = [C.c_size_t, C.c_float, _u8p]
@@ -73,7 +74,7 @@ class COracle:
         L.oracle_upsample_bilinear.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, _f32p, C.c_uint32, C.c_uint32]
         L.oracle_frame_advance.argtypes = [C.c_void_p, _u8p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, _u8p, _u32p, _u32p]
         L.oracle_set_threads.argtypes = [C.c_int]
-        for f in ("oracle_preproc_lut", "oracle_pack_normalize", "oracle_palette", "oracle_color32_from_rgba_unmultiplied",
+        for f in ("oracle_preproc_lut", "oracle_pack_normalize", "oracle_pack_u8", "oracle_palette", "oracle_color32_from_rgba_unmultiplied",
                   "oracle_color_code", "oracle_colorcode", "oracle_argmax", "oracle_model_free", "oracle_model_lowres_dims",
                   "oracle_upsample_bilinear", "oracle_set_threads"):
             getattr(L, f).restype = None
@@ -115,6 +116,14 @@ class COracle:
         out = np.empty((3, h, w), np.float32)
         src = np.ascontiguousarray(bgr)
         self.L.oracle_pack_normalize(_p(src, _u8p), w, h, _p(out, _f32p))
+        return out
+
+    def pack_u8(self, bgr: np.ndarray) -> np.ndarray:
+        """The input of a Uint8-input model (predict_onnx.rs:114-122): planes B, G, R holding the bytes."""
+        h, w = bgr.shape[:2]
+        out = np.empty((3, h, w), np.float32)
+        src = np.ascontiguousarray(bgr)
+        self.L.oracle_pack_u8(_p(src, _u8p), w, h, _p(out, _f32p))
         return out
 
     # ---- ColorCode ----

@@ -89,3 +89,14 @@ def exported50():
 
     m, folded = tv_fcn.synth_fcn(50)
     return m, folded, tv_fcn.export_onnx(m)
+
+
+@pytest.fixture(scope="session")
+def exported50_u8():
+    """The same network behind a Uint8 NHWC image input (tests/tv_fcn.py::Uint8Front), exported by PyTorch's exporter:
+    -> (module taking [1,H,W,3] u8, folded reference tensors, ModelProto bytes)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tv_fcn
+
+    m, folded = tv_fcn.synth_fcn_u8(50)
+    return m, folded, tv_fcn.export_onnx(m)

@@ -103,13 +103,16 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
               input_type=1, input_dims=("N", 3, "H", "W"), conv_op="Conv", drop_last=0, rng=None,
               order="topo", dropout=False, identities=False, resize_subgraph=True, resize_mode="linear",
               coord_mode="pytorch_half_pixel", swap_outputs=False, external=None, missing_relu=None, opset=12,
-              const_nodes=False, extra_conv=False):
+              const_nodes=False, extra_conv=False, front=()):
     """A torchvision-shaped fcn_resnet ModelProto: stem -> Relu -> MaxPool -> bottlenecks (conv1/conv2/conv3 [+ downsample],
     Add, Relu) -> classifier (Conv, Relu, [Dropout], Conv, Resize) and the aux head off layer3, as torch.onnx.export
     writes it (dynamic H/W: Shape -> Gather -> Unsqueeze -> Concat feeding Resize's `sizes`).
 
     tensors: [(name, W OIHW f32, b f32)] in INFURW01 order; specs: infur_amd.weights.graph(...).
     unfold_bn: Conv(no bias) + BatchNormalization whose folding reproduces (W, b).
+    front: nodes between the image input and the stem, in order -- "cast" (Cast to FLOAT), "cast_double" (Cast to DOUBLE),
+           "transpose" (perm 0,3,1,2), "transpose_bad" (perm 0,2,3,1), "mul" (an in-graph scaling) -- what a Uint8 and / or
+           NHWC input carries (predict_onnx.rs:116-122).
     order: "topo" (export order) | "ds_first" (every downsample conv serialised BEFORE its block's conv1..conv3) |
            "shuffled" (random node order: slot assignment must come from the edges, not from positions).
     """
@@ -177,7 +180,24 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
         return passthrough(o)
 
     # ---- backbone ----
-    x = relu(conv("backbone.conv1", "input"), "stem")
+    x = "input"
+    for kind in front:
+        o = fresh("front")
+        if kind == "cast":
+            emit("Cast", [x], [o], [attr_int("to", 1)])
+        elif kind == "cast_double":
+            emit("Cast", [x], [o], [attr_int("to", 11)])
+        elif kind == "transpose":
+            emit("Transpose", [x], [o], [attr_ints("perm", [0, 3, 1, 2])])
+        elif kind == "transpose_bad":
+            emit("Transpose", [x], [o], [attr_ints("perm", [0, 2, 3, 1])])
+        elif kind == "mul":
+            inits.append(tensor("front.scale", np.asarray([1.0 / 255.0], np.float32)))
+            emit("Mul", [x, "front.scale"], [o])
+        else:
+            raise ValueError(kind)
+        x = o
+    x = relu(conv("backbone.conv1", x), "stem")
     o = fresh("pool")
     emit("MaxPool", [x], [o], [attr_ints("kernel_shape", [3, 3]), attr_ints("pads", [1, 1, 1, 1]), attr_ints("strides", [2, 2]),
                                 attr_int("ceil_mode", 0)])

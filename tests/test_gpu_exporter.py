@@ -69,3 +69,78 @@ def test_exported_file_through_hip_matches_torch_modules(exported50, onnx_path, 
     stable = decided & (alpha(cmax - e) == alpha(cmax + e))
     assert stable.mean() > (0.5 if dtype in ("f16", "f32x") else 0.8)  # (f16: 1e-3 of error is half an alpha step)
     assert (rgba[stable] == ref_rgba[stable]).all()
+
+
+@pytest.fixture(scope="module")
+def onnx_path_u8(exported50_u8, tmp_path_factory):
+    p = tmp_path_factory.mktemp("exported_u8") / "fcn-resnet50-u8-nhwc.onnx"
+    p.write_bytes(exported50_u8[2])
+    return str(p)
+
+
+@pytest.mark.parametrize("dtype,wh", [("f32", (320, 240)), ("f32", (161, 97)), ("f32s", (320, 240)), ("f16", (320, 240)), ("f32", (1280, 720))])
+def test_uint8_nhwc_model_through_hip_matches_torch_modules(exported50_u8, onnx_path_u8, dtype, wh):
+    """A model that declares a Uint8 NHWC image input (predict_onnx.rs:255,296-301): the reference hands its session the
+    frame's bytes, BGR kept, no normalisation (:114-122).  Exported by PyTorch's exporter, loaded through ModelCmd::Load,
+    run by the HIP path (identity table in the stem, stem weights stored with the channel axis reversed) and compared with
+    the module evaluated on the same u8 frame on the CPU."""
+    import torch
+
+    m = exported50_u8[0]
+    w, h = wh
+    frame = W.synth_frame(h, w, index=13)
+    with torch.no_grad():
+        r = m(torch.from_numpy(frame)[None])
+    want_out, want_aux = r["out"][0].numpy(), r["aux"][0].numpy()
+    with Context(device=0, dtype=dtype) as c:
+        model = Model(c).control(ModelCmd.Load(onnx_path_u8))
+        info = model.get_info()
+        assert info.input_names == ["input"] and info.input0_dtype == "Uint8" and info.output_names == ["out", "aux"]
+        got = []
+        model.advance(frame, got)
+    for g, rr, name in ((got[0], want_out, "out"), (got[1], want_aux, "aux")):
+        err = np.abs(g - rr).max() / np.abs(rr).max()
+        print(f"u8 model {dtype} {w}x{h} {name}: rel err vs torch module graph {err:.2e}")
+        assert err < REL_TOL[dtype], (name, err)
+    top2 = np.sort(want_out, axis=0)[-2:]
+    decided = (top2[1] - top2[0]) > REL_TOL[dtype] * np.abs(want_out).max()
+    assert decided.mean() > 0.9
+    assert (got[0].argmax(0)[decided] == want_out.argmax(0)[decided]).all()
+
+
+def test_uint8_blob_whole_path_and_group_replication(oracle):
+    """INFURW01 blob with input kind 1 (Uint8): the fused frame path against the whole-path C oracle (which feeds the model
+    oracle_pack_u8 for such a blob), a Float model loaded afterwards on the same context switches the stem table back,
+    and infur_group_weights_broadcast carries the input kind to the other contexts."""
+    from infur_amd.processors import Group
+    from oracle.infur_oracle import COracle
+
+    blob8 = W.synth_blob(input_u8=True)
+    frame = W.synth_frame(96, 128, index=21)
+    co = COracle()
+    assert co.model_load(blob8) == 0
+    ref = co.model_forward(co.pack_u8(frame), full=False)
+    a, b = Context(device=0), Context(device=0)
+    ma = Model(a).control(ModelCmd.LoadBlob(blob8))
+    assert ma.get_info().input0_dtype == "Uint8"
+    rgba, _ = FramePath(a).advance(frame, 1.0)
+    lo, _ = ma.lowres()
+    assert np.abs(lo - ref["out_low"]).max() / np.abs(ref["out_low"]).max() < 1e-3
+    assert (rgba == oracle.colorcode(oracle.upsample_bilinear(lo, 96, 128))).all()
+    with Group([a, b]) as g:
+        g.weights_broadcast(0)
+    mb = Model(b)
+    assert mb.get_info().input0_dtype == "Uint8"
+    rgba_b, _ = FramePath(b).advance(frame, 1.0)
+    assert (rgba_b == rgba).all()
+    # back to a Float model on the same context: normalised RGB planes again
+    blob = W.synth_blob()
+    ma.control(ModelCmd.LoadBlob(blob))
+    assert ma.get_info().input0_dtype == "Float"
+    assert co.model_load(blob) == 0
+    ref = co.model_forward(co.pack_normalize(frame), full=False)
+    FramePath(a).advance(frame, 1.0)
+    lo, _ = ma.lowres()
+    assert np.abs(lo - ref["out_low"]).max() / np.abs(ref["out_low"]).max() < 1e-3
+    a.close()
+    b.close()

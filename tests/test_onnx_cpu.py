@@ -36,7 +36,7 @@ def test_folded_model_roundtrips_bit_exact(lib, blob50, tensors50, raw, packed, 
     rc, err, out = convert(lib, model)
     assert rc == 0, err
     meta, got = W.unpack_blob(out)
-    assert meta == {"depth": 50, "num_classes": 21, "aux": True, "n_convs": 57}
+    assert meta == {"depth": 50, "num_classes": 21, "aux": True, "n_convs": 57, "input_u8": False}
     for (n0, w0, b0), (n1, w1, b1) in zip(tensors50, got):
         assert n0 == n1 and (w0.view(np.uint32) == w1.view(np.uint32)).all() and (b0.view(np.uint32) == b1.view(np.uint32)).all()
 
@@ -66,8 +66,13 @@ def test_input_checks_carry_the_reference_messages(lib, tensors50):
         (dict(input_dims=(3, "H", "W")), "only 4 dimensions supported got 3"),
         (dict(input_dims=("N", "H", 3, "W")), "color dimension only at NCHW or NHWC but not in position 2 supported"),
         (dict(input_type=7), "only Float (f32) and Uint8 (u8) input supported"),
-        (dict(input_type=2), "NCHW Float segmentation models only"),          # u8 models: valid for the reference, not here
-        (dict(input_dims=("N", "H", "W", 3)), "NCHW Float segmentation models only"),
+        # Uint8 / NHWC inputs are valid for the reference (and load: test_uint8_and_nhwc_inputs); the graph must carry them
+        (dict(input_type=2), "a Uint8 image input must reach the stem convolution through one Cast to FLOAT"),
+        (dict(input_type=2, front=("cast_double",)), "must produce FLOAT"),
+        (dict(input_type=2, front=("cast", "mul")), "expected exactly one Conv after the image input"),
+        (dict(input_dims=("N", "H", "W", 3)), "an NHWC image input must reach the stem convolution through one Transpose"),
+        (dict(input_dims=("N", "H", "W", 3), front=("transpose_bad",)), "perm = [0,3,1,2]"),
+        (dict(front=("cast",)), "expected exactly one Conv after the image input"),   # a Float input needs no Cast
         (dict(conv_op="QLinearConv"), "quantised model"),                        # the int8 zoo file of infur-test-gen
         (dict(drop_last=3), "Conv nodes"),
     ]
@@ -77,6 +82,26 @@ def test_input_checks_carry_the_reference_messages(lib, tensors50):
         assert rc == _lib.E_MODEL_FORMAT and msg in err, (kw, err)
     rc, err, _ = convert(lib, b"\x08\x06garbage")
     assert rc == _lib.E_MODEL_FORMAT
+
+
+@pytest.mark.parametrize("kw,u8", [
+    (dict(input_type=2, front=("cast",)), True),                                                   # Uint8 NCHW
+    (dict(input_type=2, input_dims=("N", "H", "W", 3), front=("transpose", "cast")), True),         # Uint8 NHWC
+    (dict(input_type=2, input_dims=("N", "H", "W", 3), front=("cast", "transpose")), True),         # ... Cast first
+    (dict(input_dims=("N", "H", "W", 3), front=("transpose",)), False),                             # Float NHWC
+    (dict(input_type=2, input_dims=(1, 240, 320, 3), front=("transpose", "cast"), identities=True, order="shuffled"), True),
+])
+def test_uint8_and_nhwc_inputs(lib, tensors50, kw, u8):
+    """infer_img_pre_proc accepts NCHW / NHWC x Float / Uint8 (predict_onnx.rs:223-265).  The layout is the file's own
+    business (a Transpose in front of the stem); the element type decides what the session is fed -- normalised RGB
+    floats or the frame's BGR bytes (predict_onnx.rs:114-139) -- and travels in the blob header."""
+    model, _ = OW.fcn_model(tensors50, W.graph(50), **kw)
+    rc, err, out = convert(lib, model)
+    assert rc == 0, err
+    meta, got = W.unpack_blob(out)
+    assert meta == {"depth": 50, "num_classes": 21, "aux": True, "n_convs": 57, "input_u8": u8}
+    for (n0, w0, b0), (n1, w1, b1) in zip(tensors50, got):
+        assert n0 == n1 and (w0.view(np.uint32) == w1.view(np.uint32)).all() and (b0.view(np.uint32) == b1.view(np.uint32)).all()
 
 
 def test_wrong_conv_attributes_are_rejected(lib, tensors50):
@@ -131,7 +156,7 @@ def test_model_without_aux_head_and_resnet101_shape(lib):
     model, _ = OW.fcn_model(t, W.graph(50, aux=False), order="shuffled")
     rc, err, out = convert(lib, model)
     assert rc == 0, err
-    assert W.unpack_blob(out)[0] == {"depth": 50, "num_classes": 21, "aux": False, "n_convs": 55}
+    assert W.unpack_blob(out)[0] == {"depth": 50, "num_classes": 21, "aux": False, "n_convs": 55, "input_u8": False}
 
 
 def test_graphs_that_are_not_fcn_resnet_are_rejected(lib, tensors50):

@@ -51,7 +51,7 @@ def test_reader_accepts_real_exporter_output(lib, exported50, blob50):
     rc, err, out = convert(lib, onnx)
     assert rc == 0, err
     meta, got = W.unpack_blob(out)
-    assert meta == {"depth": 50, "num_classes": 21, "aux": True, "n_convs": 57}
+    assert meta == {"depth": 50, "num_classes": 21, "aux": True, "n_convs": 57, "input_u8": False}
     assert_folded(got, folded)
     # same PRNG streams as synth_blob: the module's folded parameters are the blob every other test runs on
     assert_folded(got, [(s, w, b) for s, (_, w, b) in zip(W.graph(50), W.unpack_blob(blob50)[1])])
@@ -66,7 +66,7 @@ def test_reader_on_exporter_variants(lib, depth, aux, dynamic):
     rc, err, out = convert(lib, tv_fcn.export_onnx(m, h=48, w=64, dynamic=dynamic))
     assert rc == 0, err
     meta, got = W.unpack_blob(out)
-    assert meta == {"depth": depth, "num_classes": 21, "aux": aux, "n_convs": len(folded)}
+    assert meta == {"depth": depth, "num_classes": 21, "aux": aux, "n_convs": len(folded), "input_u8": False}
     assert_folded(got, folded)
 
 
@@ -98,3 +98,34 @@ def test_oracle_matches_torch_module_graph(lib, oracle, exported50, wh):
     top2 = np.sort(want["out"], axis=0)[-2:]
     decided = (top2[1] - top2[0]) > 1e-4 * np.abs(want["out"]).max()
     assert decided.mean() > 0.95 and (ref["out"].argmax(0)[decided] == want["out"].argmax(0)[decided]).all()
+
+
+def test_uint8_nhwc_model_from_the_exporter(lib, oracle, exported50_u8):
+    """A model with a Uint8 NHWC image input, written by PyTorch's exporter (Transpose + Cast in front of the stem): the
+    reader accepts it and marks the blob; the oracle fed as the reference feeds such a model (predict_onnx.rs:114-122: the
+    frame's bytes, BGR kept, no normalisation -> oracle_pack_u8) agrees with the module evaluated on the frame itself."""
+    import torch
+
+    from oracle.infur_oracle import COracle, TorchModel
+
+    m, folded, onnx = exported50_u8
+    rc, err, blob = convert(lib, onnx)
+    assert rc == 0, err
+    meta, got = W.unpack_blob(blob)
+    assert meta == {"depth": 50, "num_classes": 21, "aux": True, "n_convs": 57, "input_u8": True}
+    assert_folded(got, folded)
+    assert_folded(got, [(s, w, b) for s, (_, w, b) in zip(W.graph(50), W.unpack_blob(W.synth_blob(input_u8=True))[1])])
+    frame = W.synth_frame(97, 161, index=6)
+    with torch.no_grad():
+        want = m(torch.from_numpy(frame)[None])
+    want = {k: v[0].numpy() for k, v in want.items()}
+    chw = oracle.pack_u8(frame)
+    assert (chw[0] == frame[..., 0]).all() and (chw[2] == frame[..., 2]).all()  # plane 0 = B: BGR kept
+    co = COracle()
+    assert co.model_load(blob) == 0
+    ref = co.model_forward(chw, full=True, low=False)
+    t_out, t_aux = TorchModel(blob).forward(chw)
+    for name, got_c, got_t in (("out", ref["out"], t_out), ("aux", ref["aux"], t_aux)):
+        scale = np.abs(want[name]).max()
+        assert np.abs(got_c - want[name]).max() / scale < 2e-5, name
+        assert np.abs(got_t - want[name]).max() / scale < 2e-5, name

@@ -139,6 +139,30 @@ def synth_fcn(depth=50, num_classes=21, aux=True, seed=W.DEFAULT_SEED):
     return m.eval(), folded
 
 
+class Uint8Front(nn.Module):
+    """A model that declares a Uint8 NHWC image input -- the reference then hands the session the frame's bytes as they
+    are, BGR kept (predict_onnx.rs:116-122,255,296-301): [N, H, W, 3] u8 -> permute -> float -> the FCN.  The exporter writes
+    the front as Transpose(perm = 0,3,1,2) + Cast(to = FLOAT)."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+        self.aux_classifier = m.aux_classifier
+
+    def forward(self, x):
+        return self.m(x.permute(0, 3, 1, 2).to(torch.float32))
+
+
+def synth_fcn_u8(depth=50, num_classes=21, aux=True, seed=W.DEFAULT_SEED):
+    """synth_fcn behind a Uint8 NHWC front.  The stem sees 0..255 instead of normalised values, so its weights are scaled
+    by 1/64 (as infur_amd.weights.synth_blob(input_u8=True) does): -> (module, folded tensors)."""
+    m, folded = synth_fcn(depth, num_classes, aux, seed)
+    with torch.no_grad():
+        m.backbone.conv1.weight.mul_(1.0 / 64.0)
+    folded = [(c, w * np.float32(1.0 / 64.0) if c.name == "backbone.conv1" else w, b) for c, w, b in folded]
+    return Uint8Front(m).eval(), folded
+
+
 class _TwoOutputs(nn.Module):  # the exporter flattens the OrderedDict the same way; this only fixes the output order
     def __init__(self, m):
         super().__init__()
@@ -157,7 +181,11 @@ def export_onnx(model, h=64, w=64, opset=12, dynamic=True) -> bytes:
     from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
 
     names = ["out", "aux"] if model.aux_classifier is not None else ["out"]
-    axes = {n: {0: "batch", 2: "height", 3: "width"} for n in ["input"] + names} if dynamic else None
+    u8 = isinstance(model, Uint8Front)
+    axes = {n: {0: "batch", 2: "height", 3: "width"} for n in names} if dynamic else None
+    if dynamic:
+        axes["input"] = {0: "batch", 1: "height", 2: "width"} if u8 else {0: "batch", 2: "height", 3: "width"}
+    example = torch.zeros(1, h, w, 3, dtype=torch.uint8) if u8 else torch.zeros(1, 3, h, w)
     keep = onnx_proto_utils._add_onnxscript_fn
     # the hook splices onnxscript functions into the proto through the `onnx` package; there are none in this model
     onnx_proto_utils._add_onnxscript_fn = lambda proto, custom_opsets: proto
@@ -167,7 +195,7 @@ def export_onnx(model, h=64, w=64, opset=12, dynamic=True) -> bytes:
             warnings.simplefilter("ignore")
             # (.eval(): the exporter restores the wrapper's mode afterwards -- recursively; a wrapper left in training mode would
             #  switch `model` to training and its next forward would update the BatchNorm statistics)
-            torch.onnx.export(_TwoOutputs(model).eval(), (torch.zeros(1, 3, h, w),), f, opset_version=opset, dynamo=False, input_names=["input"],
+            torch.onnx.export(_TwoOutputs(model).eval(), (example,), f, opset_version=opset, dynamo=False, input_names=["input"],
                               output_names=names, dynamic_axes=axes, do_constant_folding=True)
         assert not model.training
         return f.getvalue()
