@@ -283,7 +283,11 @@ static unsigned grid_for(size_t work) {
     return (unsigned)blocks;
 }
 
-// test/measurement hook: INFUR_WINO_VEC=2 forces the 8-byte form, INFUR_WINO_VEC=1 the 4-byte form of F(6x6)
+// test/measurement hook: INFUR_WINO_VEC=2 forces the 8-byte form, INFUR_WINO_VEC=1 the 4-byte form of F(6x6).
+// The 4-byte form needs 122 / 118 VGPRs instead of 162 / 210, so a transform wave fits on a SIMD next to the waves of
+// an f32 GEMM workgroup of the other frame in flight -- measured (scripts/ab_wino_vec.sh, same box, back to back): the
+// transforms alone run at the same speed (0.49 + 0.35 ms vs 0.51 + 0.36 ms per 1080p frame) and the two-frames-in-flight
+// rate does not move (f32 102.6 vs 102.9, f32s 205.0 vs 204.8 frames/s): co-residency is not what limits the overlap.
 static int wino_forced() {
     static const int forced = getenv("INFUR_WINO_VEC") ? atoi(getenv("INFUR_WINO_VEC")) : 0;
     return forced;
