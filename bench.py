@@ -498,6 +498,10 @@ def main():
         if world == 1 and default_workload and not a.no_side:
             out["configs2_stream_scale05"] = stream_scale05_rate(a, dev, blob, frames_np)
             out["configs4_r101_f16_4k"] = r101_f16_4k_rate(a, dev)
+            try:  # a side measurement must never cost the line its headline
+                out["configs3_batch64_group"] = group_batch64_rate(a, blob)
+            except Exception as e:  # noqa: BLE001
+                out["configs3_batch64_group"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, frames_np[0], a.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -656,6 +660,49 @@ def r101_f16_4k_rate(a, dev):
                          "frac": gflop * fps / 1e3 / PEAK_F16_MFMA_TFLOPS},
             "parity": "per-layer and whole-frame logits vs the f32 oracle at 5e-3 (tests/test_gpu_f16_r101.py); a "
                       "reduced-precision mode by definition, never the headline"}
+
+
+def group_batch64_rate(a, blob):
+    """BASELINE configs[3] through the C ABI's group calls, as a Rust host would run it (one process, one context per
+    GPU): 64 distinct 1080p frames in HOST memory, `infur_group_weights_broadcast` (RCCL across
+    distinct devices, device-to-device copies between contexts of one device), then `infur_group_batch_advance` -- a
+    contiguous slice of the batch per context, one worker thread each, masks back in frame order, PCIe inclusive.
+    Eight contexts over the GPUs this process can see (device i % n_visible): on the 1-GPU box all eight share the one
+    GPU, so this is the code path of configs[3] and its single-GPU rate, not a scaling figure -- the line says which."""
+    import torch
+
+    from infur_amd import weights as W
+    from infur_amd.processors import Context, FramePath, Group, Model, ModelCmd
+
+    ndev = max(1, torch.cuda.device_count())
+    n_ctx, n_frames = 8, 64
+    ctxs = [Context(device=i % ndev, compute_aux=not a.no_aux) for i in range(n_ctx)]
+    try:
+        t0 = time.perf_counter()
+        Model(ctxs[0]).control(ModelCmd.LoadBlob(blob))
+        t1 = time.perf_counter()
+        with Group(ctxs) as g:
+            g.weights_broadcast(0)
+            t2 = time.perf_counter()
+            frames = [W.synth_frame(a.height, a.width, index=1000 + i) for i in range(n_frames)]
+            g.advance_batch(frames[:2 * n_ctx], 1.0)  # arenas and tile configurations of every context
+            t3 = time.perf_counter()
+            masks = g.advance_batch(frames, 1.0)
+            dt = time.perf_counter() - t3
+            uses_rccl = g.uses_rccl
+        # frame order and replica agreement: a frame from the middle of another context's slice, recomputed on context 0
+        k = 5 * (n_frames // n_ctx) + 3
+        solo, _ = FramePath(ctxs[0]).advance(frames[k], 1.0)
+        ok = bool((solo == masks[k]).all()) and len(masks) == n_frames
+    finally:
+        for c in ctxs:
+            c.close()
+    return {"value": n_frames / dt, "unit": "frames/s", "dtype": "f32", "frames": n_frames, "contexts": n_ctx, "devices": min(ndev, n_ctx),
+            "rccl_broadcast": bool(uses_rccl), "weights_load_ms": round((t1 - t0) * 1e3, 2), "weights_broadcast_ms": round((t2 - t1) * 1e3, 2),
+            "masks_in_frame_order_and_equal_to_one_context": ok,
+            "workload": f"64 x {a.width}x{a.height} frames from host memory, infur_group_batch_advance over {n_ctx} contexts on "
+                        f"{min(ndev, n_ctx)} visible GPU(s), slices of {n_frames // n_ctx} frames, masks to host (PCIe inclusive)",
+            "note": "with one visible GPU the eight contexts share it: the path of BASELINE configs[3], not its scaling"}
 
 
 def idims(ctx, w, h, factor):

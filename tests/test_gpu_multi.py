@@ -284,3 +284,28 @@ def test_bench_rccl_branch_executes_on_one_rank(tmp_path):
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["backend"] == "nccl"
     assert j["config"]["weights_bcast_ms"] > 0 and j["config"]["ranks_agree_on_frame0_mask"] is True
+
+
+def test_configs3_batch64_through_the_group_on_one_gpu(blob50):
+    """BASELINE configs[3] at full size in one process: 64 distinct 1080p frames, eight contexts (here all on device 0;
+    one per GPU on an 8-GPU node), weights loaded once and replicated by infur_group_weights_broadcast, the batch split
+    into eight contiguous slices by infur_group_batch_advance.  Every mask comes back, in frame order, and equals what a
+    single context computes for that frame (checked on one frame of each slice)."""
+    n_ctx, n = 8, 64
+    frames = [W.synth_frame(1080, 1920, index=500 + i) for i in range(n)]
+    ctxs = [Context(device=0) for _ in range(n_ctx)]
+    try:
+        Model(ctxs[0]).control(ModelCmd.LoadBlob(blob50))
+        with Group(ctxs) as g:
+            g.weights_broadcast(0)
+            masks = g.advance_batch(frames, 1.0)
+        assert len(masks) == n and all(m.shape == (1080, 1920, 4) for m in masks)
+        fp = FramePath(ctxs[0])
+        for s in range(n_ctx):
+            k = s * (n // n_ctx) + (s % (n // n_ctx))
+            solo, _ = fp.advance(frames[k], 1.0)
+            assert (solo == masks[k]).all(), k
+        assert len({m.tobytes()[:4096] for m in masks}) > 1  # distinct frames, distinct masks
+    finally:
+        for c in ctxs:
+            c.close()
