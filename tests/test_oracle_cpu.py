@@ -212,3 +212,27 @@ def test_upsample_rule_matches_torch_interpolate(oracle, dims):
     if lh > 1 and lw > 1:  # and the other conventions are measurably different, so the bound above means something
         c = torch.nn.functional.interpolate(torch.from_numpy(x)[None], size=(oh, ow), mode="bilinear", align_corners=True)[0].numpy()
         assert np.abs(a - c).max() > 1e-2
+
+
+def test_uint8_input_arm_of_the_preproc(oracle):
+    """predict_onnx.rs:114-122 (ColorRange::Uint8) + :296-301 (color_seq stays BGR for non-Float inputs): a model that
+    declares a Uint8 image input is fed the frame's bytes -- no channel reversal, no scaling.  The oracle's restatement
+    (oracle_pack_u8) against numpy, the whole-path oracle choosing the arm from the blob header, and both CPU oracles
+    agreeing on such a model."""
+    from oracle.infur_oracle import COracle, TorchModel
+
+    fr = W.synth_frame(40, 56, index=3)
+    chw = oracle.pack_u8(fr)
+    assert chw.dtype == np.float32 and (chw == fr.transpose(2, 0, 1).astype(np.float32)).all()
+    blob8 = W.synth_blob(input_u8=True)
+    assert W.unpack_blob(blob8)[0]["input_u8"] is True and W.unpack_blob(W.synth_blob())[0]["input_u8"] is False
+    co = COracle()
+    assert co.model_load(blob8) == 0
+    ref = co.model_forward(chw, full=True, low=False)
+    rc, rgba = co.frame_advance(fr, 1.0)
+    assert rc == 0 and (rgba == co.colorcode(ref["out"])).all()
+    # fed the Float arm instead, the same weights give a different mask: the header is what selects the arm
+    wrong = co.model_forward(co.pack_normalize(fr), full=True, low=False)
+    assert (co.colorcode(wrong["out"]) != rgba).any()
+    t_out, _ = TorchModel(blob8).forward(chw)
+    assert np.abs(t_out - ref["out"]).max() / np.abs(ref["out"]).max() < 2e-5
