@@ -350,6 +350,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the roofline records: per-kernel HIP events of the timed region's LAST frame (every later frame resets them)
+    recs_timed = ctx.profile() if (rank == 0 and not a.no_profile) else None
+    for c in ctxs:
+        c.L.infur_profile_enable(c.h, 0)
+
     # every rank decodes the SAME frame once more (outside the timed region): replicas must agree bit for bit
     agree = None
     if multi:
@@ -361,7 +366,8 @@ def main():
         dist.all_gather_object(shas, sha)
         agree = len(set(shas)) == 1
 
-    # for reference: the same frames with strictly one frame at a time (context 0 only), outside the timed region
+    # for reference: the same frames with strictly one frame at a time (context 0 only), outside the timed region,
+    # without per-kernel events
     one_ctx_fps = None
     if K > 1 and world == 1:
         sync_all()
@@ -396,7 +402,7 @@ def main():
         # ---- roofline of the dominant kernel family from the HIP events of the last timed frame ----
         flops = W.conv_flops(rc_h, rc_w, depth=a.depth, aux=not a.no_aux)
         if not a.no_profile:
-            recs = ctx.profile()
+            recs = recs_timed
             k3 = {c.name for c in W.graph(a.depth) if c.k == 3}
             # f32s: three f16 MFMAs per product -> the ceiling for f32-equivalent FLOPs is a third of the f16 peak
             peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "f32s": PEAK_F16_MFMA_TFLOPS / 3.0,
