@@ -1,0 +1,38 @@
+"""Soak: many frames of changing sizes / scales through one context and one stream ring; device memory in use must
+settle (arena trimming) and results must stay identical for repeated inputs."""
+import hashlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from infur_amd import weights as W
+from infur_amd.app import StreamPath
+from infur_amd.processors import Context, FramePath, Model, ModelCmd
+
+c = Context(device=0, profile=False)
+Model(c).control(ModelCmd.LoadBlob(W.synth_blob()))
+fp = FramePath(c)
+sizes = [(1080, 1920), (480, 640), (720, 1280), (97, 161)]
+frames = {s: W.synth_frame(*s, index=7) for s in sizes}
+ref, used = {}, []
+t0 = time.time()
+for it in range(400):
+    s = sizes[(it // 25) % len(sizes)]
+    f = 0.5 if (it // 100) % 2 else 1.0
+    rgba, _ = fp.advance(frames[s], f)
+    h = hashlib.sha1(rgba.tobytes()).hexdigest()
+    assert ref.setdefault((s, f), h) == h, (it, s, f)
+    if it % 25 == 24:
+        free, total = torch.cuda.mem_get_info()
+        used.append((total - free) / 2**20)
+print("sync path: %d frames in %.1f s; device MiB in use every 25 frames: %s" % (400, time.time() - t0, [round(u) for u in used]))
+sp = StreamPath(c, depth=3)
+n = 0
+for rounds in range(4):
+    for s in sizes:
+        for fid, rgba in sp.run([(i, frames[s]) for i in range(40)], 1.0):
+            assert hashlib.sha1(rgba.tobytes()).hexdigest() == ref[(s, 1.0)]
+            n += 1
+free, total = torch.cuda.mem_get_info()
+print("stream path: %d frames, all equal to the synchronous path; device MiB in use %d" % (n, (total - free) / 2**20))
+sp.close(); c.close()
+free, total = torch.cuda.mem_get_info()
+print("after close: device MiB in use %d" % ((total - free) / 2**20))
