@@ -452,6 +452,21 @@ def main():
             for o in others.values():
                 o["GB/s"] = o["bytes"] / max(o["ms"], 1e-9) / 1e6
                 o["frac_hbm"] = o["GB/s"] / PEAK_HBM_GBS
+            # what actually bounds each of them: only the Winograd transforms are HBM kernels
+            bound_of = {"wino_input": ("hbm", "a plain device-to-device copy of this size sustains 5.1-5.2 TB/s on this part (scripts/copy_ceiling.py)"),
+                        "wino_output": ("hbm", "see wino_input"),
+                        "stem_pool": ("mfma", "7x7 stem as an implicit GEMM fused with the max-pool: 11.2 GFLOP executed per 1080p frame; its bytes are "
+                                              "the 6.2 MB frame + the 33 MB pooled tensor, so GB/s says nothing about it"),
+                        "upsample_argmax_shade": ("valu", "about 180 VALU instructions per 64 pixels (packed multiplies / adds of the 4-term bilerp in the "
+                                                          "reference's operation order + compare / select per class): ~9.5 us of pure issue at 1080p; "
+                                                          "its 11 MB are the compulsory bytes (PMC: 7.9 MB read + 8.3 MB written)")}
+            for k, o in others.items():
+                if k in bound_of:
+                    o["bound"], o["note"] = bound_of[k]
+            if "stem_pool" in others:
+                st = [r for r in recs if r["kernel"] == "stem_pool"]
+                others["stem_pool"]["TFLOP/s"] = sum(r["flops"] for r in st) / max(sum(r["ms"] for r in st), 1e-9) / 1e9
+                others["stem_pool"]["frac_mfma"] = others["stem_pool"]["TFLOP/s"] / peak
             algo3 = sum(r["algo_flops"] for r in c3)
             algo_dom = sum(r["algo_flops"] for r in dom)
             ach = algo_dom / max(ms(dom), 1e-9) / 1e9
