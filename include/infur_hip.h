@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define INFUR_ABI_VERSION 2
+#define INFUR_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -92,6 +92,9 @@ typedef struct infur_options {
                                   two-source GEMM (the branch tensor is never written); 1: two launches + residual */
     uint32_t no_fuse_stem_pool; /* 0 (default): the 7x7 stem convolution and the 3x3/2 max-pool run as one kernel (the stem
                                   tensor is never written); 1: two kernels.  Results are bit-identical. */
+    uint32_t no_fuse_b2b;  /* 0 (default): in the f16 mode a bottleneck's conv3 + residual and the next bottleneck's conv1 run
+                              as one launch where that measures faster (the widest tensor of the stage is written once and
+                              not read back); 1: always two launches.  Results are bit-identical. */
     void* stream;          /* optional caller-owned hipStream_t; NULL = context creates one */
 } infur_options;
 

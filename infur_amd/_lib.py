@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinfur_hip.so")
 
-ABI_VERSION = 2  # INFUR_ABI_VERSION of include/infur_hip.h
+ABI_VERSION = 3  # INFUR_ABI_VERSION of include/infur_hip.h
 
 # status codes (include/infur_hip.h)
 OK = 0
@@ -47,6 +47,7 @@ class Options(C.Structure):
         ("no_autotune", C.c_uint32),
         ("no_fuse_downsample", C.c_uint32),
         ("no_fuse_stem_pool", C.c_uint32),
+        ("no_fuse_b2b", C.c_uint32),
         ("stream", C.c_void_p),
     ]
 

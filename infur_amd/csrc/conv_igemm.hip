@@ -919,11 +919,11 @@ int conv_igemm_default_config(const ConvArgs& a) {
 }
 
 // a configuration is a candidate when its N tile is not mostly padding (and, for the LDS-DMA forms, in the f16 mode)
-bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode) {
+bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32) {
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     if (mode == 3) mode = 2;  // the fp8 cross-term form stages like the split mode
     if (cfg >= 13 && mode != 1) return false;
-    if (cfg == 15) return conv1x1_areg_valid(a, mode, 0);
+    if (cfg == 15) return conv1x1_areg_valid(a, mode, out_f32);  // (f16 output only: not the f32 logits of a 1x1 classifier)
     const int bn = kCfgs[cfg].bn;
     if (a.Cout <= 32) return bn == 32;
     if (bn == 32) return false;

@@ -509,25 +509,36 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
 // for real on the actual operands and timed with HIP events; the fastest is remembered for the
 // context's lifetime.  All configurations give bit-identical outputs, so the trial launches are
 // simply redundant evaluations of the layer.
+struct EventPair {  // the tuner's two events, released on every return path
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t create() {
+        hipError_t e = hipEventCreate(&e0);
+        return e != hipSuccess ? e : hipEventCreate(&e1);
+    }
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
 int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cfg) {
     *cfg = conv_igemm_default_config(a);
     // test hook: INFUR_CONV_CFG=<k> forces configuration k wherever it is a candidate
     static const int forced = getenv("INFUR_CONV_CFG") ? atoi(getenv("INFUR_CONV_CFG")) : -1;
     if (forced >= 0) {
-        if (conv_igemm_config_valid(a, forced, mode)) *cfg = forced;
+        if (conv_igemm_config_valid(a, forced, mode, out_f32)) *cfg = forced;
         return INFUR_OK;
     }
     if (c->opt.no_autotune) return INFUR_OK;
     const std::array<int, 13> key = {a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.stride, a.dil, a.batch,
                                      a.res ? 1 : (a.in2 ? 2 : 0), mode, out_f32};
     auto it = c->tuned.find(key);
-    if (it != c->tuned.end() && conv_igemm_config_valid(a, it->second, mode)) {
+    if (it != c->tuned.end() && conv_igemm_config_valid(a, it->second, mode, out_f32)) {
         *cfg = it->second;
         return INFUR_OK;
     }
-    hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
+    EventPair ev;
+    HIPCHK(c, ev.create());
     if (!c->tune_warm) {  // bring clocks and caches to their steady state before the first measurement
         for (int r = 0; r < 12; r++) HIPCHK(c, launch_conv_igemm(a, mode, out_f32, *cfg, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -536,16 +547,20 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
     float best = 1e30f;
     std::vector<std::pair<int, float>> timed;
     for (int k = 0; k < conv_igemm_num_configs(); k++) {
-        if (!conv_igemm_config_valid(a, k, mode)) continue;
-        HIPCHK(c, launch_conv_igemm(a, mode, out_f32, k, c->stream));  // warm-up (attributes, caches)
+        if (!conv_igemm_config_valid(a, k, mode, out_f32)) continue;
+        // a candidate that cannot launch on this shape after all (invalid value) is skipped, not fatal: the layer still
+        // has the other configurations; anything else (a fault, a lost device) is an error of the frame
+        const hipError_t le = launch_conv_igemm(a, mode, out_f32, k, c->stream);  // warm-up (attributes, caches)
+        if (le == hipErrorInvalidValue) continue;
+        HIPCHK(c, le);
         float fastest = 1e30f;
         for (int r = 0; r < 4; r++) {  // minimum of 4 single-launch timings
-            HIPCHK(c, hipEventRecord(e0, c->stream));
+            HIPCHK(c, hipEventRecord(ev.e0, c->stream));
             HIPCHK(c, launch_conv_igemm(a, mode, out_f32, k, c->stream));
-            HIPCHK(c, hipEventRecord(e1, c->stream));
-            HIPCHK(c, hipEventSynchronize(e1));
+            HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+            HIPCHK(c, hipEventSynchronize(ev.e1));
             float ms = 0;
-            HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+            HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
             if (ms < fastest) fastest = ms;
         }
         timed.emplace_back(k, fastest);
@@ -559,8 +574,6 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
     // Cache / HBM traffic, which is also what leaves room for a second frame in flight
     for (const auto& kt : timed)
         if (kt.second <= best * 1.02f && conv_igemm_config_tile_area(kt.first) > conv_igemm_config_tile_area(*cfg)) *cfg = kt.first;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     c->tuned[key] = *cfg;
     return INFUR_OK;
 }
@@ -574,6 +587,15 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
 constexpr float kSplitActScale = 4.0f;
 constexpr float kSplitWinoScaleF4 = 0.125f, kSplitWinoScaleF2 = 1.0f, kSplitWinoScaleF6 = 0.0625f;  // F6 amplifies up to 225x
 inline float split_wino_scale(int mt) { return mt == 6 ? kSplitWinoScaleF6 : (mt == 4 ? kSplitWinoScaleF4 : kSplitWinoScaleF2); }
+
+// the plain (non-Winograd) launch description of layer L on `in` (+ optional residual) -> `out`
+ConvArgs conv_args(const ConvLayer& L, const Tensor& in, const Tensor* res, const Tensor& out) {
+    ConvArgs a;
+    a.in = in.p; a.wt = L.d_w; a.bias = L.d_b; a.res = res ? res->p : nullptr; a.out = out.p;
+    a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = out.h; a.OW = out.w; a.Cout = L.cout;
+    a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = L.relu ? 1 : 0;
+    return a;
+}
 
 // ---- one convolution on the implicit-GEMM kernel ----
 int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, Tensor* out) {
@@ -620,10 +642,7 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         if (c->opt.keep_activations) c->kept.push_back(*out);
         return INFUR_OK;
     }
-    ConvArgs a;
-    a.in = in.p; a.wt = L.d_w; a.bias = L.d_b; a.res = res ? res->p : nullptr; a.out = out->p;
-    a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = L.cout;
-    a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = L.relu ? 1 : 0;
+    ConvArgs a = conv_args(L, in, res, *out);
     const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
     const double bytes = (double)in.bytes() + (double)out->bytes() + (res ? (double)res->bytes() : 0.0) +
                          (double)L.cout * L.cin * L.k * L.k * in.es;
@@ -672,6 +691,95 @@ int32_t run_conv_dual(infur_ctx* c, const ConvLayer& L3, const ConvLayer& D, con
     return INFUR_OK;
 }
 
+// ---- conv3 + residual + ReLU of one bottleneck and conv1 + ReLU of the NEXT one as ONE launch (conv1x1_b2b.hip) ----
+// f16 mode, inside a stage (the next conv1 reads exactly what this conv3 writes), C2 = 128 / 256 (layer2 / layer3).  y is
+// still written once -- it is the next block's residual -- but never read back by conv1.  Bit-identical to the two
+// launches, so whether to fuse is measured like a tile configuration: the first time a shape is seen both forms run on
+// the real operands and the faster one is remembered (at 1080p a 256-pixel workgroup tile fills only half the CUs; at 4K
+// the fused form wins).  *done == false: nothing was produced, the caller runs the two convolutions.
+bool b2b_candidate(const infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1) {
+    return ctx_f16(c) && !c->opt.no_fuse_b2b && c3.role == '3' && n1.role == '1' && c3.k == 1 && n1.k == 1 && n1.stride == 1 &&
+           n1.cin == c3.cout && n1.cout == c3.cin && c3.cout == 4 * c3.cin && (c3.cin == 128 || c3.cin == 256) && c3.relu &&
+           n1.relu && c3.d_b && n1.d_b;
+}
+
+int32_t run_b2b(infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1, const Tensor& t2, const Tensor& x, Tensor* y, Tensor* t1n, bool* done) {
+    *done = false;
+    if (!b2b_candidate(c, c3, n1) || x.h != t2.h || x.w != t2.w || x.c != c3.cout || t2.c != c3.cin || t2.es != 2 || x.es != 2) return INFUR_OK;
+    RETIF(talloc(c, t2.h, t2.w, c3.cout, 2, y));
+    RETIF(talloc(c, t2.h, t2.w, n1.cout, 2, t1n));
+    auto give_back = [&]() {  // (pool_release keeps buffers under keep_activations: these two were never results)
+        for (Tensor* t : {y, t1n}) {
+            if (t->slot >= 0) c->pool[t->slot].used = false;
+            *t = Tensor();
+        }
+    };
+    B2bArgs b;
+    b.in = t2.p; b.w3 = c3.d_w; b.b3 = c3.d_b; b.res = x.p; b.y = y->p; b.w1 = n1.d_w; b.b1 = n1.d_b; b.out2 = t1n->p;
+    b.M = t2.h * t2.w; b.C2 = c3.cin; b.relu1 = 1; b.relu2 = 1;
+    if (!conv1x1_b2b_valid(b)) {
+        give_back();
+        return INFUR_OK;
+    }
+    // the decision lives in the tuning database next to the tile configurations (flag 3 = "conv3 -> next conv1 pair")
+    const std::array<int, 13> key = {t2.h, t2.w, c3.cin, t2.h, t2.w, c3.cout, 1, 1, 1, 1, 3, 1, 0};
+    static const int forced = getenv("INFUR_B2B") ? atoi(getenv("INFUR_B2B")) : -1;  // test hook: 1 always, 0 never
+    bool use;
+    auto it = c->tuned.find(key);
+    if (forced >= 0) {
+        use = forced != 0;
+    } else if (it != c->tuned.end()) {
+        use = it->second != 0;
+    } else if (c->opt.no_autotune) {
+        use = (b.M + 255) / 256 >= 384;  // one and a half waves of workgroups on 256 CUs
+    } else {
+        const ConvArgs a3 = conv_args(c3, t2, &x, *y), a1 = conv_args(n1, *y, nullptr, *t1n);
+        int cfg3 = -1, cfg1 = -1;
+        RETIF(pick_cfg(c, a3, 1, 0, &cfg3));
+        RETIF(pick_cfg(c, a1, 1, 0, &cfg1));
+        EventPair ev;
+        HIPCHK(c, ev.create());
+        float t_pair = 1e30f, t_fused = 1e30f;
+        for (int r = 0; r < 5; r++) {  // first round = warm-up
+            HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+            HIPCHK(c, launch_conv_igemm(a3, 1, 0, cfg3, c->stream));
+            HIPCHK(c, launch_conv_igemm(a1, 1, 0, cfg1, c->stream));
+            HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+            HIPCHK(c, hipEventSynchronize(ev.e1));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+            if (r && ms < t_pair) t_pair = ms;
+        }
+        for (int r = 0; r < 5; r++) {
+            HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+            HIPCHK(c, launch_conv1x1_b2b(b, c->stream));
+            HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+            HIPCHK(c, hipEventSynchronize(ev.e1));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+            if (r && ms < t_fused) t_fused = ms;
+        }
+        use = t_fused < t_pair;
+        c->tuned[key] = use ? 1 : 0;
+    }
+    if (!use) {
+        give_back();
+        return INFUR_OK;
+    }
+    const double M = (double)b.M;
+    {
+        ProfScope ps(c, c3.name + "+next.conv1", "conv1x1_b2b_f16", 2.0 * M * c3.cout * c3.cin * 2.0,
+                     (double)t2.bytes() + (double)x.bytes() + (double)y->bytes() + (double)t1n->bytes() + 2.0 * c3.cout * c3.cin * 2.0);
+        HIPCHK(c, launch_conv1x1_b2b(b, c->stream));
+    }
+    if (c->opt.keep_activations) {
+        c->kept.push_back(*y);
+        c->kept.push_back(*t1n);
+    }
+    *done = true;
+    return INFUR_OK;
+}
+
 // FCN-ResNet forward from a packed BGR frame resident on the device.
 // Leaves the output-stride-8 logits in c->out_low / c->aux_low (NHWC).
 int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
@@ -712,13 +820,19 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     }
 
     Tensor l3;
+    Tensor t1_pre;  // this block's conv1 output when the previous block's conv3 launch already produced it (run_b2b)
     while (c->convs[ci].role == '1') {
         const ConvLayer& c1 = c->convs[ci];
         const ConvLayer& c2 = c->convs[ci + 1];
         const ConvLayer& c3 = c->convs[ci + 2];
         const bool has_ds = c->convs[ci + 3].role == 'd';
         Tensor t1, t2, idt, y;
-        RETIF(run_conv(c, c1, x, nullptr, &t1));
+        if (t1_pre.p) {
+            t1 = t1_pre;
+            t1_pre = Tensor();
+        } else {
+            RETIF(run_conv(c, c1, x, nullptr, &t1));
+        }
         RETIF(run_conv(c, c2, t1, nullptr, &t2));
         pool_release(c, t1);
         // the per-layer read-back (keep_activations) wants the branch tensor, so it runs the unfused form
@@ -730,7 +844,9 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
                 // keep_activations order follows the blob (conv3 before downsample): fix up below
                 RETIF(run_conv(c, c->convs[ci + 3], x, nullptr, &idt));
             }
-            RETIF(run_conv(c, c3, t2, has_ds ? &idt : &x, &y));
+            bool b2b = false;
+            if (!has_ds) RETIF(run_b2b(c, c3, c->convs[ci + 3], t2, x, &y, &t1_pre, &b2b));
+            if (!b2b) RETIF(run_conv(c, c3, t2, has_ds ? &idt : &x, &y));
             if (has_ds && c->opt.keep_activations) std::swap(c->kept[c->kept.size() - 1], c->kept[c->kept.size() - 2]);
         }
         pool_release(c, t2);

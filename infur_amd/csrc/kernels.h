@@ -49,13 +49,31 @@ hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, 
 int conv_igemm_num_configs();
 int conv_igemm_config_tile_area(int cfg);  // BM * BN of a configuration (operand re-reads fall with it)
 int conv_igemm_default_config(const ConvArgs& a);
-bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode);
+bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32);
 const char* conv_igemm_config_name(int cfg, int mode);
 
 // 1x1 convolution with Cin in {64, 128, 256}, f16 operands (mode 1), f16 output: the activation tile stays in registers
 // while the workgroup walks all N tiles (conv1x1_areg.hip).  Reached through launch_conv_igemm as one more configuration.
 bool conv1x1_areg_valid(const ConvArgs& a, int mode, int out_f32);
 hipError_t launch_conv1x1_areg(const ConvArgs& a, hipStream_t s);
+
+// Two 1x1 convolutions back to back on the same pixels, f16 (conv1x1_b2b.hip): y = ReLU(w3 * in + b3 + res) -- a
+// bottleneck's conv3 + residual -- is written once and immediately multiplied by the NEXT bottleneck's conv1 weights:
+// out2 = ReLU(w1 * y + b1).  C2 = channels of `in` = channels of out2 (128 or 256); y and res have 4 * C2 channels.
+// Bit-identical to the two launches it replaces.
+struct B2bArgs {
+    const void* in;    // [M][C2] f16
+    const void* w3;    // [4*C2][C2] f16
+    const float* b3;   // [4*C2]
+    const void* res;   // [M][4*C2] f16
+    void* y;           // [M][4*C2] f16
+    const void* w1;    // [C2][4*C2] f16
+    const float* b1;   // [C2]
+    void* out2;        // [M][C2] f16
+    int M, C2, relu1, relu2;
+};
+bool conv1x1_b2b_valid(const B2bArgs& a);
+hipError_t launch_conv1x1_b2b(const B2bArgs& a, hipStream_t s);
 
 // Winograd F(mt x mt, 3x3), mt = 2 or 4, for stride-1 3x3 convs (f32, any dilation d with pad = d);
 // (mt+2)^2 transform planes; see winograd.hip

@@ -104,7 +104,7 @@ class Context:
     def __init__(self, device: int = 0, compute_aux: bool = True, profile: bool = False,
                  keep_activations: bool = False, stream: Optional[int] = None, dtype: str = "f32",
                  winograd_min_cin: int = 0, winograd_tile: int = 0, autotune: bool = True, fuse_downsample: bool = True,
-                 fuse_stem_pool: bool = True):
+                 fuse_stem_pool: bool = True, fuse_b2b: bool = True):
         L = self.L = _lib.load()
         o = _lib.Options()
         L.infur_options_default(C.byref(o))
@@ -119,6 +119,7 @@ class Context:
         o.no_autotune = 0 if autotune else 1
         o.no_fuse_downsample = 0 if fuse_downsample else 1
         o.no_fuse_stem_pool = 0 if fuse_stem_pool else 1
+        o.no_fuse_b2b = 0 if fuse_b2b else 1  # f16 mode: conv3 + residual and the next block's conv1 as one launch
         o.stream = stream
         h = C.c_void_p(None)
         rc = L.infur_ctx_create(C.byref(o), C.byref(h))

@@ -28,6 +28,7 @@ pub struct infur_options {
     pub no_autotune: u32,
     pub no_fuse_downsample: u32,
     pub no_fuse_stem_pool: u32,
+    pub no_fuse_b2b: u32,
     pub stream: *mut c_void,
 }
 
@@ -55,7 +56,7 @@ pub const INFUR_E_RCCL: i32 = 8;
 pub const INFUR_E_INVALID_ARG: i32 = 9;
 pub const INFUR_E_IO: i32 = 10;
 pub const INFUR_E_CAPACITY: i32 = 11;
-pub const INFUR_ABI_VERSION: u32 = 2;
+pub const INFUR_ABI_VERSION: u32 = 3;
 pub const INFUR_SCALE_NEAREST: u32 = 0;
 pub const INFUR_SCALE_BILINEAR: u32 = 1;
 pub const INFUR_DTYPE_F32: u32 = 0;
