@@ -407,7 +407,8 @@ def main():
             # f32s: three f16 MFMAs per product -> the ceiling for f32-equivalent FLOPs is a third of the f16 peak
             peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "f32s": PEAK_F16_MFMA_TFLOPS / 3.0,
                     "f32x": PEAK_F16_MFMA_TFLOPS / 2.0}[a.dtype]  # f32x: one f16 MFMA + one fp8 MX MFMA (half an f16 unit per term) per product
-            conv = [r for r in recs if r["kernel"].startswith("conv_igemm_")]
+            CONV_KERNELS = ("conv_igemm_", "conv1x1_")  # tiled implicit GEMM; A-resident 1x1 and the fused conv3 -> next conv1 pair (f16 mode)
+            conv = [r for r in recs if r["kernel"].startswith(CONV_KERNELS)]
             # dominant kernel = the tile configuration of conv_igemm that takes the most time in a frame over the
             # launches that execute the convolution directly (algorithmic FLOPs == executed FLOPs); the
             # Winograd-domain GEMM launches are reported under "winograd" with both views
@@ -428,7 +429,7 @@ def main():
             ms_all = ms(recs)
             traffic = None
             tj = os.path.join(ROOT, "profiles", "traffic_latest.json" if a.dtype == "f32" else f"traffic_{a.dtype}.json")
-            if os.path.exists(tj) and (Wd, H, a.scale, a.depth) == (1920, 1080, 1.0, 50):
+            if os.path.exists(tj) and (Wd, H, a.scale, a.depth) == (1920, 1080, 1.0, 50) and "<" in dom_name:
                 parts = dom_name.split("<")[1].rstrip(">").split(",")  # "64,64" or "64,64,1buf" / "256,256,1frag"
                 bm, bn = parts[0], parts[1]
                 nbuf = {"1buf": "1", "1frag": "3", "dma": "4", "dmai": "5"}.get(parts[2], "2") if len(parts) > 2 else "2"
@@ -443,7 +444,7 @@ def main():
                     traffic = sum((t["read_bytes_per_launch"] + t["write_bytes_per_launch"]) * t["launches"] for t in ts) / n
             others = {}
             for r in recs:
-                if r["kernel"].startswith("conv_igemm"):
+                if r["kernel"].startswith(CONV_KERNELS):
                     continue
                 o = others.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "bytes": 0.0})
                 o["launches"] += 1

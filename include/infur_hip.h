@@ -274,7 +274,10 @@ int32_t infur_batch_advance(infur_ctx* ctx, const uint8_t* const* frames, const 
  * host reaches N GPUs through a GROUP: n contexts (normally one per device; several on one device are allowed),
  * one persistent worker thread per context, and -- when the contexts span >= 2 devices -- one RCCL communicator
  * over those devices (ncclCommInitAll).  Frames are independent (app.rs:107-153), so the only collective is the
- * one-off replication of the weights.  A group and its contexts are used from one thread at a time. */
+ * one-off replication of the weights.  A group and its contexts are used from one thread at a time.
+ * RCCL itself is resolved when the first such group is created (dlopen of librccl.so.1; INFUR_RCCL_LIB overrides the name):
+ * the library does not link it, so the single-GPU entry points work on hosts without RCCL, and a group that needs it where
+ * it is missing fails with INFUR_E_RCCL. */
 typedef struct infur_group infur_group;
 int32_t infur_group_create(infur_ctx* const* ctxs, uint32_t n_ctx, infur_group** out);
 void infur_group_destroy(infur_group* g); /* the contexts stay alive and remain the caller's */
@@ -283,6 +286,10 @@ uint32_t infur_group_size(const infur_group* g);
 /* 1 when the group holds an RCCL communicator (its contexts span >= 2 devices, or INFUR_FORCE_RCCL=1 in the
  * environment: then a single-device group routes its copies through a one-rank communicator -- a test hook) */
 uint32_t infur_group_uses_rccl(const infur_group* g);
+/* NUMA node worker i is pinned to (the node of its GPU's PCIe root, from sysfs), or -1: every worker thread moves its slice
+ * of a batch through pageable -> pinned copies, so it runs on the socket its GPU hangs off.  INFUR_NO_NUMA_PIN=1 in the
+ * environment (read at infur_group_create) disables the pinning; hosts without the sysfs files are left alone. */
+int32_t infur_group_worker_numa_node(const infur_group* g, uint32_t i);
 /* Replicates the model loaded in context `root` (index into the group) to every other context: ONE
  * ncclBroadcast of the repacked weight arena (141 MB for FCN-ResNet50 f32) over xGMI, no
  * per-GPU re-upload or repack; contexts sharing a device with an already served one get a device-to-device copy.

@@ -132,6 +132,7 @@ SIGNATURES = {
     "infur_group_last_error": (C.c_char_p, [_vp]),
     "infur_group_size": (C.c_uint32, [_vp]),
     "infur_group_uses_rccl": (C.c_uint32, [_vp]),
+    "infur_group_worker_numa_node": (C.c_int32, [_vp, _u32]),
     "infur_group_weights_broadcast": (C.c_int32, [_vp, _u32]),
     "infur_group_batch_advance": (C.c_int32, [_vp, C.POINTER(_vp), _u32p, _u32p, _u32, _f, _u32, C.POINTER(_vp),
                                               C.POINTER(_sz), _u32p, _u32p]),

@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 
+#include "blob_dir.h"
 #include "infur_ctx.h"
 #include "kernels.h"
 #include "onnx_reader.h"
@@ -277,53 +278,19 @@ bool wino_eligible(const infur_ctx* c, const ConvLayer& L) {
     return thr != 0xFFFFFFFFu && (uint32_t)L.cin >= thr && (L.cin % 32) == 0 && (L.cout % 4) == 0;
 }
 
-// ---- graph description: torchvision fcn_resnet{50,101}, output stride 8 ----
-bool layer_blocks(int depth, int lb[4]) {
-    if (depth == 50) { lb[0] = 3; lb[1] = 4; lb[2] = 6; lb[3] = 3; return true; }
-    if (depth == 101) { lb[0] = 3; lb[1] = 4; lb[2] = 23; lb[3] = 3; return true; }
-    return false;
-}
-
+// ---- graph description: torchvision fcn_resnet{50,101}, output stride 8 (blob_dir.h: shared with the format harness) ----
 std::vector<ConvLayer> build_graph(int depth, int ncls, bool aux) {
     std::vector<ConvLayer> g;
-    int lb[4];
-    layer_blocks(depth, lb);
-    auto add = [&](const std::string& n, int cout, int cin, int k, int s, int p, int d, bool relu, char role) {
+    for (const ConvSpec& sp : graph_spec(depth, ncls, aux)) {
         ConvLayer c;
-        c.name = n; c.cout = cout; c.cin = cin; c.k = k; c.stride = s; c.pad = p; c.dil = d;
-        c.relu = relu; c.role = role;
+        c.name = sp.name; c.cout = sp.cout; c.cin = sp.cin; c.k = sp.k; c.stride = sp.stride; c.pad = sp.pad; c.dil = sp.dil;
+        c.relu = sp.relu; c.role = sp.role;
         g.push_back(c);
-    };
-    add("backbone.conv1", 64, 3, 7, 2, 3, 1, true, 's');
-    int inplanes = 64, dilation = 1;
-    for (int L = 0; L < 4; L++) {
-        const int planes = 64 << L;
-        int stride = L == 0 ? 1 : 2;
-        const int prev = dilation;
-        if (L >= 2) {  // replace_stride_with_dilation = [False, True, True]
-            dilation *= stride;
-            stride = 1;
-        }
-        for (int b = 0; b < lb[L]; b++) {
-            const int bs = b == 0 ? stride : 1, bd = b == 0 ? prev : dilation;
-            const std::string p = "backbone.layer" + std::to_string(L + 1) + "." + std::to_string(b);
-            add(p + ".conv1", planes, inplanes, 1, 1, 0, 1, true, '1');
-            add(p + ".conv2", planes, planes, 3, bs, bd, bd, true, '2');
-            add(p + ".conv3", planes * 4, planes, 1, 1, 0, 1, true, '3');
-            if (b == 0) add(p + ".downsample.0", planes * 4, inplanes, 1, bs, 0, 1, false, 'd');
-            inplanes = planes * 4;
-        }
-    }
-    add("classifier.0", 512, 2048, 3, 1, 1, 1, true, 'h');
-    add("classifier.4", ncls, 512, 1, 1, 0, 1, false, 'c');
-    if (aux) {
-        add("aux_classifier.0", 256, 1024, 3, 1, 1, 1, true, 'h');
-        add("aux_classifier.4", ncls, 256, 1, 1, 0, 1, false, 'c');
     }
     return g;
 }
 
-constexpr size_t kBlobHdr = 32, kBlobEntry = 80;
+bool b2b_candidate(const infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1);
 
 void model_free(infur_ctx* c) {
     if (c->d_weights) (void)hipFree(c->d_weights);
@@ -386,51 +353,29 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     uint8_t hdr[kBlobHdr];
     HIPCHK(c, hipMemcpyAsync(hdr, d_blob, kBlobHdr, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (memcmp(hdr, "INFURW01", 8) != 0) return fail(c, INFUR_E_MODEL_FORMAT, "bad magic: not an INFURW01 weight blob");
-    uint32_t h32[6];
-    memcpy(h32, hdr + 8, 24);
-    const int depth = (int)h32[0], ncls = (int)h32[1];
-    const bool aux = h32[2] != 0;
-    const uint32_t n = h32[3];
-    // input kind: 0 = Float image input (RGB planes normalised with the torchvision constants), 1 = Uint8 (the bytes
-    // themselves, BGR kept) -- the two ColorRange arms of ImageSession::forward (predict_onnx.rs:114-139)
-    if (h32[4] > 1) return fail(c, INFUR_E_MODEL_FORMAT, "unknown input kind %u in the weight blob (0 = Float, 1 = Uint8)", h32[4]);
-    const bool input_u8 = h32[4] == 1;
-    int lb[4];
-    if (!layer_blocks(depth, lb)) return fail(c, INFUR_E_MODEL_FORMAT, "unsupported backbone depth %d (50 or 101)", depth);
-    if (ncls <= 0 || ncls > 256) return fail(c, INFUR_E_MODEL_FORMAT, "unsupported class count %d", ncls);
+    // header and directory are checked by blob_dir.h (host-only: the code `make asan` mutates files against)
+    BlobHeader bh;
+    std::vector<ConvSpec> spec;
+    std::string perr;
+    if (!blob_parse_header(hdr, len, &bh, &spec, &perr)) return fail(c, INFUR_E_MODEL_FORMAT, "%s", perr.c_str());
+    const int depth = bh.depth, ncls = bh.num_classes;
+    const bool aux = bh.aux, input_u8 = bh.input_u8;
+    const uint32_t n = bh.n_convs;
     std::vector<ConvLayer> g = build_graph(depth, ncls, aux);
-    if (n != g.size()) return fail(c, INFUR_E_MODEL_FORMAT, "blob has %u convs, graph needs %zu", n, g.size());
-    if ((len - kBlobHdr) / kBlobEntry < n) return fail(c, INFUR_E_MODEL_FORMAT, "truncated conv table");
     std::vector<uint8_t> table((size_t)n * kBlobEntry);
     HIPCHK(c, hipMemcpyAsync(table.data(), (const uint8_t*)d_blob + kBlobHdr, table.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-
-    struct Ent { uint64_t w_off, b_off; };
-    std::vector<Ent> ents(n);
+    std::vector<BlobEntry> ents;
+    if (!blob_parse_directory(table.data(), len, spec, &ents, &perr)) return fail(c, INFUR_E_MODEL_FORMAT, "%s", perr.c_str());
     size_t total = 0;
     for (uint32_t i = 0; i < n; i++) {
-        const uint8_t* e = table.data() + (size_t)i * kBlobEntry;
-        char name[41];
-        memcpy(name, e, 40);
-        name[40] = 0;
-        uint32_t d[4];
-        memcpy(d, e + 40, 16);
-        memcpy(&ents[i].w_off, e + 56, 8);
-        memcpy(&ents[i].b_off, e + 64, 8);
         const ConvLayer& L = g[i];
-        if (L.name != name) return fail(c, INFUR_E_MODEL_FORMAT, "conv %u is '%s', expected '%s'", i, name, L.name.c_str());
-        if ((int)d[0] != L.cout || (int)d[1] != L.cin || (int)d[2] != L.k || (int)d[3] != L.k)
-            return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' has shape [%u,%u,%u,%u], expected [%d,%d,%d,%d]", name, d[0], d[1], d[2], d[3], L.cout, L.cin, L.k, L.k);
         const size_t wn = (size_t)L.cout * L.cin * L.k * L.k * 4, bn = (size_t)L.cout * 4;
-        // offsets come from the (untrusted) file: compare without forming off + n, which can wrap
-        auto in_range = [len](uint64_t off, size_t n) { return off <= len && n <= len - off; };
-        if (ents[i].w_off % 4 || ents[i].b_off % 4 || !in_range(ents[i].w_off, wn) || !in_range(ents[i].b_off, bn))
-            return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s' data out of range", name);
         total += align_up(wn, 256) + align_up(bn, 256);  // upper bound (f16 weights take half)
         if (wino_eligible(c, L)) total += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
         if (L.role == '3' && i + 1 < n && g[i + 1].role == 'd')
             total += align_up((size_t)L.cout * (L.cin + g[i + 1].cin) * 4, 256) + align_up(bn, 256);
+        if (i + 1 < n && b2b_candidate(c, L, g[i + 1])) total += align_up((size_t)L.cout * L.cin * 2, 256);
     }
 
     // The new weight set is built beside the loaded one and swapped in only when everything succeeded: a failed
@@ -475,6 +420,14 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         off += align_up((size_t)L.cout * 4, 256);
         HIPCHK(c, launch_concat_rows(L.d_w, (size_t)L.cin * es, D.d_w, (size_t)D.cin * es, L.d_wcat, L.cout, c->stream));
         HIPCHK(c, launch_add_f32(L.d_b, D.d_b, L.d_bcat, L.cout, c->stream));
+    }
+    // conv3 weights in the row order of the fused conv3 -> next conv1 launch (f16 mode, inside a stage)
+    for (uint32_t i = 0; i + 1 < n; i++) {
+        ConvLayer& L = g[i];
+        if (!b2b_candidate(c, L, g[i + 1])) continue;
+        L.d_w3i = (uint8_t*)d_weights + off;
+        off += align_up((size_t)L.cout * L.cin * 2, 256);
+        HIPCHK(c, launch_b2b_pack_w3(L.d_w, L.d_w3i, L.cin, c->stream));
     }
     if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT) RETIF(split_weights(c, g));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -700,12 +653,12 @@ int32_t run_conv_dual(infur_ctx* c, const ConvLayer& L3, const ConvLayer& D, con
 bool b2b_candidate(const infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1) {
     return ctx_f16(c) && !c->opt.no_fuse_b2b && c3.role == '3' && n1.role == '1' && c3.k == 1 && n1.k == 1 && n1.stride == 1 &&
            n1.cin == c3.cout && n1.cout == c3.cin && c3.cout == 4 * c3.cin && (c3.cin == 128 || c3.cin == 256) && c3.relu &&
-           n1.relu && c3.d_b && n1.d_b;
+           n1.relu;
 }
 
 int32_t run_b2b(infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1, const Tensor& t2, const Tensor& x, Tensor* y, Tensor* t1n, bool* done) {
     *done = false;
-    if (!b2b_candidate(c, c3, n1) || x.h != t2.h || x.w != t2.w || x.c != c3.cout || t2.c != c3.cin || t2.es != 2 || x.es != 2) return INFUR_OK;
+    if (!b2b_candidate(c, c3, n1) || !c3.d_w3i || x.h != t2.h || x.w != t2.w || x.c != c3.cout || t2.c != c3.cin || t2.es != 2 || x.es != 2) return INFUR_OK;
     RETIF(talloc(c, t2.h, t2.w, c3.cout, 2, y));
     RETIF(talloc(c, t2.h, t2.w, n1.cout, 2, t1n));
     auto give_back = [&]() {  // (pool_release keeps buffers under keep_activations: these two were never results)
@@ -715,7 +668,7 @@ int32_t run_b2b(infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1, const Te
         }
     };
     B2bArgs b;
-    b.in = t2.p; b.w3 = c3.d_w; b.b3 = c3.d_b; b.res = x.p; b.y = y->p; b.w1 = n1.d_w; b.b1 = n1.d_b; b.out2 = t1n->p;
+    b.in = t2.p; b.w3 = c3.d_w3i; b.b3 = c3.d_b; b.res = x.p; b.y = y->p; b.w1 = n1.d_w; b.b1 = n1.d_b; b.out2 = t1n->p;
     b.M = t2.h * t2.w; b.C2 = c3.cin; b.relu1 = 1; b.relu2 = 1;
     if (!conv1x1_b2b_valid(b)) {
         give_back();
@@ -989,6 +942,10 @@ void infur_ctx_destroy(infur_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     // streams that outlive their context become empty shells: infur_stream_destroy on them only frees the handle
     while (!c->streams.empty()) stream_orphan(c->streams.back());
+    if (c->batch_ring) {  // the context's own ring (infur_batch_advance): orphaned above, the handle goes here
+        infur_stream_destroy(c->batch_ring);
+        c->batch_ring = nullptr;
+    }
     model_free(c);
     pool_free(c);
     for (Buf* b : {&c->st_in, &c->st_scaled, &c->st_rgba, &c->st_f32a, &c->st_f32b})
@@ -1547,8 +1504,10 @@ struct infur_stream {
 };
 
 namespace {
+// buffers grow on demand and are given back when a request needs less than a quarter of them (a ring that lives as
+// long as its context -- infur_batch_advance's -- would otherwise keep the largest frame it ever saw)
 int32_t slot_reserve(infur_ctx* c, infur_stream::Slot& sl, size_t in_bytes, size_t out_bytes) {
-    if (sl.in_cap < in_bytes) {
+    if (sl.in_cap < in_bytes || sl.in_cap / 4 > in_bytes) {
         if (sl.h_in) HIPCHK(c, hipHostFree(sl.h_in));
         if (sl.d_in) HIPCHK(c, hipFree(sl.d_in));
         sl.h_in = nullptr; sl.d_in = nullptr; sl.in_cap = 0;
@@ -1556,7 +1515,7 @@ int32_t slot_reserve(infur_ctx* c, infur_stream::Slot& sl, size_t in_bytes, size
         HIPCHK(c, hipMalloc(&sl.d_in, in_bytes));
         sl.in_cap = in_bytes;
     }
-    if (sl.out_cap < out_bytes) {
+    if (sl.out_cap < out_bytes || sl.out_cap / 4 > out_bytes) {
         if (sl.h_out) HIPCHK(c, hipHostFree(sl.h_out));
         if (sl.d_out) HIPCHK(c, hipFree(sl.d_out));
         sl.h_out = nullptr; sl.d_out = nullptr; sl.out_cap = 0;
@@ -1645,7 +1604,12 @@ int32_t infur_stream_add_lane(infur_stream* st, infur_ctx* other) {
     for (infur_ctx* l : st->lanes)
         if (l == other) return fail(c, INFUR_E_INVALID_ARG, "that context already is a lane of this stream");
     if (st->head != st->tail) return fail(c, INFUR_E_INVALID_ARG, "add lanes while no frame is pending");
-    if (other->opt.compute_dtype != c->opt.compute_dtype) return fail(c, INFUR_E_INVALID_ARG, "a lane must use the stream's compute_dtype: its frames would otherwise differ");
+    // odd and even frames must run the SAME arithmetic: the option set infur_group_weights_broadcast checks (the fusion
+    // switches are bit-identical forms and may differ; F(4x4) and F(6x6) logits differ by ~1e-6, enough to flip a tie)
+    if (other->opt.compute_dtype != c->opt.compute_dtype || other->opt.winograd_tile != c->opt.winograd_tile ||
+        other->opt.winograd_min_cin != c->opt.winograd_min_cin || other->opt.compute_aux != c->opt.compute_aux)
+        return fail(c, INFUR_E_INVALID_ARG, "a lane must share the stream's compute_dtype / winograd_tile / winograd_min_cin / compute_aux: its frames would otherwise differ");
+    if (!other->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "the lane's context has no model loaded (replicate it first: infur_group_weights_broadcast)");
     st->lanes.push_back(other);
     other->streams.push_back(st);
     return INFUR_OK;
@@ -1675,21 +1639,40 @@ int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, ui
         sl.id = frame_id;
         sl.ow = ow;
         sl.oh = oh;
-        HIPCHK(c, hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
-        HIPCHK(c, hipEventRecord(sl.ev_h2d, st->s_h2d));
-        HIPCHK(c, hipStreamWaitEvent(lane->stream, sl.ev_h2d, 0));
+        // From here on work that reads / writes this slot's buffers is in flight.  The slot is handed out again by the next
+        // submit (head does not advance on failure) and slot_reserve may free its buffers, so every failing return below
+        // first waits for whatever was enqueued (quiesce).
+        auto quiesce = [&]() {
+            (void)hipStreamSynchronize(st->s_h2d);
+            (void)hipStreamSynchronize(lane->stream);
+            (void)hipStreamSynchronize(st->s_d2h);
+        };
+#define SUBMIT_CHK(expr)                                                                                                     \
+    do {                                                                                                                     \
+        hipError_t e__ = (expr);                                                                                             \
+        if (e__ != hipSuccess) {                                                                                             \
+            quiesce();                                                                                                       \
+            return fail(c, INFUR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__);        \
+        }                                                                                                                    \
+    } while (0)
+        SUBMIT_CHK(hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
+        SUBMIT_CHK(hipEventRecord(sl.ev_h2d, st->s_h2d));
+        SUBMIT_CHK(hipStreamWaitEvent(lane->stream, sl.ev_h2d, 0));
         uint8_t* d_rgba = (uint8_t*)sl.d_out;
         uint8_t* d_sc = d_rgba + rgba_bytes;
         uint32_t a = 0, b = 0;
         sl.status = infur_frame_advance_dev(lane, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
         if (sl.status != INFUR_OK) {
-            if (lane != c) c->err = lane->err;
+            const std::string msg = lane->err;  // (quiesce must not lose the message)
+            quiesce();
+            c->err = msg;
             return sl.status;
         }
-        HIPCHK(c, hipEventRecord(sl.ev_comp, lane->stream));
-        HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
-        HIPCHK(c, hipMemcpyAsync(sl.h_out, sl.d_out, rgba_bytes + sc_bytes, hipMemcpyDeviceToHost, st->s_d2h));
-        HIPCHK(c, hipEventRecord(sl.ev_done, st->s_d2h));
+        SUBMIT_CHK(hipEventRecord(sl.ev_comp, lane->stream));
+        SUBMIT_CHK(hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
+        SUBMIT_CHK(hipMemcpyAsync(sl.h_out, sl.d_out, rgba_bytes + sc_bytes, hipMemcpyDeviceToHost, st->s_d2h));
+        SUBMIT_CHK(hipEventRecord(sl.ev_done, st->s_d2h));
+#undef SUBMIT_CHK
         sl.busy = true;
         st->head++;
         return INFUR_OK;
@@ -1737,8 +1720,11 @@ int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const ui
         enter(c);
         if (!c || (n && (!frames || !ws || !hs || !rgba || !caps))) return INFUR_E_INVALID_ARG;
         if (n == 0) return INFUR_OK;
-        infur_stream* st = nullptr;
-        RETIF(infur_stream_create(c, 3, &st));
+        // The depth-3 ring lives as long as the context (6 pinned + device buffer pairs, 2 streams, 9 events: building it
+        // per call is a visible fixed cost when a batch is 8 frames per GPU -- BASELINE configs[3] at N = 8).  It is created
+        // on the first batch, shrinks with the frames (slot_reserve) and goes with infur_ctx_destroy.
+        if (!c->batch_ring) RETIF(infur_stream_create(c, 3, &c->batch_ring));
+        infur_stream* st = c->batch_ring;
         int32_t rc = INFUR_OK;
         uint32_t done = 0;
         auto collect_one = [&]() -> int32_t {
@@ -1759,9 +1745,12 @@ int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const ui
             if (rc == INFUR_OK) rc = infur_stream_submit(st, frames[i], ws[i], hs[i], factor, mode, i);
         }
         while (rc == INFUR_OK && infur_stream_pending(st) > 0) rc = collect_one();
-        const std::string keep = c->err;  // destroy() synchronises and must not lose the message
-        infur_stream_destroy(st);
-        c->err = keep;
+        if (rc != INFUR_OK) {  // frames may still be in flight into the caller's view of the ring: drop it, the next call builds a new one
+            const std::string keep = c->err;  // destroy() synchronises and must not lose the message
+            infur_stream_destroy(st);
+            c->batch_ring = nullptr;
+            c->err = keep;
+        }
         return rc;
     } catch (const std::bad_alloc&) {
         return fail(c, INFUR_E_CAPACITY, "out of host memory");

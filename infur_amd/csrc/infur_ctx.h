@@ -46,6 +46,9 @@ struct ConvLayer {
     void* d_wcat = nullptr;
     float* d_bcat = nullptr;
     float wcat_scale = 1.0f;
+    // f16 mode, conv3 of a block whose successor's conv1 can run in the same launch (conv1x1_b2b.hip): the weight matrix in
+    // the step-interleaved row order that kernel streams
+    void* d_w3i = nullptr;
 };
 
 struct ProfRec {
@@ -88,6 +91,7 @@ struct infur_ctx {
     // live infur_stream objects of this context: infur_ctx_destroy releases their device resources and
     // orphans them, so destroying context and streams in either order is safe
     std::vector<infur_stream*> streams;
+    infur_stream* batch_ring = nullptr;  // infur_batch_advance's depth-3 ring, created on first use, owned by the context
     std::vector<infur::Tensor> kept;  // keep_activations: output of every conv
 
     // staging for the host-pointer entry points

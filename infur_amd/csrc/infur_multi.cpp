@@ -10,7 +10,10 @@
 //   * the only exchange is the replication of the weights at load: ONE ncclBroadcast of the already repacked
 //     weight arena (the receivers neither re-read the file nor repack).  xGMI is point-to-point -- every GPU has
 //     its own link to the root -- so one broadcast of 141 MB is link-bound at about 1 ms.
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <pthread.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is resolved at run time (struct Rccl below)
+#include <sched.h>
 
 #include <condition_variable>
 #include <cstdarg>
@@ -28,6 +31,129 @@ using namespace infur;
 
 namespace {
 
+// ---- RCCL, resolved lazily ----
+// libinfur_hip.so does not link librccl: the single-GPU Processor path (Scale / Model / ColorCode, one context) must load
+// on a host without RCCL, or with a copy whose ABI differs from the one PyTorch bundles under the same soname.  The
+// first group that needs a communicator (>= 2 devices, or INFUR_FORCE_RCCL=1) dlopens it -- "librccl.so.1" binds to a copy
+// the process already mapped (torch's), else the system one -- and an unavailable library is an INFUR_E_RCCL of that
+// call, never a load failure of the whole library.  INFUR_RCCL_LIB overrides the name (tests point it at nothing).
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;  // why it is unavailable
+    bool ok() const { return handle != nullptr; }
+};
+
+const Rccl& rccl() {
+    static std::mutex mu;
+    static Rccl r;
+    static std::string tried;
+    std::lock_guard<std::mutex> lk(mu);
+    const char* over = getenv("INFUR_RCCL_LIB");
+    const std::string want = over && over[0] ? over : "";
+    if (r.handle || (!r.why.empty() && tried == want)) return r;  // (a failed attempt is retried only under a different name)
+    tried = want;
+    r = Rccl();
+    const char* names[] = {want.empty() ? "librccl.so.1" : want.c_str(), want.empty() ? "librccl.so" : nullptr};
+    void* h = nullptr;
+    for (const char* n : names) {
+        if (!n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        const char* de = dlerror();  // (dlerror clears its message: read it once)
+        r.why = de ? de : (std::string("dlopen(") + n + ") failed");
+    }
+    if (!h) {
+        if (r.why.empty()) r.why = "librccl.so.1 not found";
+        return r;
+    }
+    auto sym = [&](const char* n) -> void* {
+        void* p = dlsym(h, n);
+        if (!p && r.why.empty()) r.why = std::string("RCCL library lacks ") + n;
+        return p;
+    };
+    r.why.clear();
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!r.why.empty()) {
+        dlclose(h);
+        return r;
+    }
+    r.handle = h;
+    return r;
+}
+
+// test hook (tests/test_gpu_multi.py): INFUR_RCCL_INJECT_FAIL=broadcast makes the next collective report
+// ncclInternalError without touching the communicator -- the error path (arenas released, every context keeps its old
+// model, INFUR_E_RCCL with the message) cannot be reached otherwise on a healthy box.  Read on every call.
+bool inject_fail(const char* what) {
+    const char* e = getenv("INFUR_RCCL_INJECT_FAIL");
+    return e && strcmp(e, what) == 0;
+}
+
+// ---- worker placement ----
+// A group worker moves its slice of the batch through pageable -> pinned memcpys (infur_stream_submit / collect): 1.45
+// GB/s per 100 frames/s of 1080p, eight of them on a two-socket host.  Each worker is therefore pinned to the CPUs of the
+// NUMA node its GPU hangs off (PCI bus id -> /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/nodeN/
+// cpulist), so that its staging copies and its pinned buffers (first touch) stay on that socket.  INFUR_NO_NUMA_PIN=1
+// leaves the threads where the scheduler puts them; a host without the sysfs files (containers) does the same silently.
+int numa_node_of_device(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return -1;
+    for (char* p = bus; *p; p++)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');  // sysfs spells the id in lower case
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+// "0-15,128-143" -> cpu set; false when the list is missing or empty
+bool cpus_of_node(int node, cpu_set_t* set) {
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    CPU_ZERO(set);
+    int n = 0;
+    for (const char* p = buf; *p;) {
+        char* end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            if (end == p + 1) break;
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0) {
+                CPU_SET((int)c, set);
+                n++;
+            }
+        while (*p == ',' || *p == ' ' || *p == '\n') p++;
+    }
+    return n > 0;
+}
+
 // one host thread bound to one context: runs the jobs posted to it, one at a time
 struct Worker {
     std::thread th;
@@ -36,8 +162,16 @@ struct Worker {
     std::function<int32_t()> job;
     bool has_job = false, done = true, quit = false;
     int32_t rc = INFUR_OK;
+    int numa = -1;  // node the thread is pinned to, -1 = not pinned
 
     void start(int device) {
+        const char* no = getenv("INFUR_NO_NUMA_PIN");
+        int node = -1;
+        cpu_set_t set;
+        if (!(no && no[0] && no[0] != '0')) {
+            node = numa_node_of_device(device);
+            if (node >= 0 && !cpus_of_node(node, &set)) node = -1;
+        }
         th = std::thread([this, device] {
             (void)hipSetDevice(device);
             std::unique_lock<std::mutex> lk(mu);
@@ -60,6 +194,7 @@ struct Worker {
                 cv.notify_all();
             }
         });
+        if (node >= 0 && pthread_setaffinity_np(th.native_handle(), sizeof set, &set) == 0) numa = node;
     }
     void post(std::function<int32_t()> j) {
         std::lock_guard<std::mutex> lk(mu);
@@ -109,13 +244,6 @@ int32_t gfail(infur_group* g, int32_t code, const char* fmt, ...) {
     return code;
 }
 
-#define NCCLCHK(g, expr)                                                                               \
-    do {                                                                                               \
-        ncclResult_t r__ = (expr);                                                                     \
-        if (r__ != ncclSuccess)                                                                        \
-            return gfail((g), INFUR_E_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r__), __FILE__, __LINE__); \
-    } while (0)
-
 #define GHIPCHK(g, expr)                                                                               \
     do {                                                                                               \
         hipError_t e__ = (expr);                                                                       \
@@ -155,6 +283,7 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
         L.d_u = (float*)rebase(L.d_u);
         L.d_wcat = rebase(L.d_wcat);
         L.d_bcat = (float*)rebase(L.d_bcat);
+        L.d_w3i = rebase(L.d_w3i);
     }
     dst->d_weights = d_weights;
     dst->weight_bytes = root->weight_bytes;
@@ -165,6 +294,8 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
     dst->info = root->info;
     dst->info.n_outputs = 1 + ((root->has_aux && dst->opt.compute_aux) ? 1 : 0);
     if (dst->info.n_outputs < 2) dst->info.output_names[1][0] = 0;
+    // (a root created with compute_aux = 0 reports one output and no second name; a context that does evaluate the head names it)
+    else if (!dst->info.output_names[1][0]) snprintf(dst->info.output_names[1], sizeof dst->info.output_names[1], "aux");
     dst->loaded = true;
 }
 
@@ -188,11 +319,21 @@ int32_t infur_group_create(infur_ctx* const* ctxs, uint32_t n_ctx, infur_group**
         for (infur_ctx* c : g->ctxs)
             if (rank_of_device(g, c->device) < 0) g->devs.push_back(c->device);
         if (g->devs.size() >= 2 || force_rccl()) {
+            const Rccl& R = rccl();
+            if (!R.ok()) {
+                const int32_t rc = ctx_fail(ctxs[0], INFUR_E_RCCL, "a group over %zu devices needs RCCL, which is not available: %s",
+                                            g->devs.size(), R.why.c_str());
+                delete g;
+                return rc;
+            }
             g->comms.resize(g->devs.size());
-            const ncclResult_t r = ncclCommInitAll(g->comms.data(), (int)g->devs.size(), g->devs.data());
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            const ncclResult_t r = inject_fail("init") ? ncclInternalError : R.CommInitAll(g->comms.data(), (int)g->devs.size(), g->devs.data());
+            if (prev >= 0) (void)hipSetDevice(prev);  // (ncclCommInitAll visits every device)
             if (r != ncclSuccess) {
                 const int32_t rc = ctx_fail(ctxs[0], INFUR_E_RCCL, "ncclCommInitAll over %zu devices failed: %s", g->devs.size(),
-                                            ncclGetErrorString(r));
+                                            R.GetErrorString(r));
                 g->comms.clear();
                 delete g;
                 return rc;
@@ -217,9 +358,14 @@ void infur_group_destroy(infur_group* g) {
         w->stop();
         delete w;
     }
-    for (size_t r = 0; r < g->comms.size(); r++) {
-        (void)hipSetDevice(g->devs[r]);
-        (void)ncclCommDestroy(g->comms[r]);
+    if (!g->comms.empty()) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        for (size_t r = 0; r < g->comms.size(); r++) {
+            (void)hipSetDevice(g->devs[r]);
+            (void)rccl().CommDestroy(g->comms[r]);
+        }
+        if (prev >= 0) (void)hipSetDevice(prev);
     }
     delete g;
 }
@@ -227,8 +373,21 @@ void infur_group_destroy(infur_group* g) {
 const char* infur_group_last_error(const infur_group* g) { return g ? g->err.c_str() : "null group"; }
 uint32_t infur_group_size(const infur_group* g) { return g ? (uint32_t)g->ctxs.size() : 0; }
 uint32_t infur_group_uses_rccl(const infur_group* g) { return g && !g->comms.empty() ? 1u : 0u; }
+int32_t infur_group_worker_numa_node(const infur_group* g, uint32_t i) { return g && i < g->workers.size() ? g->workers[i]->numa : -1; }
 
+static int32_t group_weights_broadcast_body(infur_group* g, uint32_t root);
+
+// The body visits every context's device (hipMalloc and launches follow the calling thread's current device): the caller's
+// own current device -- a torch or HIP host has one -- is put back whatever happens inside.
 static int32_t group_weights_broadcast_impl(infur_group* g, uint32_t root) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    const int32_t rc = group_weights_broadcast_body(g, root);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
+
+static int32_t group_weights_broadcast_body(infur_group* g, uint32_t root) {
     if (!g || root >= g->ctxs.size()) return INFUR_E_INVALID_ARG;
     infur_ctx* rc = g->ctxs[root];
     if (!rc->loaded || !rc->d_weights) return gfail(g, INFUR_E_MODEL_NOT_LOADED, "root context %u has no model to broadcast", root);
@@ -273,16 +432,26 @@ static int32_t group_weights_broadcast_impl(infur_group* g, uint32_t root) {
 
     const int root_rank = rank_of_device(g, rc->device);
     if (status == INFUR_OK && !g->comms.empty() && g->devs.size() >= 2) {
-        // ---- the collective: one broadcast over all devices, every rank's call inside one group ----
-        ncclResult_t r = ncclGroupStart();
+        // ---- the collective: one broadcast over all devices ----
+        // RCCL's rules for ONE thread driving SEVERAL devices (single-process multi-device): the per-rank calls of one
+        // collective must sit inside one ncclGroupStart / ncclGroupEnd -- outside a group the first rank's call would block
+        // waiting for peers this same thread has not called yet; every call names its own rank's communicator, runs with
+        // that rank's device current (ctx_enter) and is enqueued on a stream OF that device (the leader context's); the send
+        // buffer argument matters on the root only, where send == recv == the loaded arena (in place).  ncclGroupEnd
+        // launches them all; completion is per stream, waited for below.
+        const Rccl& R = rccl();
+        ncclResult_t r = inject_fail("broadcast") ? ncclInternalError : R.GroupStart();
+        const bool started = r == ncclSuccess;
         for (size_t k = 0; k < g->devs.size() && r == ncclSuccess; k++) {
             infur_ctx* c = g->ctxs[leader[k]];
             ctx_enter(c);
-            r = ncclBroadcast(rc->d_weights, arena[leader[k]], bytes, ncclUint8, root_rank, g->comms[k], c->stream);
+            r = R.Broadcast(rc->d_weights, arena[leader[k]], bytes, ncclUint8, root_rank, g->comms[k], c->stream);
         }
-        const ncclResult_t r2 = ncclGroupEnd();
-        if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) status = gfail(g, INFUR_E_RCCL, "ncclBroadcast of %zu weight bytes failed: %s", bytes, ncclGetErrorString(r));
+        if (started) {
+            const ncclResult_t r2 = R.GroupEnd();
+            if (r == ncclSuccess) r = r2;
+        }
+        if (r != ncclSuccess) status = gfail(g, INFUR_E_RCCL, "ncclBroadcast of %zu weight bytes failed: %s", bytes, R.GetErrorString(r));
         for (size_t k = 0; k < g->devs.size() && status == INFUR_OK; k++) {
             infur_ctx* c = g->ctxs[leader[k]];
             ctx_enter(c);
@@ -298,8 +467,10 @@ static int32_t group_weights_broadcast_impl(infur_group* g, uint32_t root) {
         infur_ctx* c = g->ctxs[i];
         ctx_enter(c);
         if (!g->comms.empty() && g->devs.size() == 1) {
-            const ncclResult_t r = ncclBroadcast(arena[leader[k]], arena[i], bytes, ncclUint8, 0, g->comms[0], c->stream);
-            if (r != ncclSuccess) status = gfail(g, INFUR_E_RCCL, "ncclBroadcast (one rank) failed: %s", ncclGetErrorString(r));
+            const Rccl& R = rccl();
+            const ncclResult_t r = inject_fail("broadcast") ? ncclInternalError
+                                                            : R.Broadcast(arena[leader[k]], arena[i], bytes, ncclUint8, 0, g->comms[0], c->stream);
+            if (r != ncclSuccess) status = gfail(g, INFUR_E_RCCL, "ncclBroadcast (one rank) failed: %s", R.GetErrorString(r));
         } else {
             he = hipMemcpyAsync(arena[i], arena[leader[k]], bytes, hipMemcpyDeviceToDevice, c->stream);
             if (he != hipSuccess) status = gfail(g, INFUR_E_HIP, "device-to-device weight copy: %s", hipGetErrorString(he));

@@ -63,7 +63,7 @@ hipError_t launch_conv1x1_areg(const ConvArgs& a, hipStream_t s);
 // Bit-identical to the two launches it replaces.
 struct B2bArgs {
     const void* in;    // [M][C2] f16
-    const void* w3;    // [4*C2][C2] f16
+    const void* w3;    // [4*C2][C2] f16 in the step-interleaved row order of launch_b2b_pack_w3
     const float* b3;   // [4*C2]
     const void* res;   // [M][4*C2] f16
     void* y;           // [M][4*C2] f16
@@ -73,6 +73,8 @@ struct B2bArgs {
     int M, C2, relu1, relu2;
 };
 bool conv1x1_b2b_valid(const B2bArgs& a);
+// one-off at model load: the conv3 weight matrix ([4*C2][C2] f16, plain row order) in the row order the kernel streams
+hipError_t launch_b2b_pack_w3(const void* w3, void* w3i, int C2, hipStream_t s);
 hipError_t launch_conv1x1_b2b(const B2bArgs& a, hipStream_t s);
 
 // Winograd F(mt x mt, 3x3), mt = 2 or 4, for stride-1 3x3 convs (f32, any dilation d with pad = d);

@@ -488,6 +488,10 @@ class Group:
     def uses_rccl(self) -> bool:
         return bool(self.L.infur_group_uses_rccl(self.g))
 
+    def worker_numa_nodes(self) -> List[int]:
+        """NUMA node each worker thread is pinned to (-1: not pinned)"""
+        return [int(self.L.infur_group_worker_numa_node(self.g, i)) for i in range(len(self))]
+
     def __len__(self):
         return self.L.infur_group_size(self.g)
 

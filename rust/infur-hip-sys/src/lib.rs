@@ -115,6 +115,7 @@ extern "C" {
     pub fn infur_group_last_error(g: *const infur_group) -> *const c_char;
     pub fn infur_group_size(g: *const infur_group) -> u32;
     pub fn infur_group_uses_rccl(g: *const infur_group) -> u32;
+    pub fn infur_group_worker_numa_node(g: *const infur_group, i: u32) -> i32;
     pub fn infur_group_weights_broadcast(g: *mut infur_group, root: u32) -> i32;
     pub fn infur_group_batch_advance(g: *mut infur_group, frames: *const *const u8, ws: *const u32, hs: *const u32,
                                      n: u32, factor: f32, mode: u32, rgba: *const *mut u8, caps: *const usize,

@@ -22,6 +22,17 @@ pub trait Processor {
     fn control(&mut self, cmd: Self::Command) -> Result<&mut Self, Self::ControlError>;
     fn advance(&mut self, inp: &Self::Input, out: &mut Self::Output) -> Self::ProcessResult;
     fn is_dirty(&self) -> bool;
+    /// Provided method of the reference's trait (`infur/src/processing.rs:53-59`): run the node on default input and
+    /// output -- how the `Proc` loop drives the final node of the graph (`main.rs:85`).
+    fn generate(&mut self) -> Self::ProcessResult
+    where
+        Self::Input: Default,
+        Self::Output: Default,
+    {
+        let inp = <Self::Input as Default>::default();
+        let mut out = <Self::Output as Default>::default();
+        self.advance(&inp, &mut out)
+    }
 }
 
 pub struct Frame {

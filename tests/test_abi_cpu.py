@@ -104,3 +104,16 @@ def test_product_path_does_not_import_the_oracle():
                     if re.search(r"(import\s+oracle|from\s+oracle|infur_oracle\.h|libinfur_oracle)", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_library_does_not_link_rccl():
+    """librccl is resolved with dlopen by the first group that needs a communicator (infur_multi.cpp), so that the
+    single-GPU Processor path loads on a host without RCCL -- the library's only NEEDED accelerator runtime is libamdhip64"""
+    import subprocess
+
+    from infur_amd import _lib
+
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    needed = [ln.split("[")[1].rstrip("]") for ln in out.splitlines() if "(NEEDED)" in ln]
+    assert any(n.startswith("libamdhip64") for n in needed), needed
+    assert not any("rccl" in n or "nccl" in n or "torch" in n for n in needed), needed

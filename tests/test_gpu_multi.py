@@ -309,3 +309,171 @@ def test_configs3_batch64_through_the_group_on_one_gpu(blob50):
     finally:
         for c in ctxs:
             c.close()
+
+
+# ---------------------------------------------------------------- round 3: the multi-GPU host path, hardened without hardware
+def test_rccl_is_resolved_lazily_and_its_absence_is_an_error_of_the_group_only(tmp_path):
+    """libinfur_hip.so does not link librccl: with RCCL unobtainable (INFUR_RCCL_LIB names nothing) the
+    single-context Processor path works, a one-device group works (device-to-device copies), and only a group that
+    needs a communicator fails -- with INFUR_E_RCCL and the loader's message, at infur_group_create."""
+    script = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+from infur_amd import _lib, weights as W
+from infur_amd.processors import Context, FramePath, Group, InfurError, Model, ModelCmd
+import os
+blob = W.synth_blob()
+a, b = Context(device=0), Context(device=0)
+Model(a).control(ModelCmd.LoadBlob(blob))
+fr = W.synth_frame(48, 64)
+ref, _ = FramePath(a).advance(fr, 1.0)                  # single-GPU path: no RCCL anywhere
+with Group([a, b]) as g:                               # one device: no communicator needed
+    assert not g.uses_rccl
+    g.weights_broadcast(0)
+assert (FramePath(b).advance(fr, 1.0)[0] == ref).all()
+os.environ["INFUR_FORCE_RCCL"] = "1"
+try:
+    Group([a, b])
+    raise SystemExit("a group that needs RCCL was created without it")
+except InfurError as e:
+    assert e.code == _lib.E_RCCL and "not available" in str(e), str(e)
+print("ok")
+"""
+    env = dict(os.environ)
+    env["INFUR_RCCL_LIB"] = str(tmp_path / "no_such_librccl.so")
+    env.pop("INFUR_FORCE_RCCL", None)
+    r = subprocess.run([sys.executable, "-c", script, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_injected_rccl_failure_leaves_every_context_as_it_was(blob50, monkeypatch):
+    """INFUR_E_RCCL from the collective (injected: INFUR_RCCL_INJECT_FAIL=broadcast; a healthy box never produces one):
+    the call reports it with RCCL's message, the receive arenas are released, the receiving context keeps what it had (here:
+    nothing, then a model of its own) and the same group succeeds once the fault is gone."""
+    monkeypatch.setenv("INFUR_FORCE_RCCL", "1")
+    a, b = Context(device=0), Context(device=0)
+    try:
+        Model(a).control(ModelCmd.LoadBlob(blob50))
+        fr = W.synth_frame(48, 64, index=2)
+        ref, _ = FramePath(a).advance(fr, 1.0)
+        with Group([a, b]) as g:
+            assert g.uses_rccl
+            monkeypatch.setenv("INFUR_RCCL_INJECT_FAIL", "broadcast")
+            with pytest.raises(InfurError) as e:
+                g.weights_broadcast(0)
+            assert e.value.code == _lib.E_RCCL and "ncclBroadcast" in str(e.value)
+            assert Model(b).get_info() is None  # nothing half-adopted
+            assert (FramePath(a).advance(fr, 1.0)[0] == ref).all()  # the root is untouched
+            mb = Model(b).control(ModelCmd.LoadBlob(W.synth_blob(aux=False)))  # b gets a model of its own ...
+            with pytest.raises(InfurError):
+                g.weights_broadcast(0)
+            assert mb.get_info().output_names == ["out"]  # ... and keeps it through a second failed broadcast
+            monkeypatch.delenv("INFUR_RCCL_INJECT_FAIL")
+            g.weights_broadcast(0)
+            assert Model(b).get_info().output_names == ["out", "aux"]
+            assert (FramePath(b).advance(fr, 1.0)[0] == ref).all()
+        monkeypatch.setenv("INFUR_RCCL_INJECT_FAIL", "init")
+        with pytest.raises(InfurError) as e:
+            Group([a, b])
+        assert e.value.code == _lib.E_RCCL and "ncclCommInitAll" in str(e.value)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_group_workers_are_pinned_to_their_gpus_numa_node(blob50, monkeypatch):
+    """every worker reports the NUMA node it is pinned to: the node sysfs gives for the GPU's PCI address, or -1 where the
+    host exposes none (containers); INFUR_NO_NUMA_PIN=1 switches the pinning off; results do not depend on it"""
+    import torch
+
+    a, b = Context(device=0), Context(device=0)
+    try:
+        Model(a).control(ModelCmd.LoadBlob(blob50))
+        imgs = [W.synth_frame(48, 64, index=i) for i in range(4)]
+        with Group([a, b]) as g:
+            nodes = g.worker_numa_nodes()
+            g.weights_broadcast(0)
+            got = g.advance_batch(imgs, 1.0)
+        pr = torch.cuda.get_device_properties(0)
+        path = f"/sys/bus/pci/devices/{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0/numa_node"
+        want = int(open(path).read()) if os.path.exists(path) else -1
+        print("worker NUMA nodes", nodes, "sysfs says", want)
+        assert len(nodes) == 2 and nodes[0] == nodes[1] and nodes[0] >= -1
+        if want >= 0 and os.path.exists(f"/sys/devices/system/node/node{want}/cpulist"):
+            assert nodes[0] == want
+        monkeypatch.setenv("INFUR_NO_NUMA_PIN", "1")
+        with Group([a, b]) as g:
+            assert g.worker_numa_nodes() == [-1, -1]
+            again = g.advance_batch(imgs, 1.0)
+        for x, y in zip(got, again):
+            assert (x == y).all()
+    finally:
+        a.close()
+        b.close()
+
+
+def test_batch_ring_is_persistent_and_follows_the_frame_size(blob50):
+    """infur_batch_advance keeps its depth-3 ring on the context: a second batch allocates nothing new (device memory
+    unchanged), a batch of much smaller frames shrinks it, a failing batch drops it and the next one works again"""
+    import torch
+
+    with Context(device=0) as c:
+        Model(c).control(ModelCmd.LoadBlob(blob50))
+        fp = FramePath(c)
+        big = [W.synth_frame(270, 480, index=i) for i in range(5)]
+        small = [W.synth_frame(32, 48, index=i) for i in range(5)]
+        ref_big = [fp.advance(f, 1.0)[0] for f in big]
+        ref_small = [fp.advance(f, 1.0)[0] for f in small]
+        assert all((x == y).all() for x, y in zip(fp.advance_batch(big, 1.0), ref_big))
+        free0 = torch.cuda.mem_get_info(0)[0]
+        for _ in range(3):
+            assert all((x == y).all() for x, y in zip(fp.advance_batch(big, 1.0), ref_big))
+        assert torch.cuda.mem_get_info(0)[0] == free0, "a repeated batch of the same size allocated device memory"
+        for _ in range(6):  # (the activation arena trims itself after a few frames of the new size as well)
+            assert all((x == y).all() for x, y in zip(fp.advance_batch(small, 1.0), ref_small))
+        assert torch.cuda.mem_get_info(0)[0] > free0, "the ring kept its 480x270 buffers for 48x32 frames"
+        # a failing batch (mask buffer of frame 1 too small) leaves the context usable
+        outs = [np.empty_like(r) for r in ref_small]
+        n = len(small)
+        fr = (C.c_void_p * n)(*[i.ctypes.data for i in small])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ws = (C.c_uint32 * n)(*[i.shape[1] for i in small])
+        hs = (C.c_uint32 * n)(*[i.shape[0] for i in small])
+        caps = (C.c_size_t * n)(*[o.nbytes if k != 1 else 4 for k, o in enumerate(outs)])
+        assert c.L.infur_batch_advance(c.h, fr, ws, hs, n, 1.0, 0, op, caps, None, None) == _lib.E_CAPACITY
+        assert all((x == y).all() for x, y in zip(fp.advance_batch(small, 1.0), ref_small))
+
+
+def test_stream_lane_must_match_the_streams_arithmetic(blob50):
+    """a lane with another Winograd tile (or no model yet) would make odd and even frames differ"""
+    a, b, d = Context(device=0), Context(device=0, winograd_tile=4), Context(device=0)
+    try:
+        Model(a).control(ModelCmd.LoadBlob(blob50))
+        Model(b).control(ModelCmd.LoadBlob(blob50))
+        sp = StreamPath(a, depth=3)
+        with pytest.raises(InfurError) as e:
+            sp.add_lane(b)
+        assert e.value.code == _lib.E_INVALID_ARG and "winograd_tile" in str(e.value)
+        with pytest.raises(InfurError) as e:
+            sp.add_lane(d)  # same options, but nothing loaded
+        assert e.value.code == _lib.E_MODEL_NOT_LOADED
+        sp.close()
+    finally:
+        for c in (a, b, d):
+            c.close()
+
+
+def test_bench_self_launches_eight_ranks_on_one_gpu(tmp_path):
+    """the driver's N = 8 command, `python bench.py --gpus 8`, on the 1-GPU box: eight ranks share device 0 over gloo
+    (tiny frames), the line reports n_gpus == 8 and all ranks agree on frame 0's mask"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "1", "--frames-per-step", "1", "--contexts-per-gpu", "1", "--width", "160", "--height", "120",
+                        "--no-cpu-baseline", "--no-split", "--no-side", "--no-profile"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 8 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["ranks_agree_on_frame0_mask"] is True and j["config"]["oversubscribed"] is True
