@@ -671,6 +671,8 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     // own slice of the (now idle) operand LDS and stores / loads the residual with 16 lanes on the
     // 256 contiguous bytes of a pixel: 8 full lines per instruction, a quarter of the TA work.
     OutT* out = reinterpret_cast<OutT*>(static_cast<char*>(a.out) + (size_t)bidx * a.out_bs);
+    // split modes: one accumulator scale per launch, or one per batched problem (the Winograd planes carry their own weight scale)
+    const float acc_scale = a.acc_scale_b ? a.acc_scale_b[bidx] : a.acc_scale;
     const bool has_bias = a.bias != nullptr;
     const bool vec_ok = (a.Cout & 3) == 0;
 #ifdef KTRACE
@@ -703,7 +705,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                 for (int g = 0; g < 4; g++) {
                     float4 v = make_float4(acc[i][jj][4 * g + 0], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
                     if constexpr (SPLIT) {
-                        v.x *= a.acc_scale; v.y *= a.acc_scale; v.z *= a.acc_scale; v.w *= a.acc_scale;
+                        v.x *= acc_scale; v.y *= acc_scale; v.z *= acc_scale; v.w *= acc_scale;
                     }
                     *reinterpret_cast<float4*>(stage + (lane & 31) * ROWB + (jj * 32 + 8 * g + 4 * (lane >> 5)) * 4) = v;
                 }
@@ -788,7 +790,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                 for (int t = 0; t < 4; t++) {
                     if (n + t >= a.Cout) break;
                     float x = acc[i][j][4 * g + t];
-                    if constexpr (SPLIT) x *= a.acc_scale;
+                    if constexpr (SPLIT) x *= acc_scale;
                     x += has_bias ? a.bias[n + t] : 0.f;
                     if (res) x += (float)res[o + t];
                     if (a.relu) x = fmaxf(x, 0.f);

@@ -308,20 +308,23 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // 2^-16 of the largest -- and replace them in place by (hi, lo) f16 pairs.  The stem is not a GEMM.
 int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
     const size_t n = g.size();
+    const size_t P = (size_t)wino_planes(c);
+    // per conv: [0] max |w|, [1] max |conv3 ++ downsample matrix|, [2 .. 2 + P) max |U| of every Winograd plane
+    const size_t per = 2 + P;
     float* d_max = nullptr;
-    HIPCHK(c, hipMalloc(&d_max, 2 * n * sizeof(float)));
-    hipError_t e = hipMemsetAsync(d_max, 0, 2 * n * sizeof(float), c->stream);
+    HIPCHK(c, hipMalloc(&d_max, per * n * sizeof(float)));
+    hipError_t e = hipMemsetAsync(d_max, 0, per * n * sizeof(float), c->stream);
     for (size_t i = 0; i < n && e == hipSuccess; i++) {
         const ConvLayer& L = g[i];
-        e = launch_absmax((const float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, d_max + 2 * i, c->stream);
+        e = launch_absmax((const float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, d_max + per * i, c->stream);
         if (L.role == 's') continue;  // the stem keeps f32 weights (its kernel splits them while it stages them): scale only
-        if (e == hipSuccess && L.d_u) e = launch_absmax(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, d_max + 2 * i + 1, c->stream);
-        // (a 1x1 conv has no Winograd weights: the second slot takes the conv3 ++ downsample matrix)
+        for (size_t pl = 0; pl < P && e == hipSuccess && L.d_u; pl++)
+            e = launch_absmax(L.d_u + pl * (size_t)L.cout * L.cin, (size_t)L.cout * L.cin, d_max + per * i + 2 + pl, c->stream);
         if (e == hipSuccess && L.d_wcat)
-            e = launch_absmax((const float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), d_max + 2 * i + 1, c->stream);
+            e = launch_absmax((const float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), d_max + per * i + 1, c->stream);
     }
-    std::vector<float> mx(2 * n, 0.0f);
-    if (e == hipSuccess) e = hipMemcpyAsync(mx.data(), d_max, 2 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    std::vector<float> mx(per * n, 0.0f);
+    if (e == hipSuccess) e = hipMemcpyAsync(mx.data(), d_max, per * n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_max);
     HIPCHK(c, e);
@@ -331,15 +334,31 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
     };
     for (size_t i = 0; i < n; i++) {
         ConvLayer& L = g[i];
-        L.w_scale = pow2_for(mx[2 * i]);
+        L.w_scale = pow2_for(mx[per * i]);
         if (L.role == 's') continue;
         HIPCHK(c, launch_split_weights((float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, L.w_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         if (L.d_u) {
-            L.u_scale = pow2_for(mx[2 * i + 1]);
-            HIPCHK(c, launch_split_weights(L.d_u, (size_t)wino_planes(c) * L.cout * L.cin, L.u_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
+            // Every Winograd plane gets its OWN power-of-two scale: U = G g G^T mixes G's entries (1 ... 1/180 for F(6x6)), so the
+            // planes' magnitudes span four decades before the weights' own spread; under one scale per layer the small planes
+            // lost their lo halves to f16 underflow -- invisible on uniform synthetic weights (4-6e-6), 9e-3 .. 1.6e-2 on
+            // heavy-tailed ones with per-channel scales over three decades (tests/test_gpu_hostile.py).  The GEMM of plane p
+            // multiplies its accumulators by d_uacc[p] = 1 / (activation scale * scale of plane p).
+            const int mt = wino_mt(c);
+            const float a_scale = mt == 6 ? 0.0625f : (mt == 4 ? 0.125f : 1.0f);  // = split_wino_scale(mt)
+            std::vector<float> acc(P);
+            float smin = 0.f;
+            for (size_t pl = 0; pl < P; pl++) {
+                const float sc = pow2_for(mx[per * i + 2 + pl]);
+                acc[pl] = 1.0f / (a_scale * sc);
+                if (pl == 0 || sc < smin) smin = sc;
+                HIPCHK(c, launch_split_weights(L.d_u + pl * (size_t)L.cout * L.cin, (size_t)L.cout * L.cin, sc, ctx_fp8x(c) ? 1 : 0, c->stream));
+            }
+            L.u_scale = smin;
+            HIPCHK(c, hipMemcpyAsync(L.d_uacc, acc.data(), P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));  // (acc goes out of scope)
         }
         if (L.d_wcat) {
-            L.wcat_scale = pow2_for(mx[2 * i + 1]);
+            L.wcat_scale = pow2_for(mx[per * i + 1]);
             HIPCHK(c, launch_split_weights((float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), L.wcat_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         }
     }
@@ -372,7 +391,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         const ConvLayer& L = g[i];
         const size_t wn = (size_t)L.cout * L.cin * L.k * L.k * 4, bn = (size_t)L.cout * 4;
         total += align_up(wn, 256) + align_up(bn, 256);  // upper bound (f16 weights take half)
-        if (wino_eligible(c, L)) total += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
+        if (wino_eligible(c, L)) total += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256) + align_up((size_t)wino_planes(c) * 4, 256);
         if (L.role == '3' && i + 1 < n && g[i + 1].role == 'd')
             total += align_up((size_t)L.cout * (L.cin + g[i + 1].cin) * 4, 256) + align_up(bn, 256);
         if (i + 1 < n && b2b_candidate(c, L, g[i + 1])) total += align_up((size_t)L.cout * L.cin * 2, 256);
@@ -405,6 +424,8 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         if (wino_eligible(c, L)) {
             L.d_u = (float*)((uint8_t*)d_weights + off);
             off += align_up((size_t)wino_planes(c) * L.cout * L.cin * 4, 256);
+            L.d_uacc = (float*)((uint8_t*)d_weights + off);  // per-plane accumulator scales (split modes; split_weights fills them)
+            off += align_up((size_t)wino_planes(c) * 4, 256);
             HIPCHK(c, launch_wino_weights(src_w, L.cout, L.cin, wino_mt(c), L.d_u, c->stream));
         }
     }
@@ -577,6 +598,7 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         if (mode == INFUR_DTYPE_F32_SPLIT) {
             g.a_scale = split_wino_scale(mt);
             g.acc_scale = 1.0f / (g.a_scale * L.u_scale);
+            g.acc_scale_b = L.d_uacc;  // one scale per Winograd plane
         }
         int gcfg = -1;
         RETIF(pick_cfg(c, g, conv_mode(c), 1, &gcfg));

@@ -41,6 +41,7 @@ struct ConvLayer {
     float* d_u = nullptr;  // Winograd-domain weights U[(mt+2)^2][cout][cin] (f32 stride-1 3x3 convs only)
     // INFUR_DTYPE_F32_SPLIT: d_w / d_u hold f16 (hi, lo) pairs of w * w_scale / u * u_scale (powers of two)
     float w_scale = 1.0f, u_scale = 1.0f;
+    float* d_uacc = nullptr;  // split modes: per Winograd plane, 1 / (activation scale * that plane's weight scale)
     // conv3 of a stage's first block: its weights and the downsample branch's side by side ([cout][cin + ds.cin],
     // context dtype), the two biases summed -- the two-source GEMM of run_conv_dual
     void* d_wcat = nullptr;

@@ -284,6 +284,7 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
         L.d_wcat = rebase(L.d_wcat);
         L.d_bcat = (float*)rebase(L.d_bcat);
         L.d_w3i = rebase(L.d_w3i);
+        L.d_uacc = (float*)rebase(L.d_uacc);
     }
     dst->d_weights = d_weights;
     dst->weight_bytes = root->weight_bytes;

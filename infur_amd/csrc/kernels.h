@@ -27,6 +27,10 @@ struct ConvArgs {
     // load time (launch_split_weights), and the accumulators are multiplied by acc_scale =
     // 1 / (a_scale * weight scale) before bias / residual / ReLU.  Powers of two: exact.
     float a_scale = 1.0f, acc_scale = 1.0f;
+    // batched use in the split modes: one accumulator scale PER PROBLEM (device array of `batch` floats) instead of acc_scale --
+    // the (m+2)^2 Winograd-domain weight planes differ by orders of magnitude (G's entries run from 1/180 to 1), so each
+    // plane is scaled into the f16 pair's range on its own
+    const float* acc_scale_b = nullptr;
     // mode 2, optional: atomicMax target (bit pattern of a non-negative float) for max |output| of this launch --
     // the range monitor of the split mode (infur_split_range)
     unsigned* amax = nullptr;

@@ -239,6 +239,129 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ---- the same two transforms with 16-BYTE accesses for F(6x6) (round 3) ----
+// The per-thread forms above hold a whole (m+2)^2 patch per lane, which for F(6x6) fits the register file only with 8-byte
+// vectors (64 vectors) -- and 8-byte global accesses run at 0.54-0.70 of the 16-byte rate on this part
+// (MI355X_MICROARCH.md).  Here a workgroup owns one tile x 128 channels and splits the two 1-D passes between its
+// threads through LDS: thread (b, cv) loads column b of the patch (8 x 16 bytes, 32 lanes = the 512 contiguous bytes of
+// 128 channels), runs the column pass and parks its 8 results in LDS; after one barrier thread (a, cv) reads row a back,
+// runs the row pass and stores 8 x 16 bytes.  8 vectors per lane instead of 64 (~50 VGPRs: 5 workgroups per CU), every
+// global access 16 bytes and 512-byte contiguous per 32 lanes.  Same 1-D functions on the same values in the same order:
+// bit-identical to the per-thread forms (tests/test_gpu_parity.py runs both).
+constexpr int WL_CV = 32;  // float4 channel vectors per unit = 128 channels
+
+template <int MT>
+__global__ void __launch_bounds__(256)
+    wino_input_lds_kernel(const float* __restrict__ in, WinoGeom g, int C, int T, float* __restrict__ V, unsigned* __restrict__ amax) {
+    constexpr int AL = MT + 2;
+    static_assert(AL <= 8, "one row / column per 32-lane group of a 256-thread workgroup");
+    __shared__ f32x4w lds[AL * AL * WL_CV];
+    const int tid = threadIdx.x, q = tid >> 5, cvl = tid & 31;  // q: column in pass 1, row in pass 2
+    const int cgroups = C / (4 * WL_CV);
+    const size_t units = (size_t)T * cgroups;
+    const size_t plane = (size_t)T * C;
+    float vmax = 0.f;
+    for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const int cg = (int)(u % cgroups), t = (int)(u / cgroups);
+        const int c0 = cg * 4 * WL_CV + cvl * 4;
+        int ry, rx, ty, tx;
+        tile_coords(g, t, ry, rx, ty, tx);
+        if (q < AL) {
+            const int x = g.d * (MT * tx - 1 + q) + rx;
+            f32x4w d[AL], col[AL];
+#pragma unroll
+            for (int a = 0; a < AL; a++) {
+                const int y = g.d * (MT * ty - 1 + a) + ry;
+                f32x4w v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
+                    v = *reinterpret_cast<const f32x4w*>(in + ((size_t)y * g.W + x) * C + c0);
+                d[a] = v;
+            }
+            bt_1d<MT, 1, 1>(d, col);  // columns: B^T d
+#pragma unroll
+            for (int a = 0; a < AL; a++) lds[(a * AL + q) * WL_CV + cvl] = col[a];
+        }
+        __syncthreads();
+        if (q < AL) {
+            f32x4w rin[AL], row[AL];
+#pragma unroll
+            for (int b = 0; b < AL; b++) rin[b] = lds[(q * AL + b) * WL_CV + cvl];
+            bt_1d<MT, 1>(rin, row);  // rows: (.) B
+            float* o = V + (size_t)t * C + c0;
+#pragma unroll
+            for (int b = 0; b < AL; b++) {
+                *reinterpret_cast<f32x4w*>(o + (size_t)(q * AL + b) * plane) = row[b];
+#pragma unroll
+                for (int e = 0; e < 4; e++) vmax = fmaxf(vmax, fabsf(row[b][e]));
+            }
+        }
+        __syncthreads();  // the next unit overwrites the LDS image
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(vmax));
+    }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(256)
+    wino_output_lds_kernel(const float* __restrict__ M, WinoGeom g, int Cout, int T, const float* __restrict__ bias, int relu,
+                           float* __restrict__ out, unsigned* __restrict__ amax) {
+    constexpr int AL = MT + 2;
+    static_assert(AL <= 8, "one row / column per 32-lane group of a 256-thread workgroup");
+    __shared__ f32x4w lds[MT * AL * WL_CV];
+    const int tid = threadIdx.x, q = tid >> 5, cvl = tid & 31;
+    const int cgroups = Cout / (4 * WL_CV);
+    const size_t units = (size_t)T * cgroups;
+    const size_t plane = (size_t)T * Cout;
+    float vmax = 0.f;
+    for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const int cg = (int)(u % cgroups), t = (int)(u / cgroups);
+        const int n0 = cg * 4 * WL_CV + cvl * 4;
+        int ry, rx, ty, tx;
+        tile_coords(g, t, ry, rx, ty, tx);
+        if (q < AL) {
+            const float* mp = M + (size_t)t * Cout + n0;
+            f32x4w col[AL], s[MT];
+#pragma unroll
+            for (int a = 0; a < AL; a++) col[a] = *reinterpret_cast<const f32x4w*>(mp + (size_t)(a * AL + q) * plane);
+            at_1d<MT, 1, 1>(col, s);  // A^T m over the rows of column q
+#pragma unroll
+            for (int a = 0; a < MT; a++) lds[(a * AL + q) * WL_CV + cvl] = s[a];
+        }
+        __syncthreads();
+        if (q < MT) {
+            f32x4w rin[AL], yv[MT];
+#pragma unroll
+            for (int b = 0; b < AL; b++) rin[b] = lds[(q * AL + b) * WL_CV + cvl];
+            at_1d<MT, 1>(rin, yv);  // rows: (.) A
+            const f32x4w bv = *reinterpret_cast<const f32x4w*>(bias + n0);
+            const int y = g.d * (MT * ty + q) + ry;
+            if (y < g.H) {
+#pragma unroll
+                for (int b = 0; b < MT; b++) {
+                    const int x = g.d * (MT * tx + b) + rx;
+                    if (x >= g.W) continue;
+                    f32x4w v = yv[b] + bv;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                        vmax = fmaxf(vmax, fabsf(v[e]));
+                    }
+                    *reinterpret_cast<f32x4w*>(out + ((size_t)y * g.W + x) * Cout + n0) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, __float_as_uint(vmax));
+    }
+}
+
 // ---- weight transform: U[xi][o][c] = (G g G^T)[xi],  g = w[o][c][3][3] (OIHW) ----
 template <int MT>
 __global__ void wino_weight_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ U) {
@@ -293,13 +416,21 @@ static int wino_forced() {
     return forced;
 }
 static bool wino_vec4(int C) { return (C & 3) == 0 && wino_forced() != 2; }
+// the LDS two-pass forms (16-byte accesses for F(6x6)): INFUR_WINO_LDS=0 switches back to the per-thread forms (A/B, tests)
+static bool wino_lds(int C, int mt) {
+    static const int on = getenv("INFUR_WINO_LDS") ? atoi(getenv("INFUR_WINO_LDS")) : 1;
+    return on && mt == 6 && C % (4 * WL_CV) == 0 && wino_forced() == 0;
+}
+static unsigned grid_units(size_t units) { return (unsigned)(units < 256 * 40 ? units : 256 * 40); }
 
 hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt, float* V, unsigned* amax, hipStream_t s) {
     const WinoGeom g = geom(H, W, d, mt);
     const int T = d * d * g.TY * g.TX;
     const bool v4 = wino_vec4(C) && mt != 6;  // F(6x6): 64 patch vectors per thread -- 8-byte vectors keep them in registers
     const unsigned blocks = grid_for((size_t)T * (C / (v4 ? 4 : 2)));
-    if (mt == 6 && wino_forced() == 1)
+    if (wino_lds(C, mt))
+        hipLaunchKernelGGL(wino_input_lds_kernel<6>, dim3(grid_units((size_t)T * (C / (4 * WL_CV)))), dim3(256), 0, s, in, g, C, T, V, amax);
+    else if (mt == 6 && wino_forced() == 1)
         hipLaunchKernelGGL((wino_input_kernel<6, f32x1>), dim3(grid_for((size_t)T * C)), dim3(256), 0, s, in, g, C, T, V, amax);
     else if (mt == 6)
         hipLaunchKernelGGL((wino_input_kernel<6, f32x2>), dim3(blocks), dim3(256), 0, s, in, g, C, T, V, amax);
@@ -320,7 +451,9 @@ hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int
     const int T = d * d * g.TY * g.TX;
     const bool v4 = wino_vec4(Cout) && mt != 6;
     const unsigned blocks = grid_for((size_t)T * (Cout / (v4 ? 4 : 2)));
-    if (mt == 6 && wino_forced() == 1)
+    if (wino_lds(Cout, mt))
+        hipLaunchKernelGGL(wino_output_lds_kernel<6>, dim3(grid_units((size_t)T * (Cout / (4 * WL_CV)))), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
+    else if (mt == 6 && wino_forced() == 1)
         hipLaunchKernelGGL((wino_output_kernel<6, f32x1>), dim3(grid_for((size_t)T * Cout)), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
     else if (mt == 6)
         hipLaunchKernelGGL((wino_output_kernel<6, f32x2>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);

@@ -241,7 +241,9 @@ class TorchModel:
     torchvision fcn_resnet50/101 with BN folded (see infur_amd/weights.py::graph).
     """
 
-    def __init__(self, blob: bytes, threads: int = 0):
+    def __init__(self, blob: bytes, threads: int = 0, float64: bool = False):
+        """``float64``: parameters and arithmetic in double precision -- the reference the hostile-parameter tests grade
+        both the f32 oracle and the HIP modes against (tests/test_gpu_hostile.py)."""
         import torch
 
         from infur_amd import weights as W
@@ -257,6 +259,9 @@ class TorchModel:
         for spec, (name, w, b) in zip(self.specs, tensors):
             assert spec.name == name and w.shape == (spec.cout, spec.cin, spec.k, spec.k), name
             self.params.append((torch.from_numpy(np.array(w)), torch.from_numpy(np.array(b))))
+        self.float64 = float64
+        if float64:
+            self.params = [(w.double(), b.double()) for w, b in self.params]
 
     def forward_lowres(self, chw: np.ndarray, taps=None):
         """[3,h,w] f32 -> (out_low [K,lh,lw], aux_low or None) as torch tensors.
@@ -266,6 +271,8 @@ class TorchModel:
         torch = self.torch
         F = torch.nn.functional
         x = torch.from_numpy(np.ascontiguousarray(chw, np.float32))[None]
+        if self.float64:
+            x = x.double()
         it = iter(zip(self.specs, self.params))
 
         def conv(x, residual=None):

@@ -1,0 +1,102 @@
+"""the numerics the headline depends on, on UNFRIENDLY data.  Every other suite uses one benign weight
+distribution (uniform U(-a, a), BN gamma in [0.5, 1.5]); pretrained BN-folded weights have heavy tails and per-channel scales
+orders of magnitude apart, and the default f32 path runs 14 convs as Winograd F(6x6, 3x3), whose error grows with the dynamic
+range of weights and activations.  tests/hostile.py builds such a parameter set (1 % outliers at 30 sigma, per-channel scales
+over 3.2 decades as an exact reparametrisation, always-on channels) and a frame with saturated regions; the HIP modes f32
+(F(6x6) default), f32s and f32x are graded per layer at 320x240 and on the whole 1920x1080 frame against a FLOAT64 evaluation of
+the network (torch CPU), with two metrics: max-abs error / max-abs reference (the reading tests/test_gpu_parity.py uses)
+and the worst per-element relative error over the elements with |ref| > 1e-2 max |ref|.  north_star's bar: logits within 1e-3."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import hostile as H  # noqa: E402
+
+from infur_amd import weights as W
+from infur_amd.processors import Context, FramePath, Model, ModelCmd
+
+pytestmark = pytest.mark.gpu
+
+# Measured on an MI355X (scripts/hostile_probe.py prints every mode x Winograd tile; gpurun_out/hostile_probe2.log):
+#   mode   logits 1080p (max-abs/max-abs | per-element)   per-layer worst
+#   f32    3.8e-06 | 2.1e-04                               9.1e-06      exact f32 MFMA, F(6x6): as good as direct convs (4.1e-06)
+#   f32s   1.6e-05 | 1.0e-03                               3.1e-05      F(6x6); direct convs 9.4e-06.  BEFORE round 3's per-plane
+#                                                                      weight scales: 8.9e-03 .. 1.6e-02 -- outside the bar, found by this test
+#   f32x   7.1e-04 | 5.1e-02                               1.8e-03      the fp8 cross terms (products exact to ~2^-14) do not like
+#                                                                      heavy tails: direct convs give 5.7e-04 too; inside 1e-3, with little room
+# The logits bar is north_star's 1e-3 for every mode; the per-layer bars are the measured values with ~3x head-room.
+LOGIT_BAR = {"f32": 1e-3, "f32s": 1e-3, "f32x": 1e-3}
+LAYER_BAR = {"f32": 3e-5, "f32s": 1e-4, "f32x": 5e-3}
+ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 0.3}  # worst per-element relative error over |ref| > 1e-2 max |ref|
+
+
+@pytest.fixture(scope="module")
+def hostile_blob():
+    return H.hostile_blob()
+
+
+@pytest.fixture(scope="module")
+def ref64(hostile_blob):
+    from oracle.infur_oracle import TorchModel
+
+    return TorchModel(hostile_blob, float64=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f32s", "f32x"])
+def test_per_layer_on_hostile_parameters(hostile_blob, ref64, oracle, dtype):
+    fr = H.saturated_frame(240, 320)
+    taps = {}
+    ref64.forward_lowres(oracle.pack_normalize(fr), taps=taps)
+    c = Context(device=0, dtype=dtype, keep_activations=True)
+    m = Model(c).control(ModelCmd.LoadBlob(hostile_blob))
+    out = []
+    m.advance(fr, out)
+    worst = (0.0, 0.0, "", "")
+    for i, spec in enumerate(W.graph(50)):
+        ref = taps[spec.name].numpy()
+        buf = np.empty(ref.shape, np.float32)
+        cc, hh, ww = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        c.check(c.L.infur_debug_read_activation(c.h, i, buf.ctypes.data, buf.size, C.byref(cc), C.byref(hh), C.byref(ww)))
+        e_max, e_rel = H.errors(buf, ref)
+        if e_max > worst[0]:
+            worst = (e_max, worst[1], spec.name, worst[3])
+        if e_rel > worst[1]:
+            worst = (worst[0], e_rel, worst[2], spec.name)
+        assert e_max < LAYER_BAR[dtype], (dtype, spec.name, e_max, e_rel)
+    print(f"{dtype} hostile per-layer 320x240: worst max-abs/max-abs {worst[0]:.2e} ({worst[2]}), worst per-element {worst[1]:.2e} ({worst[3]})")
+    assert worst[1] < ELEM_BAR[dtype]
+    if dtype != "f32":
+        amax, wmax, sat = c.split_range()
+        print(f"   split range monitor: max |activation| {amax:.3g}, max |Winograd input| {wmax:.3g}, saturated {sat}")
+        assert not sat
+    c.close()
+
+
+def test_whole_frame_1080p_on_hostile_parameters(hostile_blob, ref64, oracle):
+    fr = H.saturated_frame(1080, 1920, index=2)
+    ref, ref_aux = ref64.forward_lowres(oracle.pack_normalize(fr))
+    ref, ref_aux = ref.numpy(), ref_aux.numpy()
+    for dtype in ("f32", "f32s", "f32x"):
+        c = Context(device=0, dtype=dtype)
+        m = Model(c).control(ModelCmd.LoadBlob(hostile_blob))
+        rgba, _ = FramePath(c).advance(fr, 1.0)
+        lo, la = m.lowres()
+        (e_max, e_rel), (a_max, a_rel) = H.errors(lo, ref), H.errors(la, ref_aux)
+        kr, _ = oracle.argmax(ref)
+        kg, _ = oracle.argmax(lo)
+        srt = np.sort(np.maximum(ref, 0.0), axis=0)
+        gap = srt[-1] - srt[-2]
+        bad = kr != kg
+        unexplained = int((bad & (gap >= LOGIT_BAR[dtype] * np.abs(ref).max())).sum())
+        print(f"{dtype} hostile 1920x1080: out {e_max:.2e} / {e_rel:.2e}, aux {a_max:.2e} / {a_rel:.2e} (max-abs/max-abs / per-element); "
+              f"low-res class map differs on {int(bad.sum())} of {bad.size} pixels, {unexplained} outside the tolerance band")
+        assert e_max < LOGIT_BAR[dtype] and a_max < LOGIT_BAR[dtype] and unexplained == 0
+        assert e_rel < ELEM_BAR[dtype] and a_rel < ELEM_BAR[dtype]
+        # the post stage stays bit-exact given the logits
+        h, w = fr.shape[:2]
+        assert (rgba == oracle.colorcode(oracle.upsample_bilinear(lo, h, w))).all()
+        c.close()
