@@ -50,12 +50,17 @@ __device__ __forceinline__ void ar_dma16(const u32x4a rsrc, const unsigned lds, 
         : "memory");
 }
 
-// KS = K steps of 64 channels (Cin = 64 * KS)
-template <int KS>
+// KS = K steps of 64 channels (Cin = 64 * KS).  A wave owns TMI x TNJ blocks of 32 x 32 of the 256 x 128 tile:
+//   <KS, 2, 2>: 4 waves along M x 2 along N, 64 x 64 each (Cin <= 256: the activation fragment is <= 128 VGPRs)
+//   <8, 1, 4>:  8 waves along M, 32 pixels x all 128 channels each (round 3: Cin = 512, the expansions of layer4 -- the
+//               fragment of 32 pixels x 512 channels is 128 VGPRs; every weight fragment then feeds one MFMA instead of two)
+template <int KS, int TMI = 2, int TNJ = 2>
 __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, const int mtiles) {
+    static_assert(TMI * TNJ == 4 && (TMI == 1 || TMI == 2), "8 waves cover 256 x 128");
+    constexpr int WN = 4 / TNJ;  // waves along N
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int M = a.OH * a.OW;
     const int Kb = a.Cin * 2;  // bytes of a row of A / B
     int tile;
@@ -67,12 +72,12 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
     const int m0 = tile * AR_BM;
     const int ntiles = (a.Cout + AR_BN - 1) / AR_BN;
 
-    // ---- the wave's activation fragments, loaded once: rows wm * 64 + i * 32 + (lane & 31), all Cin channels ----
+    // ---- the wave's activation fragments, loaded once: rows wm * 32 TMI + i * 32 + (lane & 31), all Cin channels ----
     const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (unsigned)((size_t)a.H * a.W * a.Cin * 2), 0x00020000);
-    h16x8a areg[2][KS * 4];
+    h16x8a areg[TMI][KS * 4];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < TMI; i++) {
+        const int m = m0 + wm * (32 * TMI) + i * 32 + (lane & 31);
         // (1x1, stride s: pixel (oy, ox) reads input pixel (oy * s, ox * s))
         const int oy = m / a.OW, ox = m - oy * a.OW;
         const unsigned base = m < M ? (unsigned)(oy * a.stride * a.W + ox * a.stride) * (unsigned)Kb + (unsigned)(lane >> 5) * 16u : OOBA;
@@ -120,7 +125,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int b_lds = (wn * 64 + (lane & 31)) * 128;
+    const int b_lds = (wn * (32 * TNJ) + (lane & 31)) * 128;
     const int b_swz = ar_swz(lane & 31);  // fragment rows are 32 apart: the swizzle does not change
     char* stage = smem + AR_NIMG * AR_B_IMG + wave * 32 * AR_ROWB;
     const int e_row = lane >> 4, e_col = lane & 15;  // epilogue: 16 lanes x 4 channels per pixel row, 4 rows per instruction
@@ -136,11 +141,11 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
 
     for (int wnt = 0; wnt < ntiles; wnt++) {
         const int nt = nt_of(wnt);
-        f32x16a acc[2][2];
+        f32x16a acc[TMI][TNJ];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TMI; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < TNJ; j++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 #pragma unroll
@@ -149,14 +154,14 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
             const char* Bb = smem + (q & (AR_NIMG - 1)) * AR_B_IMG + b_lds;
 #pragma unroll
             for (int sl = 0; sl < 4; sl++) {
-                h16x8a fb[2];
+                h16x8a fb[TNJ];
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < TNJ; j++)
                     fb[j] = *reinterpret_cast<const h16x8a*>(Bb + j * 32 * 128 + (((2 * sl + (lane >> 5)) ^ b_swz) * 16));
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+                for (int i = 0; i < TMI; i++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++)
+                    for (int j = 0; j < TNJ; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], areg[i][ks * 4 + sl], acc[i][j], 0, 0, 0);
             }
             // Before the barrier that ends K step q the wave's pieces of step q + 1 must have landed.  They were issued
@@ -176,18 +181,20 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
 
         // ---- epilogue of this N tile: + bias, + residual, ReLU, f16 store; through the wave's own LDS slice so that 16
         //      lanes write the 128 contiguous bytes of a pixel's 64 channels (same scheme as conv_igemm_kernel) ----
-        const int n = nt * AR_BN + wn * 64 + e_col * 4;
+#pragma unroll
+        for (int hf = 0; hf < TNJ / 2; hf++) {  // 64 output channels at a time through the wave's LDS slice
+        const int n = nt * AR_BN + wn * (32 * TNJ) + hf * 64 + e_col * 4;
         const bool n_ok = n < a.Cout;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_bias && n_ok) bv = *reinterpret_cast<const float4*>(a.bias + n);
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < TMI; i++) {
             // (Fetching the first block's residual before the K loop of the N tile, so that it lands behind the MFMAs, was
             //  measured too: no change -- 0.134-0.136 ms on layer3 conv3 at 4K either way; the kernel is at 0.9 of copy speed.)
             // All eight residual loads of this 32-row block are in flight before the accumulators are staged: with one
             // workgroup per CU nothing else hides their latency (two at a time made the whole kernel latency-bound,
             // 1.8 TB/s of stores).
-            const unsigned eoff = n_ok ? ((unsigned)(m0 + wm * 64 + i * 32 + e_row) * (unsigned)a.Cout + (unsigned)n) * 2u : OOBA;
+            const unsigned eoff = n_ok ? ((unsigned)(m0 + wm * (32 * TMI) + i * 32 + e_row) * (unsigned)a.Cout + (unsigned)n) * 2u : OOBA;
             u32x2a rr[8];
 #pragma unroll
             for (int it = 0; it < 8; it++) rr[it] = __builtin_amdgcn_raw_buffer_load_b64(res_rsrc, eoff, it * it_bytes, 0);
@@ -195,7 +202,8 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
             for (int jj = 0; jj < 2; jj++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const float4 v = make_float4(acc[i][jj][4 * g + 0], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
+                    const float4 v = make_float4(acc[i][2 * hf + jj][4 * g + 0], acc[i][2 * hf + jj][4 * g + 1], acc[i][2 * hf + jj][4 * g + 2],
+                                                 acc[i][2 * hf + jj][4 * g + 3]);
                     *reinterpret_cast<float4*>(stage + (lane & 31) * AR_ROWB + (jj * 32 + 8 * g + 4 * (lane >> 5)) * 4) = v;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -217,14 +225,15 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
+        }
     }
 }
 
-template <int KS>
+template <int KS, int TMI = 2, int TNJ = 2>
 hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + AR_BM - 1) / AR_BM;
-    auto k = conv1x1_areg_kernel<KS>;
+    auto k = conv1x1_areg_kernel<KS, TMI, TNJ>;
     static std::atomic<bool> attr_done[64];
     int dev = 0;
     const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
@@ -241,7 +250,7 @@ hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
 
 bool conv1x1_areg_valid(const ConvArgs& a, int mode, int out_f32) {
     return mode == 1 && !out_f32 && a.KH == 1 && a.KW == 1 && a.pad == 0 && !a.in2 && a.batch <= 1 &&
-           (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.Cout >= 256 && (a.Cout & (AR_BN - 1)) == 0 &&
+           (a.Cin == 64 || a.Cin == 128 || a.Cin == 256 || a.Cin == 512) && a.Cout >= 256 && (a.Cout & (AR_BN - 1)) == 0 &&
            // (whole N tiles only: every conv3 of a ResNet; the ragged-N guards in the kernel are untested)
            (size_t)a.H * a.W * a.Cin * 2 < 0x80000000ull && (size_t)a.OH * a.OW * a.Cout * 2 < 0x80000000ull && (size_t)a.Cout * a.Cin * 2 < 0x80000000ull;
 }
@@ -251,6 +260,7 @@ hipError_t launch_conv1x1_areg(const ConvArgs& a, hipStream_t s) {
         case 64: return launch_ks<1>(a, s);
         case 128: return launch_ks<2>(a, s);
         case 256: return launch_ks<4>(a, s);
+        case 512: return launch_ks<8, 1, 4>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -150,11 +150,24 @@ constexpr int SP_SR = 2 * SP_PR + 1, SP_SC = 2 * SP_PC + 1;  // 11 x 23 stem pix
 constexpr int SP_NPIX = SP_SR * SP_SC;                       // 253
 constexpr int SP_IH = 2 * SP_SR + 5, SP_IW = 2 * SP_SC + 5;  // 27 x 51 input pixels
 constexpr int SP_STAGE = 68;                                 // floats per staged stem pixel (64 + pad: conflict-free b128 writes)
-constexpr int SP_PATCH = SP_IH * SP_IW * 3;
+// The normalised input patch of the f32 kernel lives in LDS as FOUR images -- input rows and columns split by parity -- of
+// [14 rows][SP_PP floats]: a stem pixel (r, c) reads tap (ky, kx, ch) at image (ky & 1, kx & 1), row r + ky / 2, float
+// 3 (c + kx / 2) + ch, so its lane-dependent part is r * SP_PP + 3 c.  With SP_PP = 133 (= 5 mod 64, and 3 * 23 = 69 = 5 mod 64:
+// the tile is 23 stem pixels wide) that is 3 * (23 r + c) mod 64 = 3 x the lane's linear pixel index: the 32 lanes of an
+// M block always hit 32 different banks.  (The plain [27][51][3] image gave a lane stride of 6 floats plus a row jump of an
+// even number of floats: 6.2 M conflict cycles per 1080p launch in the MFMA loop, scripts/stem_conflicts.sh.)
+constexpr int SP_PP = 133, SP_PROWS = (SP_IH + 1) / 2, SP_PIMG = SP_PROWS * SP_PP;
+static_assert(SP_PP >= 3 * ((SP_IW + 1) / 2) && SP_PP % 64 == (3 * SP_SC) % 64, "patch row pitch");
+constexpr int SP_PATCH = 4 * SP_PIMG;
 constexpr int SP_LDS_FLOATS = (SP_PATCH + ST_KP * 64 + 768) > 256 * SP_STAGE ? (SP_PATCH + ST_KP * 64 + 768) : 256 * SP_STAGE;  // patch, weights, LUT | stem tile
 static_assert(SP_NPIX <= 256 && SP_NPIX > 224, "the stem tile must fill 8 M-blocks of 32");
 
-__host__ __device__ constexpr int sp_koff(int k) { return (k / 21) * (SP_IW * 3) + (k % 21); }
+// float offset of tap k = ky * 21 + kx * 3 + ch relative to the stem pixel's base r * SP_PP + 3 c
+__host__ __device__ constexpr int sp_koff(int k) {
+    return (((k / 21) & 1) * 2 + (((k % 21) / 3) & 1)) * SP_PIMG + ((k / 21) >> 1) * SP_PP + (((k % 21) / 3) >> 1) * 3 + (k % 3);
+}
+// where input pixel (row, col) of the patch sits
+__host__ __device__ constexpr int sp_pixoff(int row, int col) { return ((row & 1) * 2 + (col & 1)) * SP_PIMG + (row >> 1) * SP_PP + (col >> 1) * 3; }
 
 // stem tile (+bias, ReLU, * acc_scale) -> LDS -> 3x3/2 max-pool -> global; shared by the f32 and the f16-rate stems.
 // `smem` is the whole (now idle) operand LDS; every wave has passed a barrier since its last operand read.
@@ -279,9 +292,11 @@ __global__ void __launch_bounds__(256, 2)
         const int i = tid + 256 * j;
         if (i >= SP_IH * SP_IW) continue;
         // zero padding of the NORMALISED tensor outside the frame
-        patch[i * 3 + 0] = pin[j] ? slut[0 * 256 + pb[j][2]] : 0.f;  // R
-        patch[i * 3 + 1] = pin[j] ? slut[1 * 256 + pb[j][1]] : 0.f;  // G
-        patch[i * 3 + 2] = pin[j] ? slut[2 * 256 + pb[j][0]] : 0.f;  // B
+        const int pr_ = i / SP_IW, pq_ = i - pr_ * SP_IW;
+        float* pp = patch + sp_pixoff(pr_, pq_);
+        pp[0] = pin[j] ? slut[0 * 256 + pb[j][2]] : 0.f;  // R
+        pp[1] = pin[j] ? slut[1 * 256 + pb[j][1]] : 0.f;  // G
+        pp[2] = pin[j] ? slut[2 * 256 + pb[j][0]] : 0.f;  // B
     }
     __syncthreads();
 
@@ -304,7 +319,7 @@ __global__ void __launch_bounds__(256, 2)
         pidx[i] = (2 * wave + i) * 32 + px;
         const int p = pidx[i] < SP_NPIX ? pidx[i] : SP_NPIX - 1;
         const int r = p / SP_SC, c = p - r * SP_SC;
-        pa[i] = patch + ((2 * r) * SP_IW + 2 * c) * 3;
+        pa[i] = patch + r * SP_PP + 3 * c;  // (input pixel (2r, 2c): both even -> image 0, row r, column c)
     }
     const float* pw = wsm + half * 64 + px;
 #pragma unroll
