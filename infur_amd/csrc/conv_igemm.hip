@@ -62,6 +62,29 @@ constexpr int LDS_ROW = ROW_BYTES + 16;
 constexpr unsigned OOB = 0x80000000u;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4q __attribute__((ext_vector_type(4)));
+typedef int i32x16q __attribute__((ext_vector_type(16)));
+
+// ---- quantised epilogue (mode 4): every floating-point step is ONE f32 operation, never contracted -- the arithmetic is
+//      defined bit for bit (oracle/infur_qoracle.py) ----
+// QLinearConv: sat_u8(round_half_even(f32(acc) * mult) + zp)
+__device__ __forceinline__ int q_requant(const int acc, const float mult, const int yzp) {
+#pragma clang fp contract(off)
+    float t = (float)acc * mult;
+    t = __builtin_rintf(t) + (float)yzp;
+    t = __builtin_fminf(__builtin_fmaxf(t, 0.f), 255.f);
+    return (int)t;
+}
+// QLinearAdd: sat_u8(round(f32(a - a_zp) * ra + f32(b - b_zp) * rb) + c_zp)
+__device__ __forceinline__ int q_add(const int a, const int azp, const float ra, const int b, const int bzp, const float rb, const int czp) {
+#pragma clang fp contract(off)
+    const float ta = (float)(a - azp) * ra;
+    const float tb = (float)(b - bzp) * rb;
+    float t = ta + tb;
+    t = __builtin_rintf(t) + (float)czp;
+    t = __builtin_fminf(__builtin_fmaxf(t, 0.f), 255.f);
+    return (int)t;
+}
 
 // four f32 (one staged 16-byte chunk) * scale -> 4 x f16 hi at dst, 4 x f16 lo at dst + 64
 // (round to nearest even twice: |x - hi| <= 2^-11 |x| is exact in f32, so hi + lo = x to 2^-22)
@@ -171,6 +194,7 @@ template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NBUF, b
 __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN, NBUF))
     conv_igemm_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
     constexpr bool F32 = std::is_same<T, float>::value && !SPLIT;
+    constexpr bool I8 = std::is_same<T, signed char>::value;  // u8 activations x s8 weights, i32 accumulation (ConvArgs::q_*)
     static_assert(!SPLIT || std::is_same<T, float>::value, "SPLIT stages f32 tensors");
     constexpr int ES = sizeof(T);              // operand element size
     constexpr int BK = ROW_BYTES / ES;         // channels per K step
@@ -451,6 +475,11 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                         const i32x8 b8 = __builtin_bit_cast(i32x8, (F2{fb8[j][0], fb8[j][1]}));
                         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc[i][j], 0, 0, 0, kFp8CrossScaleA, 0, 127);
                     }
+                } else if constexpr (I8) {
+                    // activations are u8, the MFMA is signed: x ^ 0x80 = x - 128 as s8 (the -128 * sum w is in q_bias)
+                    const i32x4q ax = __builtin_bit_cast(i32x4q, fa[i]) ^ (int)0x80808080;
+                    acc[i][j] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4q, fb[j]), ax,
+                                                                                                  __builtin_bit_cast(i32x16q, acc[i][j]), 0, 0, 0));
                 } else if constexpr (F32) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].x, fa[i].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j].y, fa[i].y, acc[i][j], 0, 0, 0);
@@ -562,7 +591,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     const int e_row = lane / LPR, e_col = lane % LPR;
     const int e_n = n0 + wn * TN * 32 + e_col * 4;
     const T* res = static_cast<const T*>(a.res);
-    using ResV = typename std::conditional<std::is_same<T, float>::value, float4, f16x4>::type;
+    using ResV = typename std::conditional<std::is_same<T, float>::value, float4, typename std::conditional<I8, unsigned, f16x4>::type>::type;
     ResV rres[RESPF ? TM : 1][RESPF ? 32 / RPI : 1];
     if constexpr (RESPF) {
 #pragma unroll
@@ -696,6 +725,17 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         const bool n_ok = n < a.Cout;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_bias && n_ok) bv = *reinterpret_cast<const float4*>(a.bias + n);
+        int qb[4] = {0, 0, 0, 0};          // I8: folded bias and requantisation multiplier of this lane's 4 channels
+        float qm[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (I8) {
+            if (n_ok) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    qb[t] = a.q_bias[n + t];
+                    qm[t] = a.q_mult[n + t];
+                }
+            }
+        }
         float vmax = 0.f;  // SPLIT: largest |output| of this lane (range monitor)
 #pragma unroll
         for (int i = 0; i < TM; i++) {
@@ -734,7 +774,32 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                 const int row = it * RPI + rrow;
                 const int m = mb + row;
                 float4 v = *reinterpret_cast<const float4*>(stage + row * ROWB + rcol * 16);
-                if (m < M && n_ok) {
+                if constexpr (I8) {
+                    if (m < M && n_ok) {
+                        const size_t o = (size_t)m * a.Cout + n;
+                        const i32x4q ai = __builtin_bit_cast(i32x4q, v);
+                        int q[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) q[t] = q_requant(ai[t] + qb[t], qm[t], a.q_yzp);
+                        if (RESPF || res) {
+                            unsigned rv;
+                            if constexpr (RESPF)
+                                rv = rres[i][it];
+                            else
+                                rv = rlate[it];
+#pragma unroll
+                            for (int t = 0; t < 4; t++) q[t] = q_add(q[t], a.q_yzp, a.q_ra, (int)((rv >> (8 * t)) & 0xffu), a.q_bzp, a.q_rb, a.q_czp);
+                        }
+                        if constexpr (std::is_same<OutT, float>::value) {
+                            float4 d;
+                            d.x = (float)(q[0] - a.q_yzp) * a.q_dq; d.y = (float)(q[1] - a.q_yzp) * a.q_dq;
+                            d.z = (float)(q[2] - a.q_yzp) * a.q_dq; d.w = (float)(q[3] - a.q_yzp) * a.q_dq;
+                            *reinterpret_cast<float4*>(out + o) = d;
+                        } else {
+                            *reinterpret_cast<unsigned*>(out + o) = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
+                        }
+                    }
+                } else if (m < M && n_ok) {
                     const size_t o = (size_t)m * a.Cout + n;
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     if (RESPF || res) {
@@ -789,12 +854,22 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if (n + t >= a.Cout) break;
-                    float x = acc[i][j][4 * g + t];
-                    if constexpr (SPLIT) x *= acc_scale;
-                    x += has_bias ? a.bias[n + t] : 0.f;
-                    if (res) x += (float)res[o + t];
-                    if (a.relu) x = fmaxf(x, 0.f);
-                    out[o + t] = (OutT)x;
+                    if constexpr (I8) {
+                        const int ai = __builtin_bit_cast(int, acc[i][j][4 * g + t]);
+                        int q = q_requant(ai + a.q_bias[n + t], a.q_mult[n + t], a.q_yzp);
+                        if (res) q = q_add(q, a.q_yzp, a.q_ra, (int)(unsigned char)res[o + t], a.q_bzp, a.q_rb, a.q_czp);
+                        if constexpr (std::is_same<OutT, float>::value)
+                            out[o + t] = (OutT)((float)(q - a.q_yzp) * a.q_dq);
+                        else
+                            out[o + t] = (OutT)q;
+                    } else {
+                        float x = acc[i][j][4 * g + t];
+                        if constexpr (SPLIT) x *= acc_scale;
+                        x += has_bias ? a.bias[n + t] : 0.f;
+                        if (res) x += (float)res[o + t];
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        out[o + t] = (OutT)x;
+                    }
                 }
             }
         }
@@ -827,7 +902,10 @@ static hipError_t launch_cfg_g(const ConvArgs& a, hipStream_t s) {
 template <typename T, typename OutT, bool SPLIT, bool FP8X, int BM, int BN, int WM, int WN, int NBUF = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     const bool g1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
-    constexpr bool kSameType = std::is_same<T, OutT>::value;  // the f16 -> f32 kernel only ever runs the classifier
+    // the f16 -> f32 (and u8 -> f32) kernel only ever runs the classifier; an i8 convolution stores u8 activations
+    constexpr bool kI8 = std::is_same<T, signed char>::value;
+    constexpr bool kSameType = std::is_same<T, OutT>::value || (kI8 && std::is_same<OutT, unsigned char>::value);
+    if (kI8 && a.in2) return hipErrorInvalidValue;  // (the two convolutions of a quantised block requantise separately)
     if constexpr (kSameType) {
         if (a.in2) {
             if (!g1 || a.stride != 1 || a.res) return hipErrorInvalidValue;
@@ -897,18 +975,21 @@ int conv_igemm_num_configs() { return kNumCfgs; }
 int conv_igemm_config_tile_area(int cfg) { return cfg < 0 || cfg >= kNumCfgs ? 0 : kCfgs[cfg].bm * kCfgs[cfg].bn; }
 
 const char* conv_igemm_config_name(int cfg, int mode) {
-    if (cfg < 0 || cfg >= kNumCfgs || mode < 0 || mode > 3) return "conv_igemm<?>";
-    if (mode == 3) {  // "conv_igemm_f32s<...>" -> "conv_igemm_f32x<...>"
-        static std::string names[64];
+    if (cfg < 0 || cfg >= kNumCfgs || mode < 0 || mode > 4) return "conv_igemm<?>";
+    if (mode >= 3) {  // "conv_igemm_f32s<...>" -> "conv_igemm_f32x<...>" / "conv_igemm_i8<...>"
+        static std::string names[2][64];
         static std::once_flag once;
         std::call_once(once, [] {
             for (int k = 0; k < kNumCfgs && k < 64; k++) {
-                names[k] = kCfgs[k].name[2];
-                const size_t p = names[k].find("f32s");
-                if (p != std::string::npos) names[k][p + 3] = 'x';
+                names[0][k] = names[1][k] = kCfgs[k].name[2];
+                const size_t p = names[0][k].find("f32s");
+                if (p != std::string::npos) {
+                    names[0][k][p + 3] = 'x';
+                    names[1][k].replace(p, 4, "i8");
+                }
             }
         });
-        return names[cfg].c_str();
+        return names[mode - 3][cfg].c_str();
     }
     return kCfgs[cfg].name[mode];
 }
@@ -924,7 +1005,7 @@ int conv_igemm_default_config(const ConvArgs& a) {
 bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32) {
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     if (mode == 3) mode = 2;  // the fp8 cross-term form stages like the split mode
-    if (cfg >= 13 && mode != 1) return false;
+    if (cfg >= 13 && mode != 1 && mode != 4) return false;  // LDS-DMA staging: byte operands that need no conversion (f16, i8)
     if (cfg == 15) return conv1x1_areg_valid(a, mode, out_f32);  // (f16 output only: not the f32 logits of a 1x1 classifier)
     const int bn = kCfgs[cfg].bn;
     if (a.Cout <= 32) return bn == 32;
@@ -956,14 +1037,14 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 12: return launch_cfg<T, OutT, SPLIT, FP8X, 256, 128, 4, 2, 3>(a, s);  // 8 waves of 64x64, one fragment set
         case 13:
         case 14:
-            if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {  // LDS-DMA staging
+            if constexpr ((std::is_same<T, _Float16>::value || std::is_same<T, signed char>::value) && !SPLIT) {  // LDS-DMA staging
                 if (cfg == 13) return launch_cfg<T, OutT, SPLIT, FP8X, 256, 256, 2, 4, 4>(a, s);
                 return launch_cfg<T, OutT, SPLIT, FP8X, 256, 128, 4, 2, 4>(a, s);
             }
             return hipErrorInvalidValue;
         case 16:
         case 17:
-            if constexpr (std::is_same<T, _Float16>::value && !SPLIT) {
+            if constexpr ((std::is_same<T, _Float16>::value || std::is_same<T, signed char>::value) && !SPLIT) {
                 if (cfg == 16) return launch_cfg<T, OutT, SPLIT, FP8X, 256, 256, 2, 4, 5>(a, s);
                 return launch_cfg<T, OutT, SPLIT, FP8X, 256, 128, 4, 2, 5>(a, s);
             }
@@ -981,6 +1062,10 @@ hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, 
     if (mode == 0) return launch_t<float, float>(a, cfg, s);
     if (mode == 2) return launch_t<float, float, true>(a, cfg, s);
     if (mode == 3) return launch_t<float, float, true, true>(a, cfg, s);  // f32 tensors, f16 MFMA + fp8 MX MFMA for the cross terms
+    if (mode == 4) {  // quantised: u8 activations x s8 weights on the i8 MFMA, requantised in the epilogue
+        if (!a.q_mult || !a.q_bias) return hipErrorInvalidValue;
+        return out_f32 ? launch_t<signed char, float>(a, cfg, s) : launch_t<signed char, unsigned char>(a, cfg, s);
+    }
     return out_f32 ? launch_t<_Float16, float>(a, cfg, s) : launch_t<_Float16, _Float16>(a, cfg, s);
 }
 

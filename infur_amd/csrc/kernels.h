@@ -34,6 +34,16 @@ struct ConvArgs {
     // mode 2, optional: atomicMax target (bit pattern of a non-negative float) for max |output| of this launch --
     // the range monitor of the split mode (infur_split_range)
     unsigned* amax = nullptr;
+    // mode 4 (quantised models: u8 activations, s8 weights, exact i32 accumulation on v_mfma_i32_32x32x32_i8): the requantisation
+    // of ONNX QLinearConv in the epilogue -- y = sat_u8(round(f32(acc + q_bias[o]) * q_mult[o]) + q_yzp) -- then, with `res`, the
+    // com.microsoft QLinearAdd of the residual sum -- c = sat_u8(round(f32(y - q_yzp) * q_ra + f32(res - q_bzp) * q_rb) + q_czp)
+    // -- and, for an f32 output (the logits), DequantizeLinear: f32(y - q_yzp) * q_dq.  q_bias already holds the operator's
+    // bias + (128 - x_zp) * sum_k w[o][k]: the kernel feeds the MFMA x - 128 (one XOR per fragment; an out-of-range tap loads 0,
+    // i.e. x = 0 = the zero point of every padded tensor).
+    const float* q_mult = nullptr;
+    const int32_t* q_bias = nullptr;
+    int q_yzp = 0, q_bzp = 0, q_czp = 0;
+    float q_ra = 0.f, q_rb = 0.f, q_dq = 0.f;
     // two-source 1x1 GEMM (a bottleneck's conv3 and its downsample branch as ONE launch, no residual tensor):
     // out = W[:, :Cin] * in  +  W[:, Cin:] * in2(stride2)  + bias.  in2 == nullptr: ordinary convolution.
     // Requires KH = KW = 1, pad = 0, stride = 1; wt rows are Cin + Cin2 long; OH x OW = ceil(H2/stride2) x ...
@@ -47,6 +57,7 @@ struct ConvArgs {
 // MFMAs per product, f32 accumulation (Cin % 32 == 0) -- f32-grade results at f16 matrix rate / 3.
 // mode 3: as mode 2, but the two cross terms hi * lo run on the fp8 (e4m3) MX MFMA: 2 MFMA units per product instead of
 // 3, products exact to ~2^-14 (logits ~4e-5 from f32); weights prepared with launch_split_weights(fp8_cross = 1).
+// mode 4: quantised (ConvArgs::q_*): u8 NHWC activations, s8 OHWI weights (Cin % 128 == 0), output u8 or (out_f32) dequantised f32.
 // cfg: tile configuration index (conv_igemm_num_configs), -1 = built-in heuristic.  Every
 // configuration produces bit-identical results; only the speed differs.
 hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, hipStream_t s);
@@ -125,6 +136,20 @@ hipError_t launch_add_f32(const float* x, const float* y, float* sum, int n, hip
 // reverse_c: the kernels read a pixel's channels as (p[2], p[1], p[0]); a model whose channel 0 is B (Uint8 input:
 // BGR kept, predict_onnx.rs:296-301) gets its stem weights stored with the input-channel axis reversed instead
 hipError_t launch_repack_stem(const float* src, float* dst, int reverse_c, hipStream_t s);
+
+// ---- quantised models (quant.hip) ----
+// stem: packed BGR u8 frame -> QuantizeLinear of the normalised image through a [3][256] u8 table (RGB order; out-of-frame
+// taps take x_zp) -> QLinearConv 7x7/2 pad 3 (wq: [64][7][7] dwords = (r, g, b, 0) s8; q_bias / q_mult per channel) -> u8
+// NHWC [SH][SW][64]
+hipError_t launch_stem_q(const uint8_t* bgr, int H, int W, const uint8_t* qlut, int x_zp, const int32_t* wq, const int32_t* q_bias,
+                         const float* q_mult, int y_zp, uint8_t* out, int SH, int SW, hipStream_t s);
+// max-pool 3x3/2 pad 1 on u8 NHWC [H][W][C] -> [OH][OW][CP] (CP >= C: channels C..CP-1 are written as 0; C, CP % 16 == 0)
+hipError_t launch_maxpool_q(const uint8_t* in, int H, int W, int C, uint8_t* out, int OH, int OW, int CP, hipStream_t s);
+// OIHW s8 -> OHWI s8 with the input-channel axis zero-padded to IP and `OP - O` zero rows appended; also sums every row
+// (wsum[o] = sum_k w[o][k], i32; rows O..OP-1: 0)
+hipError_t launch_repack_q(const int8_t* src, int8_t* dst, int32_t* wsum, int O, int I, int KH, int KW, int OP, int IP, hipStream_t s);
+// u8 NHWC -> planar f32 [C][H][W] (debug read-back of a quantised activation: the byte values)
+hipError_t launch_u8_nhwc_to_planar(const uint8_t* in, int H, int W, int C, float* out, hipStream_t s);
 
 // Scale: packed BGR u8 resize.  mode 0 nearest, 1 bilinear (definitions: oracle/infur_oracle.c)
 hipError_t launch_scale_bgr(const uint8_t* in, int W, int H, uint8_t* out, int OW, int OH,

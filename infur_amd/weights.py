@@ -266,3 +266,96 @@ def unpack_blob(blob: bytes):
         b = np.frombuffer(blob, dtype=np.float32, count=cout, offset=b_off)
         out.append((name, w, b))
     return {"depth": depth, "num_classes": ncls, "aux": bool(aux), "n_convs": n, "input_u8": kind == 1}, out
+
+
+# --------------------------------------------------------------------------- #
+# quantised models: the "INFURQ01" blob
+# --------------------------------------------------------------------------- #
+# The reference's own tests load `fcn-resnet50-12-int8.onnx` (infur-test-gen/build.rs:88-93; predict_onnx.rs:357-381): the
+# QOperator form of the same network -- QuantizeLinear on the image, QLinearConv (u8 activations, s8 weights, i32 bias,
+# per-output-channel weight scales) for every convolution with the ReLU folded into the clamp at the zero point, a u8
+# MaxPool, QLinearAdd (com.microsoft) for the residual sums, DequantizeLinear in front of the two Resize nodes.  This blob
+# carries exactly what those nodes carry (little endian):
+#
+#     0   char[8]  magic "INFURQ01"
+#     8   u32 depth, u32 num_classes, u32 has_aux, u32 n_convs, u32 n_adds, u32 reserved
+#     32  n_convs x 96-byte entries: char name[40]; u32 cout, cin, kh, kw; f32 x_scale; i32 x_zp; f32 y_scale; i32 y_zp;
+#                                    u64 w_off (s8 OIHW); u64 ws_off (f32 [cout] weight scales); u64 b_off (i32 [cout])
+#     ..  n_adds x 24-byte entries:  f32 a_scale; i32 a_zp; f32 b_scale; i32 b_zp; f32 c_scale; i32 c_zp
+#                                    (A = the block's conv3 output, B = the identity / downsample branch, C = the block output)
+#     ..  data, 64-byte aligned
+# conv 0's (x_scale, x_zp) quantise the normalised image; the (y_scale, y_zp) of classifier.4 / aux_classifier.4 dequantise
+# the logits.  Arithmetic (ONNX operator definitions; every step is one IEEE f32 operation, round = to nearest even):
+#     QuantizeLinear   q = sat_u8(round(x / s) + zp)
+#     QLinearConv      acc = sum (x - x_zp) * w + b   (i32, exact);   y = sat_u8(round(f32(acc) * M[o]) + y_zp),
+#                      M[o] = (x_scale * w_scale[o]) / y_scale;  padding contributes x_zp, i.e. nothing
+#     QLinearAdd       c = sat_u8(round(f32(a - a_zp) * (a_s / c_s) + f32(b - b_zp) * (b_s / c_s)) + c_zp)
+#     DequantizeLinear x = f32(q - zp) * s
+QMAGIC = b"INFURQ01"
+QENTRY, QADD = 96, 24
+
+
+@dataclass
+class QConv:
+    name: str
+    w: np.ndarray        # s8 [cout, cin, kh, kw]
+    w_scale: np.ndarray  # f32 [cout]
+    bias: np.ndarray     # i32 [cout]
+    x_scale: float
+    x_zp: int
+    y_scale: float
+    y_zp: int
+
+
+@dataclass
+class QAdd:
+    a_scale: float
+    a_zp: int
+    b_scale: float
+    b_zp: int
+    c_scale: float
+    c_zp: int
+
+
+def pack_qblob(convs: List[QConv], adds: List[QAdd], depth: int, num_classes: int, aux: bool) -> bytes:
+    n, na = len(convs), len(adds)
+    off = (HDR + n * QENTRY + na * QADD + 63) & ~63
+    table, chunks = bytearray(), []
+    for c in convs:
+        w = np.ascontiguousarray(c.w, dtype=np.int8)
+        ws = np.ascontiguousarray(c.w_scale, dtype=np.float32)
+        b = np.ascontiguousarray(c.bias, dtype=np.int32)
+        assert w.ndim == 4 and ws.shape == (w.shape[0],) and b.shape == (w.shape[0],), c.name
+        offs = []
+        for arr in (w, ws, b):
+            offs.append(off)
+            chunks.append((off, arr))
+            off = (off + arr.nbytes + 63) & ~63
+        nb = c.name.encode()
+        assert len(nb) < 40
+        table += nb.ljust(40, b"\0") + struct.pack("<4IfifI3Q", *w.shape, np.float32(c.x_scale), int(c.x_zp), np.float32(c.y_scale),
+                                                   int(c.y_zp) & 0xFFFFFFFF, *offs)
+    for a in adds:
+        table += struct.pack("<fififi", np.float32(a.a_scale), int(a.a_zp), np.float32(a.b_scale), int(a.b_zp), np.float32(a.c_scale), int(a.c_zp))
+    buf = bytearray(off)
+    buf[0:HDR] = QMAGIC + struct.pack("<6I", depth, num_classes, 1 if aux else 0, n, na, 0)
+    buf[HDR:HDR + len(table)] = table
+    for o, arr in chunks:
+        buf[o:o + arr.nbytes] = arr.tobytes()
+    return bytes(buf)
+
+
+def unpack_qblob(blob: bytes):
+    if len(blob) < HDR or blob[:8] != QMAGIC:
+        raise ValueError("not an INFURQ01 quantised weight blob")
+    depth, ncls, aux, n, na, _ = struct.unpack_from("<6I", blob, 8)
+    convs, adds = [], []
+    for i in range(n):
+        e = HDR + i * QENTRY
+        name = blob[e:e + 40].split(b"\0", 1)[0].decode()
+        cout, cin, kh, kw, xs, xz, ys, yz, w_off, ws_off, b_off = struct.unpack_from("<4Ififi3Q", blob, e + 40)
+        convs.append(QConv(name, np.frombuffer(blob, np.int8, cout * cin * kh * kw, w_off).reshape(cout, cin, kh, kw),
+                           np.frombuffer(blob, np.float32, cout, ws_off), np.frombuffer(blob, np.int32, cout, b_off), xs, xz, ys, yz))
+    for i in range(na):
+        adds.append(QAdd(*struct.unpack_from("<fififi", blob, HDR + n * QENTRY + i * QADD)))
+    return {"depth": depth, "num_classes": ncls, "aux": bool(aux), "n_convs": n, "n_adds": na}, convs, adds
