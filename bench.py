@@ -537,6 +537,10 @@ def main():
         if world == 1 and a.dtype == "f32" and not a.no_split:
             out["f32_split_mode"] = split_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H)
             out["f32_split_fp8_mode"] = split_fp8_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H)
+            try:
+                out["int8_quantised_model"] = int8_mode_rate(a, dev, d_frames, d_masks, Wd, H)
+            except Exception as e:  # noqa: BLE001
+                out["int8_quantised_model"] = {"error": f"{type(e).__name__}: {e}"}
         default_workload = (Wd, H, a.scale, a.dtype, a.depth) == (1920, 1080, 1.0, "f32", 50)
         if world == 1 and not a.no_side:
             try:
@@ -749,6 +753,26 @@ def pcie_inclusive_rate(a, dev, blob, frames_np, dtype="f32"):
     finally:
         for c in lanes:
             c.close()
+
+
+def int8_mode_rate(a, dev, d_frames, d_masks, Wd, H):
+    """The same 1080p frames through a QUANTISED model -- the QOperator int8 form the reference's own tests load
+    (fcn-resnet50-12-int8.onnx, predict_onnx.rs:357-381; here the seeded synthetic FCN-ResNet50 statically quantised by
+    infur_amd/quantize.py): u8 activations x s8 weights on v_mfma_i32_32x32x32_i8, QLinearConv / QLinearAdd / DequantizeLinear
+    arithmetic in the epilogues, bit-exact against the integer oracle (tests/test_gpu_quant.py).  A side measurement: another
+    model file, not another way to compute the headline's."""
+    from infur_amd import quantize
+    from infur_amd import weights as W
+
+    qblob = quantize.synth_qblob(depth=50)
+    fps, ms = resident_rate(a, dev, "f32", qblob, d_frames, d_masks, Wd, H, a.scale, len(d_frames) * a.steps)
+    gop = W.conv_flops(H, Wd, depth=50, aux=not a.no_aux)["total"] / 1e9
+    peak = 2.0 * PEAK_F16_MFMA_TFLOPS  # dense i8 MFMA: twice the f16 rate (MI355X_MICROARCH.md: >= 3944 TOPS measured)
+    return {"value": fps, "unit": "frames/s", "dtype": "int8 (u8 x s8 -> i32)", "ms_per_frame": ms, "contexts_per_gpu": max(1, a.contexts_per_gpu),
+            "model": "FCN-ResNet50, QOperator static quantisation of the synthetic weights (per-channel s8 weights, per-tensor u8 activations)",
+            "parity": "every layer's u8 tensor, the dequantised logits and the mask bit-exact against oracle/infur_qoracle.py (tests/test_gpu_quant.py)",
+            "roofline": {"bound": "mfma", "achieved": gop * fps / 1e3, "peak": peak, "unit": "TOP/s", "frac": gop * fps / 1e3 / peak,
+                         "note": "direct-convolution integer ops (2 x MAC) x frames/s against the dense i8 MFMA peak"}}
 
 
 def r101_f16_4k_rate(a, dev):

@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     // split modes: one accumulator scale per launch, or one per batched problem (the Winograd planes carry their own weight scale)
     const float acc_scale = a.acc_scale_b ? a.acc_scale_b[bidx] : a.acc_scale;
     const bool has_bias = a.bias != nullptr;
-    const bool vec_ok = (a.Cout & 3) == 0;
+    const bool vec_ok = I8 || (a.Cout & 3) == 0;  // (the quantised epilogue guards its 4 channels one by one: 21-class logits too)
 #ifdef KTRACE
     const unsigned long long kt_epi = __builtin_amdgcn_s_memtime();
     struct KtEnd {
@@ -728,13 +728,12 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         int qb[4] = {0, 0, 0, 0};          // I8: folded bias and requantisation multiplier of this lane's 4 channels
         float qm[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (I8) {
-            if (n_ok) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < 4; t++)
+                if (n + t < a.Cout) {
                     qb[t] = a.q_bias[n + t];
                     qm[t] = a.q_mult[n + t];
                 }
-            }
         }
         float vmax = 0.f;  // SPLIT: largest |output| of this lane (range monitor)
 #pragma unroll
@@ -794,7 +793,14 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                             float4 d;
                             d.x = (float)(q[0] - a.q_yzp) * a.q_dq; d.y = (float)(q[1] - a.q_yzp) * a.q_dq;
                             d.z = (float)(q[2] - a.q_yzp) * a.q_dq; d.w = (float)(q[3] - a.q_yzp) * a.q_dq;
-                            *reinterpret_cast<float4*>(out + o) = d;
+                            if ((a.Cout & 3) == 0) {
+                                *reinterpret_cast<float4*>(out + o) = d;
+                            } else {  // (21 logits per pixel: rows are not 16-byte aligned, the last group is partial)
+                                const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                                for (int t = 0; t < 4; t++)
+                                    if (n + t < a.Cout) out[o + t] = dd[t];
+                            }
                         } else {
                             *reinterpret_cast<unsigned*>(out + o) = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
                         }
@@ -855,13 +861,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                 for (int t = 0; t < 4; t++) {
                     if (n + t >= a.Cout) break;
                     if constexpr (I8) {
-                        const int ai = __builtin_bit_cast(int, acc[i][j][4 * g + t]);
-                        int q = q_requant(ai + a.q_bias[n + t], a.q_mult[n + t], a.q_yzp);
-                        if (res) q = q_add(q, a.q_yzp, a.q_ra, (int)(unsigned char)res[o + t], a.q_bzp, a.q_rb, a.q_czp);
-                        if constexpr (std::is_same<OutT, float>::value)
-                            out[o + t] = (OutT)((float)(q - a.q_yzp) * a.q_dq);
-                        else
-                            out[o + t] = (OutT)q;
+                        // (never reached: the quantised epilogue above handles every Cout)
                     } else {
                         float x = acc[i][j][4 * g + t];
                         if constexpr (SPLIT) x *= acc_scale;

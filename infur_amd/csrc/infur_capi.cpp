@@ -18,7 +18,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <array>
+#include <climits>
 #include <cstring>
 #include <exception>
 #include <map>
@@ -296,6 +298,9 @@ void model_free(infur_ctx* c) {
     if (c->d_weights) (void)hipFree(c->d_weights);
     c->d_weights = nullptr;
     c->convs.clear();
+    c->qadds.clear();
+    c->quant = false;
+    c->d_qlut = nullptr;
     c->loaded = false;
     c->weight_bytes = 0;
     pool_release_all(c);
@@ -755,6 +760,256 @@ int32_t run_b2b(infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1, const Te
     return INFUR_OK;
 }
 
+
+// ---- quantised models (INFURQ01) ----
+// d_blob resident on the device.  Header and directory are checked by blob_dir.h (host-only); weights are repacked to
+// OHWI with the channel axes padded to the K step of the i8 GEMM (128 bytes: the 64-channel tensors of the stem and layer1
+// travel as 128 channels, the upper half zero), the operator bias is folded with the (128 - x_zp) * sum w term of the kernel's
+// signed operands, and the requantisation multipliers are computed as ONNX Runtime computes them (f32: x_s * w_s[o] / y_s).
+inline int q_cpad(int c, bool padded) { return padded && c < 128 ? 128 : c; }
+// bytes of a layer's repacked weights: s8 OHWI (padded); the stem: one dword (r, g, b, 0) per tap and channel
+inline size_t q_wbytes(const ConvLayer& L) {
+    return L.role == 's' ? (size_t)L.cout * L.k * L.k * 4 : (size_t)L.cout_p * L.k * L.k * L.cin_p + 64;
+}
+
+int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
+    if (len < kBlobHdr) return fail(c, INFUR_E_MODEL_FORMAT, "weight blob too short (%zu bytes)", len);
+    uint8_t hdr[kBlobHdr];
+    HIPCHK(c, hipMemcpyAsync(hdr, d_blob, kBlobHdr, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    BlobHeader bh;
+    uint32_t n_adds = 0;
+    std::vector<ConvSpec> spec;
+    std::string perr;
+    if (!qblob_parse_header(hdr, len, &bh, &n_adds, &spec, &perr)) return fail(c, INFUR_E_MODEL_FORMAT, "%s", perr.c_str());
+    const uint32_t n = bh.n_convs;
+    std::vector<uint8_t> table((size_t)n * kQEntry + (size_t)n_adds * kQAdd);
+    HIPCHK(c, hipMemcpyAsync(table.data(), (const uint8_t*)d_blob + kBlobHdr, table.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<QBlobConv> qc;
+    std::vector<QBlobAdd> qa;
+    if (!qblob_parse_directory(table.data(), len, spec, n_adds, &qc, &qa, &perr)) return fail(c, INFUR_E_MODEL_FORMAT, "%s", perr.c_str());
+    std::vector<ConvLayer> g = build_graph(bh.depth, bh.num_classes, bh.aux);
+    // a block's QLinearAdd takes conv3's output as A: the kernel requantises with conv3's own (y_scale, y_zp) and adds in place
+    {
+        uint32_t blk = 0;
+        for (uint32_t i = 0; i < n; i++)
+            if (g[i].role == '3') {
+                if (blk >= n_adds || qa[blk].a_zp != qc[i].y_zp || qa[blk].a_scale != qc[i].y_scale)
+                    return fail(c, INFUR_E_MODEL_FORMAT, "residual sum %u does not take '%s' as its first input (scale / zero point differ)", blk, g[i].name.c_str());
+                blk++;
+            }
+    }
+    size_t total = 1024;  // the quantisation table of the image
+    for (uint32_t i = 0; i < n; i++) {
+        ConvLayer& L = g[i];
+        const bool logits = L.role == 'c';
+        L.cin_p = L.role == 's' ? L.cin : q_cpad(L.cin, true);
+        L.cout_p = L.role == 's' ? L.cout : q_cpad(L.cout, !logits);
+        total += align_up(q_wbytes(L), 256) + 2 * align_up((size_t)L.cout_p * 4, 256);
+    }
+    struct DevMem {
+        void* p = nullptr;
+        ~DevMem() { if (p) (void)hipFree(p); }
+    } arena, tmp;
+    HIPCHK(c, hipMalloc(&arena.p, total));
+    HIPCHK(c, hipMemsetAsync(arena.p, 0, total, c->stream));
+    size_t max_c = 0;
+    for (const ConvLayer& L : g) max_c = std::max(max_c, (size_t)L.cout_p);
+    HIPCHK(c, hipMalloc(&tmp.p, max_c * 4));  // row sums of the layer being repacked
+    uint8_t* const base = (uint8_t*)arena.p;
+    size_t off = 0;
+    // image quantisation table: QuantizeLinear of the reference's normalised value of every byte (predict_onnx.rs:126-137)
+    {
+        std::vector<float> pre(768);
+        build_pre_lut(pre.data());
+        std::vector<uint8_t> ql(768);
+        const volatile float xs = qc[0].x_scale;
+        for (int i = 0; i < 768; i++) {
+            volatile float t = pre[i] / xs;  // (one f32 division, then round half to even)
+            float r = std::nearbyintf(t) + (float)qc[0].x_zp;
+            r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+            ql[i] = (uint8_t)r;
+        }
+        HIPCHK(c, hipMemcpyAsync(base + off, ql.data(), 768, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    uint8_t* const d_qlut = base + off;
+    off += 1024;
+    std::vector<int32_t> h_sum, h_bias;
+    std::vector<float> h_ws, h_mult;
+    for (uint32_t i = 0; i < n; i++) {
+        ConvLayer& L = g[i];
+        const size_t taps = (size_t)L.k * L.k;
+        L.x_scale = qc[i].x_scale; L.x_zp = qc[i].x_zp; L.y_scale = qc[i].y_scale; L.y_zp = qc[i].y_zp;
+        L.d_w = base + off;
+        off += align_up(q_wbytes(L), 256);
+        L.d_qbias = (int32_t*)(base + off);
+        off += align_up((size_t)L.cout_p * 4, 256);
+        L.d_qmult = (float*)(base + off);
+        off += align_up((size_t)L.cout_p * 4, 256);
+        const int8_t* src_w = (const int8_t*)d_blob + qc[i].w_off;
+        h_sum.assign(L.cout_p, 0);
+        h_bias.assign(L.cout, 0);
+        h_ws.assign(L.cout, 0.f);
+        if (L.role == 's') {
+            // stem: one dword (r, g, b, 0) per tap and channel, built on the host (9.4 KB)
+            std::vector<int8_t> w((size_t)L.cout * 3 * 49);
+            HIPCHK(c, hipMemcpyAsync(w.data(), src_w, w.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::vector<int32_t> wq((size_t)L.cout * 49);
+            for (int o = 0; o < L.cout; o++)
+                for (int t = 0; t < 49; t++) {
+                    uint32_t d = 0;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const int8_t v = w[((size_t)o * 3 + ch) * 49 + t];
+                        d |= (uint32_t)(uint8_t)v << (8 * ch);
+                        h_sum[o] += v;
+                    }
+                    wq[(size_t)o * 49 + t] = (int32_t)d;
+                }
+            HIPCHK(c, hipMemcpyAsync(L.d_w, wq.data(), wq.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        } else {
+            HIPCHK(c, launch_repack_q(src_w, (int8_t*)L.d_w, (int32_t*)tmp.p, L.cout, L.cin, L.k, L.k, L.cout_p, L.cin_p, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_sum.data(), tmp.p, (size_t)L.cout_p * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(h_bias.data(), (const uint8_t*)d_blob + qc[i].b_off, (size_t)L.cout * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_ws.data(), (const uint8_t*)d_blob + qc[i].ws_off, (size_t)L.cout * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<int32_t> qb(L.cout_p, 0);
+        h_mult.assign(L.cout_p, 0.f);
+        for (int o = 0; o < L.cout; o++) {
+            if (!qscale_ok(h_ws[o])) return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s': weight scale of channel %d is not positive and finite", L.name.c_str(), o);
+            const int64_t b = (int64_t)h_bias[o] + (int64_t)(128 - L.x_zp) * (int64_t)h_sum[o];
+            if (b > INT32_MAX || b < INT32_MIN) return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s': bias of channel %d overflows int32", L.name.c_str(), o);
+            qb[o] = (int32_t)b;
+            volatile float xw = L.x_scale * h_ws[o];  // f32 product, then f32 division: ONNX Runtime's output scale
+            h_mult[o] = xw / L.y_scale;
+        }
+        HIPCHK(c, hipMemcpyAsync(L.d_qbias, qb.data(), (size_t)L.cout_p * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(L.d_qmult, h_mult.data(), (size_t)L.cout_p * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    model_free(c);  // the old model goes only now
+    c->d_weights = arena.p;
+    arena.p = nullptr;
+    c->convs.swap(g);
+    c->qadds.clear();
+    for (const QBlobAdd& a : qa) c->qadds.push_back(QAddParams{a.a_scale, a.b_scale, a.c_scale, a.a_zp, a.b_zp, a.c_zp});
+    c->d_qlut = d_qlut;
+    c->quant = true;
+    c->depth = bh.depth;
+    c->num_classes = bh.num_classes;
+    c->has_aux = bh.aux;
+    c->input_u8 = false;
+    c->weight_bytes = total;
+    c->loaded = true;
+    infur_model_info& mi = c->info;
+    memset(&mi, 0, sizeof mi);
+    snprintf(mi.input_name, sizeof mi.input_name, "input");
+    snprintf(mi.input0_dtype, sizeof mi.input0_dtype, "Float");  // the int8 zoo model keeps float I/O (QuantizeLinear is its first node)
+    snprintf(mi.output_names[0], 32, "out");
+    mi.n_outputs = 1 + ((bh.aux && c->opt.compute_aux) ? 1 : 0);
+    if (mi.n_outputs == 2) snprintf(mi.output_names[1], 32, "aux");
+    mi.num_classes = (uint32_t)bh.num_classes;
+    mi.depth = (uint32_t)bh.depth;
+    mi.n_convs = n;
+    mi.weight_bytes = total;
+    return INFUR_OK;
+}
+
+// one QLinearConv (+ the block's QLinearAdd when `res` is given; f32 output = + DequantizeLinear) on the i8 MFMA
+int32_t run_qconv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, const QAddParams* add, Tensor* out) {
+    const int oh = conv_out(in.h, L.k, L.stride, L.pad, L.dil), ow = conv_out(in.w, L.k, L.stride, L.pad, L.dil);
+    const int out_f32 = L.role == 'c' ? 1 : 0;
+    if (in.c != L.cin_p || in.es != 1) return fail(c, INFUR_E_SHAPE, "'%s' expects %d u8 channels, got %d", L.name.c_str(), L.cin_p, in.c);
+    RETIF(talloc(c, oh, ow, L.cout_p, out_f32 ? 4 : 1, out));
+    ConvArgs a;
+    a.in = in.p; a.wt = L.d_w; a.bias = nullptr; a.res = res ? res->p : nullptr; a.out = out->p;
+    a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = L.cout_p;
+    a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = 0;
+    a.q_mult = L.d_qmult; a.q_bias = L.d_qbias; a.q_yzp = L.y_zp; a.q_dq = L.y_scale;
+    if (res) {
+        if (!add || res->c != L.cout_p || res->h != oh || res->w != ow) return fail(c, INFUR_E_SHAPE, "residual of '%s' has the wrong shape", L.name.c_str());
+        volatile float ra = add->a_scale / add->c_scale, rb = add->b_scale / add->c_scale;  // f32 divisions, as MLAS' QLinearAdd
+        a.q_ra = ra; a.q_rb = rb; a.q_bzp = add->b_zp; a.q_czp = add->c_zp;
+    }
+    const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
+    const double bytes = (double)in.bytes() + (double)out->bytes() + (res ? (double)res->bytes() : 0.0) + (double)L.cout_p * L.cin_p * L.k * L.k;
+    int cfg = -1;
+    RETIF(pick_cfg(c, a, 4, out_f32, &cfg));
+    {
+        ProfScope ps(c, L.name, conv_igemm_config_name(cfg, 4), flops, bytes);
+        HIPCHK(c, launch_conv_igemm(a, 4, out_f32, cfg, c->stream));
+    }
+    if (c->opt.keep_activations) c->kept.push_back(*out);
+    return INFUR_OK;
+}
+
+// the forward of a quantised model: u8 NHWC activations end to end, dequantised f32 logits in c->out_low / c->aux_low
+int32_t forward_q(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
+    size_t ci = 0;
+    const ConvLayer& stem = c->convs[ci++];
+    const int sh = conv_out(h, 7, 2, 3, 1), sw = conv_out(w, 7, 2, 3, 1);
+    const int ph = conv_out(sh, 3, 2, 1, 1), pw = conv_out(sw, 3, 2, 1, 1);
+    Tensor s, x;
+    {
+        RETIF(talloc(c, sh, sw, 64, 1, &s));
+        ProfScope ps(c, stem.name, "stem_q", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)s.bytes());
+        HIPCHK(c, launch_stem_q(d_bgr, h, w, c->d_qlut, stem.x_zp, (const int32_t*)stem.d_w, stem.d_qbias, stem.d_qmult, stem.y_zp, (uint8_t*)s.p, sh, sw, c->stream));
+    }
+    if (c->opt.keep_activations) c->kept.push_back(s);
+    {
+        RETIF(talloc(c, ph, pw, 128, 1, &x));
+        ProfScope ps(c, "backbone.maxpool", "maxpool_q", 0, (double)s.bytes() + (double)x.bytes());
+        HIPCHK(c, launch_maxpool_q((const uint8_t*)s.p, sh, sw, 64, (uint8_t*)x.p, ph, pw, 128, c->stream));
+    }
+    pool_release(c, s);
+    Tensor l3;
+    size_t blk = 0;
+    while (c->convs[ci].role == '1') {
+        const ConvLayer& c1 = c->convs[ci];
+        const ConvLayer& c2 = c->convs[ci + 1];
+        const ConvLayer& c3 = c->convs[ci + 2];
+        const bool has_ds = c->convs[ci + 3].role == 'd';
+        if (blk >= c->qadds.size()) return fail(c, INFUR_E_SHAPE, "quantised model has fewer residual sums than blocks");
+        Tensor t1, t2, idt, y;
+        RETIF(run_qconv(c, c1, x, nullptr, nullptr, &t1));
+        RETIF(run_qconv(c, c2, t1, nullptr, nullptr, &t2));
+        pool_release(c, t1);
+        if (has_ds) RETIF(run_qconv(c, c->convs[ci + 3], x, nullptr, nullptr, &idt));
+        RETIF(run_qconv(c, c3, t2, has_ds ? &idt : &x, &c->qadds[blk], &y));
+        if (has_ds && c->opt.keep_activations) std::swap(c->kept[c->kept.size() - 1], c->kept[c->kept.size() - 2]);  // blob order: conv3, downsample
+        pool_release(c, t2);
+        if (has_ds) pool_release(c, idt);
+        blk++;
+        ci += has_ds ? 4 : 3;
+        const bool end_l3 = c1.name.compare(0, 16, "backbone.layer3.") == 0 && c->convs[ci].name.compare(0, 16, "backbone.layer4.") == 0;
+        if (!(l3.p && x.p == l3.p)) pool_release(c, x);
+        x = y;
+        if (end_l3 && c->has_aux && c->opt.compute_aux) l3 = y;
+    }
+    {
+        Tensor h1;
+        RETIF(run_qconv(c, c->convs[ci], x, nullptr, nullptr, &h1));
+        pool_release(c, x);
+        RETIF(run_qconv(c, c->convs[ci + 1], h1, nullptr, nullptr, &c->out_low));
+        pool_release(c, h1);
+        ci += 2;
+    }
+    if (c->has_aux && c->opt.compute_aux) {
+        Tensor a1;
+        RETIF(run_qconv(c, c->convs[ci], l3, nullptr, nullptr, &a1));
+        pool_release(c, l3);
+        RETIF(run_qconv(c, c->convs[ci + 1], a1, nullptr, nullptr, &c->aux_low));
+        pool_release(c, a1);
+    }
+    c->last_h = h;
+    c->last_w = w;
+    return INFUR_OK;
+}
+
 // FCN-ResNet forward from a packed BGR frame resident on the device.
 // Leaves the output-stride-8 logits in c->out_low / c->aux_low (NHWC).
 int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
@@ -764,6 +1019,7 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     c->frame_no++;
     c->same_size = (h == c->last_h && w == c->last_w) ? c->same_size + 1 : 0;
     if (c->same_size == kPoolTrimAfter) pool_trim(c);  // no tensor is live here: slots may be renumbered
+    if (c->quant) return forward_q(c, d_bgr, w, h);  // a quantised model defines its own arithmetic
     if (c->d_range) HIPCHK(c, hipMemsetAsync(c->d_range, 0, 2 * sizeof(unsigned), c->stream));
     size_t ci = 0;
     const ConvLayer& stem = c->convs[ci++];
@@ -1082,6 +1338,12 @@ int32_t infur_model_load_blob_dev(infur_ctx* c, const void* d_blob, size_t len) 
     try {
         enter(c);
         if (!c || !d_blob) return INFUR_E_INVALID_ARG;
+        char magic[8] = {0};
+        if (len >= 8) {
+            HIPCHK(c, hipMemcpyAsync(magic, d_blob, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (memcmp(magic, "INFURQ01", 8) == 0) return model_load_q_dev(c, d_blob, len);
         return model_load_dev(c, d_blob, len);
     } catch (const std::bad_alloc&) {
         return fail(c, INFUR_E_CAPACITY, "out of host memory");
@@ -1094,12 +1356,14 @@ int32_t infur_model_load_blob(infur_ctx* c, const void* blob, size_t len) {
     try {
         enter(c);
         if (!c || !blob) return INFUR_E_INVALID_ARG;
-        if (len < kBlobHdr || memcmp(blob, "INFURW01", 8) != 0)
-            return fail(c, INFUR_E_MODEL_FORMAT, "bad magic: not an INFURW01 weight blob");
+        const bool quant = len >= kBlobHdr && memcmp(blob, "INFURQ01", 8) == 0;
+        if (len < kBlobHdr || (!quant && memcmp(blob, "INFURW01", 8) != 0))
+            return fail(c, INFUR_E_MODEL_FORMAT, "bad magic: not an INFURW01 / INFURQ01 weight blob");
         void* d = nullptr;
         HIPCHK(c, hipMalloc(&d, len));
         hipError_t e = hipMemcpyAsync(d, blob, len, hipMemcpyHostToDevice, c->stream);
-        int32_t rc = e == hipSuccess ? model_load_dev(c, d, len) : fail(c, INFUR_E_HIP, "weight upload failed: %s", hipGetErrorString(e));
+        int32_t rc = e != hipSuccess ? fail(c, INFUR_E_HIP, "weight upload failed: %s", hipGetErrorString(e))
+                                     : (quant ? model_load_q_dev(c, d, len) : model_load_dev(c, d, len));
         (void)hipStreamSynchronize(c->stream);
         (void)hipFree(d);
         return rc;
@@ -1125,7 +1389,8 @@ int32_t infur_model_load(infur_ctx* c, const char* path) {
         fclose(f);
         if (got != buf.size()) return fail(c, INFUR_E_IO, "short read on '%s'", path);
         if (buf.empty()) return fail(c, INFUR_E_MODEL_FORMAT, "model file '%s' is empty", path);
-        if (buf.size() >= 8 && memcmp(buf.data(), "INFURW01", 8) == 0) return infur_model_load_blob(c, buf.data(), buf.size());
+        if (buf.size() >= 8 && (memcmp(buf.data(), "INFURW01", 8) == 0 || memcmp(buf.data(), "INFURQ01", 8) == 0))
+            return infur_model_load_blob(c, buf.data(), buf.size());
         if (looks_like_onnx(buf.data(), buf.size())) {
             std::vector<uint8_t> blob;
             OnnxInfo oi;
@@ -1317,7 +1582,10 @@ int32_t infur_debug_read_activation(infur_ctx* c, uint32_t index, float* host, s
         if (w) *w = (uint32_t)t.w;
         if (cap < t.elems()) return fail(c, INFUR_E_CAPACITY, "activation needs %zu floats", t.elems());
         RETIF(ensure(c, c->st_f32a, t.elems() * 4));
-        HIPCHK(c, launch_nhwc_to_planar(t.p, t.es == 2, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
+        if (t.es == 1)  // a quantised activation: the byte values
+            HIPCHK(c, launch_u8_nhwc_to_planar((const uint8_t*)t.p, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
+        else
+            HIPCHK(c, launch_nhwc_to_planar(t.p, t.es == 2, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
         HIPCHK(c, hipMemcpyAsync(host, c->st_f32a.p, t.elems() * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return INFUR_OK;

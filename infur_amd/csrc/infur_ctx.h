@@ -50,6 +50,18 @@ struct ConvLayer {
     // f16 mode, conv3 of a block whose successor's conv1 can run in the same launch (conv1x1_b2b.hip): the weight matrix in
     // the step-interleaved row order that kernel streams
     void* d_w3i = nullptr;
+    // quantised models (INFURQ01): d_w = s8 OHWI with cin_p input channels and cout_p rows (zero padded to the K step of the i8
+    // GEMM); d_qbias = operator bias + (128 - x_zp) * sum_k w (the kernel feeds x - 128); d_qmult = x_scale * w_scale[o] / y_scale
+    int cin_p = 0, cout_p = 0;
+    float x_scale = 0.f, y_scale = 0.f;
+    int x_zp = 0, y_zp = 0;
+    int32_t* d_qbias = nullptr;
+    float* d_qmult = nullptr;
+};
+
+struct QAddParams {  // com.microsoft QLinearAdd of one bottleneck: C = A (conv3) + B (identity / downsample)
+    float a_scale, b_scale, c_scale;
+    int a_zp, b_zp, c_zp;
 };
 
 struct ProfRec {
@@ -79,6 +91,9 @@ struct infur_ctx {
     int depth = 0, num_classes = 0;
     bool has_aux = false;
     bool input_u8 = false;  // the model declares a Uint8 image input: raw BGR bytes, no normalisation
+    bool quant = false;     // a quantised (QOperator) model: u8 activations, s8 weights, the i8 MFMA -- whatever compute_dtype says
+    std::vector<infur::QAddParams> qadds;
+    uint8_t* d_qlut = nullptr;  // [3][256] u8: byte value -> QuantizeLinear of the normalised value (RGB order); in d_weights
     std::vector<infur::ConvLayer> convs;
     void* d_weights = nullptr;  // single allocation holding every repacked tensor
     size_t weight_bytes = 0;

@@ -285,6 +285,8 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
         L.d_bcat = (float*)rebase(L.d_bcat);
         L.d_w3i = rebase(L.d_w3i);
         L.d_uacc = (float*)rebase(L.d_uacc);
+        L.d_qbias = (int32_t*)rebase(L.d_qbias);
+        L.d_qmult = (float*)rebase(L.d_qmult);
     }
     dst->d_weights = d_weights;
     dst->weight_bytes = root->weight_bytes;
@@ -292,6 +294,9 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
     dst->num_classes = root->num_classes;
     dst->has_aux = root->has_aux;
     dst->input_u8 = root->input_u8;
+    dst->quant = root->quant;
+    dst->qadds = root->qadds;
+    dst->d_qlut = (uint8_t*)rebase(root->d_qlut);
     dst->info = root->info;
     dst->info.n_outputs = 1 + ((root->has_aux && dst->opt.compute_aux) ? 1 : 0);
     if (dst->info.n_outputs < 2) dst->info.output_names[1][0] = 0;

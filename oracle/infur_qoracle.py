@@ -16,10 +16,7 @@ with round = round-half-to-even and every floating-point step ONE IEEE f32 opera
 ONNX Runtime's MLAS requantisation uses: int32 -> f32, one multiply, nearbyint, + zero point, saturate).  The integer
 convolution is evaluated exactly (float64 conv2d on integer-valued operands: |acc| < 2^53).
 
-`quantise_model` makes a quantised model out of the seeded synthetic float one (static quantisation as ONNX Runtime's /
-Neural Compressor's tools do it: u8 activations with per-tensor scale and zero point from calibration ranges, s8 weights
-with per-output-channel scales and zero point 0, int32 bias in units of x_s * w_s[o]; a tensor that follows a ReLU is
-calibrated from 0, so its zero point is 0 and the ReLU is the clamp).
+The quantised model itself comes from infur_amd/quantize.py (static quantisation of the seeded synthetic float model).
 """
 from __future__ import annotations
 
@@ -129,114 +126,7 @@ def qforward(blob: bytes, chw: np.ndarray, taps: Optional[Dict[str, np.ndarray]]
     return out, aux
 
 
-# --------------------------------------------------------------------------- #
-# static quantisation of the synthetic float model
-# --------------------------------------------------------------------------- #
-def _act_params(lo: float, hi: float) -> Tuple[float, int]:
-    lo, hi = min(0.0, float(lo)), max(0.0, float(hi))
-    scale = max((hi - lo) / 255.0, 1e-8)
-    zp = int(np.clip(np.rint(-lo / scale), 0, 255))
-    return float(f32(scale)), zp
+def synth_qblob(depth: int = 50) -> bytes:
+    from infur_amd import quantize
 
-
-def quantise_model(float_blob: bytes, calib_chw: List[np.ndarray]) -> bytes:
-    """INFURW01 float blob + calibration inputs (normalised [3,h,w] f32) -> INFURQ01 quantised blob"""
-    import torch
-
-    F = torch.nn.functional
-    meta, tensors = W.unpack_blob(float_blob)
-    specs = W.graph(meta["depth"], meta["num_classes"], meta["aux"])
-    params = [(torch.from_numpy(np.array(w)), torch.from_numpy(np.array(b))) for _, w, b in tensors]
-    rng: Dict[str, List[float]] = {}
-
-    def see(name, t):
-        lo, hi = float(t.min()), float(t.max())
-        r = rng.setdefault(name, [lo, hi])
-        r[0], r[1] = min(r[0], lo), max(r[1], hi)
-
-    with torch.no_grad():
-        for chw in calib_chw:
-            x = torch.from_numpy(np.ascontiguousarray(chw, np.float32))[None]
-            see("input", x)
-            it = iter(zip(specs, params))
-
-            def conv(x, relu):
-                s, (w, b) = next(it)
-                y = F.conv2d(x, w, b, stride=s.stride, padding=s.pad, dilation=s.dil)
-                if relu:
-                    y = F.relu(y)
-                see(s.name, y)
-                return y, s
-
-            x, _ = conv(x, True)
-            x = F.max_pool2d(x, 3, 2, 1)
-            i, l3, blk = 1, None, 0
-            while specs[i].role == "conv1":
-                has_down = specs[i + 3].role == "down"
-                t, _ = conv(x, True)
-                t, _ = conv(t, True)
-                y3, s3 = conv(t, False)  # the QLinearConv of conv3 has no ReLU: the Add follows
-                idt = x
-                if has_down:
-                    idt, _ = conv(x, False)
-                x = F.relu(y3 + idt)
-                see(f"add{blk}", x)
-                blk += 1
-                i += 4 if has_down else 3
-                if s3.name.startswith("backbone.layer3.") and specs[i].name.startswith("backbone.layer4."):
-                    l3 = x
-            h, _ = conv(x, True)
-            conv(h, False)
-            if meta["aux"]:
-                a, _ = conv(l3, True)
-                conv(a, False)
-
-    act = {k: _act_params(*v) for k, v in rng.items()}
-    convs: List[W.QConv] = []
-    adds: List[W.QAdd] = []
-    # which tensor feeds each conv: walk the graph again, names only
-    src_of: Dict[str, str] = {}
-    cur, i, blk, l3n = "backbone.conv1", 1, 0, None
-    src_of["backbone.conv1"] = "input"
-    while specs[i].role == "conv1":
-        has_down = specs[i + 3].role == "down"
-        src_of[specs[i].name] = cur
-        src_of[specs[i + 1].name] = specs[i].name
-        src_of[specs[i + 2].name] = specs[i + 1].name
-        if has_down:
-            src_of[specs[i + 3].name] = cur
-        a_p, c_p = act[specs[i + 2].name], act[f"add{blk}"]
-        b_p = act[specs[i + 3].name] if has_down else act[cur]
-        adds.append(W.QAdd(a_p[0], a_p[1], b_p[0], b_p[1], c_p[0], c_p[1]))
-        act[f"blockout{blk}"] = c_p
-        name3 = specs[i + 2].name
-        cur = f"add{blk}"
-        blk += 1
-        i += 4 if has_down else 3
-        if name3.startswith("backbone.layer3.") and specs[i].name.startswith("backbone.layer4."):
-            l3n = cur
-    src_of[specs[i].name] = cur
-    src_of[specs[i + 1].name] = specs[i].name
-    if meta["aux"]:
-        src_of[specs[i + 2].name] = l3n
-        src_of[specs[i + 3].name] = specs[i + 2].name
-    for s, (_, w, b) in zip(specs, tensors):
-        xs, xz = act[src_of[s.name]]
-        ys, yz = act[s.name]
-        w = np.asarray(w, np.float64)
-        amax = np.abs(w).reshape(s.cout, -1).max(1)
-        ws = np.maximum(amax / 127.0, 1e-12).astype(f32)
-        wq = np.clip(np.rint(w / ws.astype(np.float64)[:, None, None, None]), -127, 127).astype(np.int8)
-        bq = np.rint(np.asarray(b, np.float64) / (np.float64(f32(xs)) * ws.astype(np.float64))).astype(np.int64)
-        bq = np.clip(bq, -2**31 + 1, 2**31 - 1).astype(np.int32)
-        convs.append(W.QConv(s.name, wq, ws, bq, xs, xz, ys, yz))
-    return W.pack_qblob(convs, adds, meta["depth"], meta["num_classes"], meta["aux"])
-
-
-def synth_qblob(depth: int = 50, calib: int = 3, size: Tuple[int, int] = (96, 128)) -> bytes:
-    """the seeded synthetic model, statically quantised on `calib` synthetic frames"""
-    from oracle.infur_oracle import COracle
-
-    co = COracle()
-    frames = [co.pack_normalize(W.synth_frame(size[0], size[1], index=100 + k)) for k in range(calib)]
-    return quantise_model(W.synth_blob(depth=depth), frames)
+    return quantize.synth_qblob(depth=depth)

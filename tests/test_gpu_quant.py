@@ -1,0 +1,105 @@
+"""Quantised models (the QOperator int8 form the reference's own tests load: fcn-resnet50-12-int8.onnx, predict_onnx.rs:357-381):
+u8 activations x s8 weights on v_mfma_i32_32x32x32_i8 with the QLinearConv / QLinearAdd / DequantizeLinear arithmetic in the
+epilogues.  Integer accumulation is exact and every requantisation step is one defined f32 operation, so this is the one
+forward where parity is BIT-EXACT: every layer's u8 tensor, the dequantised logits and the mask must equal the integer oracle
+(oracle/infur_qoracle.py) byte for byte, at sizes that are ragged against every tile."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from infur_amd import weights as W
+from infur_amd.processors import Context, FramePath, Model, ModelCmd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qblob():
+    from oracle import infur_qoracle as Q
+
+    return Q.synth_qblob()
+
+
+@pytest.mark.parametrize("size", [(96, 128), (72, 104), (135, 241), (8, 8)])
+def test_every_layer_and_the_logits_are_bit_exact(qblob, oracle, size):
+    from oracle import infur_qoracle as Q
+
+    h, w = size
+    fr = W.synth_frame(h, w, index=h)
+    taps = {}
+    ref_lo, ref_aux = Q.qforward(qblob, oracle.pack_normalize(fr), taps)
+    c = Context(device=0, keep_activations=True)
+    m = Model(c).control(ModelCmd.LoadBlob(qblob))
+    info = m.get_info()
+    assert info.output_names == ["out", "aux"] and info.depth == 50
+    rgba, _ = FramePath(c).advance(fr, 1.0)
+    lo, la = m.lowres()
+    for i, spec in enumerate(W.graph(50)):
+        ref = taps[spec.name]
+        if spec.role in ("cls", "auxcls"):
+            continue  # the logit convs leave the stack dequantised: compared below
+        buf = np.empty(64 << 18, np.float32) if i == 0 else buf
+        cc, hh, ww = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        c.check(c.L.infur_debug_read_activation(c.h, i, buf.ctypes.data, buf.size, C.byref(cc), C.byref(hh), C.byref(ww)))
+        got = buf[: cc.value * hh.value * ww.value].reshape(cc.value, hh.value, ww.value)
+        assert (hh.value, ww.value) == ref.shape[1:] and cc.value >= ref.shape[0], spec.name
+        assert (got[: ref.shape[0]] == ref.astype(np.float32)).all(), (spec.name, int((got[: ref.shape[0]] != ref).sum()))
+        assert (got[ref.shape[0]:] == 0).all(), spec.name  # channel padding of the 64-channel tensors
+    assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
+    assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, h, w))).all()
+    c.close()
+
+
+def test_model_advance_and_tile_configurations(qblob, oracle):
+    """Model::advance (full-resolution f32 outputs) on a quantised model; results do not depend on the tile configuration
+    (autotuned here, heuristic there) -- integer accumulation has no summation order"""
+    from oracle import infur_qoracle as Q
+
+    fr = W.synth_frame(120, 200, index=9)
+    ref_lo, ref_aux = Q.qforward(qblob, oracle.pack_normalize(fr))
+    outs = []
+    for autotune in (True, False):
+        c = Context(device=0, autotune=autotune)
+        m = Model(c).control(ModelCmd.LoadBlob(qblob))
+        out = []
+        m.advance(fr, out)
+        assert len(out) == 2 and out[0].shape == (21, 120, 200)
+        assert (out[0].view(np.uint32) == oracle.upsample_bilinear(ref_lo, 120, 200).view(np.uint32)).all()
+        assert (out[1].view(np.uint32) == oracle.upsample_bilinear(ref_aux, 120, 200).view(np.uint32)).all()
+        outs.append(out[0])
+        c.close()
+    assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all()
+
+
+def test_quantised_logits_track_the_float_model(qblob, oracle, blob50):
+    """sanity of the quantiser, not of the kernels: the dequantised logits stay near the float model's"""
+    from oracle.infur_oracle import TorchModel
+
+    fr = W.synth_frame(96, 128, index=5)
+    c = Context(device=0)
+    m = Model(c).control(ModelCmd.LoadBlob(qblob))
+    FramePath(c).advance(fr, 1.0)
+    lo, _ = m.lowres()
+    fl, _ = TorchModel(blob50).forward_lowres(oracle.pack_normalize(fr))
+    fl = fl.numpy()
+    assert np.abs(lo - fl).max() / np.abs(fl).max() < 0.15 and (lo.argmax(0) == fl.argmax(0)).mean() > 0.85
+    c.close()
+
+
+def test_switching_between_float_and_quantised_models(qblob, blob50, oracle):
+    """ModelCmd::Load of a quantised file after a float one (and back) on the same context"""
+    from oracle import infur_qoracle as Q
+
+    fr = W.synth_frame(64, 96, index=1)
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(blob50))
+        ref_f, _ = FramePath(c).advance(fr, 1.0)
+        m.control(ModelCmd.LoadBlob(qblob))
+        rq, _ = FramePath(c).advance(fr, 1.0)
+        lo, _ = m.lowres()
+        ref_lo, _ = Q.qforward(qblob, oracle.pack_normalize(fr))
+        assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all()
+        m.control(ModelCmd.LoadBlob(blob50))
+        again, _ = FramePath(c).advance(fr, 1.0)
+        assert (again == ref_f).all() and rq.shape == ref_f.shape
