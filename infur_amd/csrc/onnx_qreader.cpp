@@ -1,0 +1,430 @@
+// onnx_qreader.cpp -- ModelCmd::Load of the QUANTISED model file: the QOperator int8 form of FCN-ResNet the reference's own
+// tests load (`fcn-resnet50-12-int8.onnx`: infur-test-gen/build.rs:88-93, infur/src/predict_onnx.rs:357-381) -> INFURQ01.
+//
+// The zoo file itself is not available in this environment (no network); what is accepted here is the graph ONNX Runtime's /
+// Neural Compressor's static quantisation writes for that network in QOperator format, followed by its EDGES from the image
+// input exactly as onnx_reader.cpp follows the float graph:
+//   input (Float, NCHW) -> QuantizeLinear -> QLinearConv 7x7/2 -> MaxPool 3x3/2 (on u8)
+//   per bottleneck: QLinearConv 1x1 -> QLinearConv 3x3 -> QLinearConv 1x1 -> QLinearAdd(com.microsoft) with the identity or
+//                   the downsample QLinearConv of the block's input; ReLUs are folded into the clamps (a Relu node left on a
+//                   tensor whose zero point is 0 is looked through)
+//   heads: QLinearConv 3x3 -> QLinearConv 1x1 -> DequantizeLinear -> Resize(linear, [pytorch_]half_pixel) -> output 0 / 1
+// Requirements (format errors otherwise): u8 activations (zero points UINT8), s8 weights with zero point 0 and one scale per
+// tensor or per output channel, int32 bias, group 1, every shape / stride / pad / dilation as torchvision's fcn_resnet50/101.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "blob_dir.h"
+#include "onnx_pb.h"
+#include "onnx_reader.h"
+
+namespace infur {
+namespace {
+
+using namespace pb;
+
+struct QGraph {
+    std::map<std::string, Tensor> inits;
+    std::vector<Node> nodes;
+    std::map<std::string, std::vector<int>> consumers;
+    std::map<std::string, int> producer;
+};
+
+bool scalar_f32(const QGraph& g, const std::string& name, float* v) {
+    auto it = g.inits.find(name);
+    std::vector<float> f;
+    if (it == g.inits.end() || it->second.dims.size() > 1 || !it->second.floats(f) || f.size() != 1) return false;
+    *v = f[0];
+    return true;
+}
+
+// bytes of an integer tensor (UINT8 = 2, INT8 = 3, INT32 = 6) stored as raw_data or as int32_data (field 5 is not parsed by
+// onnx_pb.h: exporters write quantised initializers as raw_data)
+bool int_bytes(const Tensor& t, int dtype, size_t elem, size_t* n, const uint8_t** p) {
+    size_t cnt = 1;
+    if (!t.dims.empty() && !t.count(cnt)) return false;
+    if (t.dtype != dtype || t.external || !t.raw || t.raw_len != cnt * elem) return false;
+    *n = cnt;
+    *p = t.raw;
+    return true;
+}
+
+bool scalar_u8(const QGraph& g, const std::string& name, int32_t* v) {
+    auto it = g.inits.find(name);
+    if (it == g.inits.end()) return false;
+    size_t n;
+    const uint8_t* p;
+    if (!int_bytes(it->second, 2, 1, &n, &p) || n != 1) return false;
+    *v = p[0];
+    return true;
+}
+
+struct QC {  // one QLinearConv as the blob wants it
+    int node = -1;
+    int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, dil = 1;
+    float x_scale = 0, y_scale = 0;
+    int32_t x_zp = 0, y_zp = 0;
+    const uint8_t* w = nullptr;
+    std::vector<float> w_scale;
+    std::vector<int32_t> bias;
+    std::string out;
+};
+
+bool read_qconv(const QGraph& g, int ni, QC* q, std::string* err) {
+    const Node& n = g.nodes[ni];
+    auto bad = [&](const std::string& m) { *err = "QLinearConv '" + (n.out.empty() ? std::string("?") : n.out[0]) + "': " + m; return false; };
+    if (n.in.size() < 8 || n.out.empty()) return bad("needs 8 or 9 inputs and an output");
+    if (!scalar_f32(g, n.in[1], &q->x_scale) || !scalar_u8(g, n.in[2], &q->x_zp)) return bad("x_scale / x_zero_point must be a float / UINT8 scalar initializer");
+    if (!scalar_f32(g, n.in[6], &q->y_scale) || !scalar_u8(g, n.in[7], &q->y_zp)) return bad("y_scale / y_zero_point must be a float / UINT8 scalar initializer");
+    if (!qscale_ok(q->x_scale) || !qscale_ok(q->y_scale)) return bad("scales must be positive and finite");
+    auto wi = g.inits.find(n.in[3]);
+    if (wi == g.inits.end() || wi->second.dims.size() != 4) return bad("the weight must be a 4-D initializer");
+    const Tensor& wt = wi->second;
+    for (auto d : wt.dims)
+        if (d <= 0 || d > 65536) return bad("absurd weight shape");
+    q->cout = (int)wt.dims[0]; q->cin = (int)wt.dims[1]; q->kh = (int)wt.dims[2]; q->kw = (int)wt.dims[3];
+    size_t wn;
+    if (wt.dtype == 2) return bad("UINT8 weights are not supported (INT8 with zero point 0 is what the quantisers write for convolutions)");
+    if (!int_bytes(wt, 3, 1, &wn, &q->w)) return bad("the weight must be INT8 raw_data");
+    // weight zero point: INT8 scalar or [cout], all zero
+    {
+        auto zi = g.inits.find(n.in[5]);
+        size_t zn;
+        const uint8_t* zp;
+        if (zi == g.inits.end() || !int_bytes(zi->second, 3, 1, &zn, &zp) || (zn != 1 && zn != (size_t)q->cout)) return bad("w_zero_point must be an INT8 scalar or [cout] initializer");
+        for (size_t i = 0; i < zn; i++)
+            if (zp[i] != 0) return bad("a non-zero weight zero point is not supported");
+    }
+    {
+        auto si = g.inits.find(n.in[4]);
+        std::vector<float> ws;
+        if (si == g.inits.end() || si->second.dtype != 1) return bad("w_scale must be a float initializer");
+        if (si->second.dims.size() > 1 || !si->second.floats(ws)) return bad("w_scale must be a float scalar or [cout] initializer");
+        if (ws.size() == 1) ws.assign((size_t)q->cout, ws[0]);
+        if (ws.size() != (size_t)q->cout) return bad("w_scale must be a scalar or have one value per output channel");
+        for (float s : ws)
+            if (!qscale_ok(s)) return bad("weight scales must be positive and finite");
+        q->w_scale = ws;
+    }
+    q->bias.assign((size_t)q->cout, 0);
+    if (n.in.size() > 8 && !n.in[8].empty()) {
+        auto bi = g.inits.find(n.in[8]);
+        size_t bn;
+        const uint8_t* bp;
+        if (bi == g.inits.end() || !int_bytes(bi->second, 6, 4, &bn, &bp) || bn != (size_t)q->cout) return bad("the bias must be an INT32 [cout] initializer");
+        memcpy(q->bias.data(), bp, bn * 4);
+    }
+    auto attr1 = [&](const char* name, int64_t dflt, size_t count, int64_t* v) {
+        auto it = n.ints.find(name);
+        if (it == n.ints.end()) { *v = dflt; return true; }
+        if (it->second.size() != count) return false;
+        for (auto x : it->second)
+            if (x != it->second[0]) return false;
+        *v = it->second[0];
+        return true;
+    };
+    int64_t st, pd, dl, grp;
+    if (!attr1("strides", 1, 2, &st) || !attr1("pads", 0, 4, &pd) || !attr1("dilations", 1, 2, &dl) || !attr1("group", 1, 1, &grp)) return bad("strides / pads / dilations must be uniform");
+    if (grp != 1 || st < 1 || st > 2 || pd < 0 || pd > 8 || dl < 1 || dl > 8) return bad("unsupported group / stride / pad / dilation");
+    auto ap = n.strs.find("auto_pad");
+    if (ap != n.strs.end() && ap->second != "NOTSET") return bad("auto_pad is not supported");
+    q->stride = (int)st; q->pad = (int)pd; q->dil = (int)dl;
+    q->node = ni;
+    q->out = n.out[0];
+    return true;
+}
+
+}  // namespace
+
+// 0 ok; 1 malformed; 2 parsed but not a model this path can run.  `data` is a ModelProto whose graph contains QLinearConv.
+int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, OnnxInfo& info, std::string& err) {
+    PB m(data, len);
+    uint32_t f, wt; uint64_t v; const uint8_t* s; size_t l;
+    const uint8_t* gp = nullptr;
+    size_t gl = 0;
+    while (m.next(f, wt, v, s, l))
+        if (f == 7 && wt == 2) { gp = s; gl = l; }
+    if (!m.ok || !gp) { err = "not an ONNX ModelProto (no graph)"; return 1; }
+    QGraph g;
+    std::vector<ValueInfo> inputs, outputs;
+    PB gr(gp, gl);
+    while (gr.next(f, wt, v, s, l)) {
+        if (wt != 2) continue;
+        if (f == 1) { Node n; if (!parse_node(s, l, n)) { err = "malformed NodeProto"; return 1; } g.nodes.push_back(std::move(n)); }
+        else if (f == 5) { std::string name; Tensor t; if (!parse_tensor(s, l, name, t)) { err = "malformed or external-data TensorProto"; return 1; } g.inits[name] = std::move(t); }
+        else if (f == 11) { ValueInfo vi; if (!parse_value_info(s, l, vi)) { err = "malformed graph input"; return 1; } inputs.push_back(std::move(vi)); }
+        else if (f == 12) { ValueInfo vi; if (!parse_value_info(s, l, vi)) { err = "malformed graph output"; return 1; } outputs.push_back(std::move(vi)); }
+    }
+    if (!gr.ok) { err = "malformed GraphProto"; return 1; }
+    // input 0: the reference's infer_img_pre_proc (predict_onnx.rs:223-265); the int8 zoo file keeps a Float NCHW input
+    const ValueInfo* in0 = nullptr;
+    for (auto& vi : inputs)
+        if (!g.inits.count(vi.name)) { in0 = &vi; break; }
+    if (!in0) { err = "model has no image input"; return 1; }
+    int col = -1;
+    for (size_t i = 0; i < in0->dims.size(); i++)
+        if (in0->dims[i] == 3) { col = (int)i; break; }
+    if (col < 0) { err = "couldn't locate model's color input by dimension length 3"; return 2; }
+    if (in0->dims.size() != 4) { err = "only 4 dimensions supported got " + std::to_string(in0->dims.size()); return 2; }
+    if (col != 1) { err = "quantised model: only an NCHW image input is supported"; return 2; }
+    if (in0->elem_type != 1) { err = "quantised model: only a Float (f32) image input (QuantizeLinear is the first node) is supported"; return 2; }
+    info.input_name = in0->name;
+    info.input_dtype = "Float";
+    info.input_u8 = false;
+    info.input_nhwc = false;
+    for (auto& o : outputs) info.output_names.push_back(o.name);
+
+    for (size_t i = 0; i < g.nodes.size(); i++) {
+        for (auto& o : g.nodes[i].out) g.producer[o] = (int)i;
+        for (auto& in : g.nodes[i].in)
+            if (!in.empty() && !g.inits.count(in)) g.consumers[in].push_back((int)i);
+    }
+    // value-preserving nodes: Identity / Dropout always; a Relu on a u8 tensor whose zero point is 0 (checked by the caller)
+    auto transparent = [&](const Node& n) { return n.op == "Identity" || n.op == "Dropout" || n.op == "Relu"; };
+    std::function<void(const std::string&, std::vector<int>&, int)> users_d = [&](const std::string& t, std::vector<int>& out, int depth) {
+        auto it = g.consumers.find(t);
+        if (it == g.consumers.end() || depth > 64) return;
+        for (int i : it->second) {
+            const Node& n = g.nodes[i];
+            if (n.op == "Shape") continue;
+            if (transparent(n)) { if (!n.out.empty() && n.in[0] == t) users_d(n.out[0], out, depth + 1); }
+            else out.push_back(i);
+        }
+    };
+    auto users = [&](const std::string& t) { std::vector<int> u; users_d(t, u, 0); return u; };
+    auto origin = [&](std::string t) {
+        for (int guard = 0; guard < 64; guard++) {
+            auto it = g.producer.find(t);
+            if (it == g.producer.end() || !transparent(g.nodes[it->second]) || g.nodes[it->second].in.empty()) break;
+            t = g.nodes[it->second].in[0];
+        }
+        return t;
+    };
+
+    size_t nq = 0;
+    for (auto& n : g.nodes) nq += n.op == "QLinearConv";
+    int depth = 0;
+    bool aux = false;
+    switch (nq) {
+        case 57: depth = 50; aux = true; break;
+        case 55: depth = 50; break;
+        case 108: depth = 101; aux = true; break;
+        case 106: depth = 101; break;
+        default: err = "model has " + std::to_string(nq) + " QLinearConv nodes; fcn_resnet50 has 57 (55 without aux), fcn_resnet101 108 (106)"; return 2;
+    }
+    int lb[4];
+    layer_blocks(depth, lb);
+
+    std::vector<QC> convs;
+    std::vector<QBlobAdd> adds;
+    std::map<std::string, int32_t> zp_of;  // every u8 tensor the walk produced -> its zero point
+    std::vector<char> used(g.nodes.size(), 0);
+    auto take = [&](int ni, QC* q) {
+        if (used[ni]) { err = "a QLinearConv is reached twice by the walk"; return false; }
+        used[ni] = 1;
+        if (!read_qconv(g, ni, q, &err)) return false;
+        zp_of[q->out] = q->y_zp;
+        return true;
+    };
+    auto sole = [&](const std::string& t, const char* op, const char* what, int* idx) {
+        const std::vector<int> u = users(t);
+        if (u.size() != 1 || g.nodes[u[0]].op != op) {
+            err = std::string("expected exactly one ") + op + " after " + what + ", found " + std::to_string(u.size()) + (u.empty() ? "" : " (" + g.nodes[u[0]].op + ")");
+            return false;
+        }
+        *idx = u[0];
+        return true;
+    };
+    // ---- front: QuantizeLinear of the image ----
+    int ni;
+    if (!sole(in0->name, "QuantizeLinear", "the image input", &ni)) return 2;
+    float in_scale;
+    int32_t in_zp;
+    if (g.nodes[ni].in.size() < 3 || !scalar_f32(g, g.nodes[ni].in[1], &in_scale) || !scalar_u8(g, g.nodes[ni].in[2], &in_zp) || !qscale_ok(in_scale)) {
+        err = "the image's QuantizeLinear needs a float scale and a UINT8 zero point initializer"; return 2;
+    }
+    std::string t = g.nodes[ni].out[0];
+    // ---- stem + max-pool ----
+    QC stem;
+    if (!sole(t, "QLinearConv", "QuantizeLinear", &ni) || !take(ni, &stem)) return 2;
+    if (stem.x_scale != in_scale || stem.x_zp != in_zp) { err = "the stem's x_scale / x_zero_point differ from the image's QuantizeLinear"; return 2; }
+    convs.push_back(stem);
+    if (!sole(stem.out, "MaxPool", "the stem", &ni)) return 2;
+    {
+        const Node& mp = g.nodes[ni];
+        auto chk = [&](const char* nm, std::vector<int64_t> want) { auto it = mp.ints.find(nm); return it != mp.ints.end() && it->second == want; };
+        if (!chk("kernel_shape", {3, 3}) || !chk("strides", {2, 2}) || !chk("pads", {1, 1, 1, 1})) { err = "the stem's MaxPool must be 3x3 / 2 / pad 1"; return 2; }
+        auto cm = mp.ints.find("ceil_mode");
+        if (cm != mp.ints.end() && cm->second[0] != 0) { err = "MaxPool ceil_mode is not supported"; return 2; }
+        t = mp.out[0];
+        zp_of[t] = stem.y_zp;
+    }
+    // ---- bottlenecks ----
+    std::string l3;
+    for (int L = 0; L < 4; L++) {
+        const int planes = 64 << L;
+        for (int b = 0; b < lb[L]; b++) {
+            const bool has_ds = b == 0;
+            const std::vector<int> u = users(t);
+            int i1 = -1, ids = -1, iadd = -1;
+            size_t n_block_users = 0;
+            for (int k : u) {
+                const Node& n = g.nodes[k];
+                n_block_users++;
+                if (n.op == "QLinearAdd") iadd = k;
+                else if (n.op == "QLinearConv") {
+                    auto wi = g.inits.find(n.in.size() > 3 ? n.in[3] : std::string());
+                    const bool w4 = wi != g.inits.end() && wi->second.dims.size() == 4;
+                    const int64_t co = w4 ? wi->second.dims[0] : -1;
+                    if (w4 && wi->second.dims[2] == 3) n_block_users--;  // the aux head reads layer3's output too: taken by head()
+                    else if (co == planes && i1 < 0) i1 = k;
+                    else if (co == 4 * planes && ids < 0) ids = k;
+                    else { err = "unexpected QLinearConv at the input of a bottleneck"; return 2; }
+                } else { err = "unexpected " + n.op + " at the input of a bottleneck"; return 2; }
+            }
+            if (i1 < 0 || (has_ds ? (ids < 0 || iadd >= 0) : (ids >= 0 || iadd < 0)) || n_block_users != 2) {
+                err = "bottleneck " + std::to_string(L + 1) + "." + std::to_string(b) + ": its input must feed conv1 and " + (has_ds ? "the downsample QLinearConv" : "the block's QLinearAdd");
+                return 2;
+            }
+            QC c1, c2, c3, ds;
+            int k2, k3;
+            if (!take(i1, &c1)) return 2;
+            if (!sole(c1.out, "QLinearConv", "conv1", &k2) || !take(k2, &c2)) return 2;
+            if (!sole(c2.out, "QLinearConv", "conv2", &k3) || !take(k3, &c3)) return 2;
+            std::string idt = t;
+            if (has_ds) {
+                if (!take(ids, &ds)) return 2;
+                idt = ds.out;
+            }
+            int ka;
+            if (!sole(c3.out, "QLinearAdd", "conv3", &ka)) return 2;
+            if (!has_ds && ka != iadd) { err = "conv3 and the identity do not meet in the same QLinearAdd"; return 2; }
+            const Node& an = g.nodes[ka];
+            if (an.in.size() < 8 || an.out.empty()) { err = "QLinearAdd needs 8 inputs"; return 2; }
+            const bool a_first = origin(an.in[0]) == c3.out;
+            const int ia = a_first ? 0 : 3, ib = a_first ? 3 : 0;
+            if (origin(an.in[ia]) != c3.out || origin(an.in[ib]) != origin(idt)) { err = "QLinearAdd does not add conv3 and the block's identity / downsample branch"; return 2; }
+            QBlobAdd qa;
+            if (!scalar_f32(g, an.in[ia + 1], &qa.a_scale) || !scalar_u8(g, an.in[ia + 2], &qa.a_zp) || !scalar_f32(g, an.in[ib + 1], &qa.b_scale) ||
+                !scalar_u8(g, an.in[ib + 2], &qa.b_zp) || !scalar_f32(g, an.in[6], &qa.c_scale) || !scalar_u8(g, an.in[7], &qa.c_zp) || !qscale_ok(qa.a_scale) ||
+                !qscale_ok(qa.b_scale) || !qscale_ok(qa.c_scale)) {
+                err = "QLinearAdd scales / zero points must be float / UINT8 scalar initializers"; return 2;
+            }
+            convs.push_back(c1); convs.push_back(c2); convs.push_back(c3);
+            if (has_ds) convs.push_back(ds);
+            adds.push_back(qa);
+            t = an.out[0];
+            zp_of[t] = qa.c_zp;
+            if (L == 2 && b == lb[2] - 1) l3 = t;
+        }
+    }
+    // ---- heads: QLinearConv 3x3 -> QLinearConv 1x1 -> DequantizeLinear -> Resize -> graph output #k ----
+    auto head = [&](const std::string& feat, size_t out_index, const char* what) {
+        const std::vector<int> u = users(feat);
+        int ih = -1;
+        for (int k : u)
+            if (g.nodes[k].op == "QLinearConv" && !used[k]) {
+                auto wi = g.inits.find(g.nodes[k].in.size() > 3 ? g.nodes[k].in[3] : std::string());
+                if (wi != g.inits.end() && wi->second.dims.size() == 4 && wi->second.dims[2] == 3) ih = k;
+            }
+        if (ih < 0) { err = std::string(what) + ": no 3x3 head QLinearConv reads the feature map"; return 2; }
+        QC h0, h1;
+        int k1, kd, kr;
+        if (!take(ih, &h0)) return 2;
+        if (!sole(h0.out, "QLinearConv", what, &k1) || !take(k1, &h1)) return 2;
+        if (!sole(h1.out, "DequantizeLinear", what, &kd)) return 2;
+        const Node& dq = g.nodes[kd];
+        float ds_;
+        int32_t dz;
+        if (dq.in.size() < 3 || !scalar_f32(g, dq.in[1], &ds_) || !scalar_u8(g, dq.in[2], &dz) || ds_ != h1.y_scale || dz != h1.y_zp) {
+            err = std::string(what) + ": DequantizeLinear must use the logit conv's y_scale / y_zero_point"; return 2;
+        }
+        const std::vector<int> ur = users(dq.out[0]);
+        if (ur.size() != 1 || g.nodes[ur[0]].op != "Resize") { err = std::string(what) + ": the dequantised logits must feed exactly one Resize"; return 2; }
+        kr = ur[0];
+        const Node& R = g.nodes[kr];
+        auto md = R.strs.find("mode");
+        if (md == R.strs.end() || md->second != "linear") { err = std::string(what) + ": Resize mode must be linear"; return 2; }
+        auto cm = R.strs.find("coordinate_transformation_mode");
+        const std::string cmode = cm == R.strs.end() ? "half_pixel" : cm->second;
+        if (cmode != "pytorch_half_pixel" && cmode != "half_pixel") { err = std::string(what) + ": Resize coordinate_transformation_mode '" + cmode + "' is not align_corners=False bilinear"; return 2; }
+        if (out_index >= outputs.size() || R.out.empty() || origin(outputs[out_index].name) != R.out[0]) { err = std::string(what) + ": its up-sampled logits are not graph output #" + std::to_string(out_index); return 2; }
+        convs.push_back(h0); convs.push_back(h1);
+        return 0;
+    };
+    int rc;
+    if ((rc = head(t, 0, "classifier"))) return rc;
+    if (aux && (rc = head(l3, 1, "aux_classifier"))) return rc;
+    const int ncls = convs[aux ? convs.size() - 3 : convs.size() - 1].cout;
+    if (ncls <= 0 || ncls > 256 || (aux && convs.back().cout != ncls)) { err = "out and aux heads disagree on the class count"; return 2; }
+    const std::vector<ConvSpec> spec = graph_spec(depth, ncls, aux);
+    if (spec.size() != convs.size()) { err = "the walk assigned " + std::to_string(convs.size()) + " of " + std::to_string(spec.size()) + " convolutions"; return 2; }
+    for (size_t i = 0; i < g.nodes.size(); i++)
+        if (g.nodes[i].op == "QLinearConv" && !used[i]) { err = "a QLinearConv node is not part of the FCN-ResNet topology"; return 2; }
+    for (size_t i = 0; i < spec.size(); i++) {
+        const QC& c = convs[i];
+        const ConvSpec& e = spec[i];
+        if (c.cout != e.cout || c.cin != e.cin || c.kh != e.k || c.kw != e.k || c.stride != e.stride || c.pad != e.pad || c.dil != e.dil) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "QLinearConv #%zu (%s) is [%d,%d,%d,%d] s%d p%d d%d, expected [%d,%d,%d,%d] s%d p%d d%d", i, e.name.c_str(), c.cout, c.cin, c.kh,
+                     c.kw, c.stride, c.pad, c.dil, e.cout, e.cin, e.k, e.k, e.stride, e.pad, e.dil);
+            err = buf;
+            return 2;
+        }
+        if (e.pad != 0 && e.role != 's' && c.x_zp != 0) { err = "QLinearConv (" + e.name + ") pads an input whose zero point is not 0: unsupported"; return 2; }
+    }
+    // a Relu that was looked through must sit on a u8 tensor whose zero point is 0 (then the clamp at 0 already is the ReLU)
+    for (auto& n : g.nodes)
+        if (n.op == "Relu") {
+            auto z = zp_of.find(origin(n.in.empty() ? std::string() : n.in[0]));
+            if (z == zp_of.end() || z->second != 0) { err = "a Relu follows a tensor that is not a quantised tensor with zero point 0"; return 2; }
+        }
+
+    // ---- INFURQ01 ----
+    const size_t n = spec.size(), na = adds.size();
+    size_t off = (kBlobHdr + n * kQEntry + na * kQAdd + 63) & ~(size_t)63;
+    struct Offs { size_t w, ws, b; };
+    std::vector<Offs> offs(n);
+    for (size_t i = 0; i < n; i++) {
+        const QC& c = convs[i];
+        offs[i].w = off;
+        off = (off + (size_t)c.cout * c.cin * c.kh * c.kw + 63) & ~(size_t)63;
+        offs[i].ws = off;
+        off = (off + (size_t)c.cout * 4 + 63) & ~(size_t)63;
+        offs[i].b = off;
+        off = (off + (size_t)c.cout * 4 + 63) & ~(size_t)63;
+    }
+    blob.assign(off, 0);
+    memcpy(blob.data(), "INFURQ01", 8);
+    auto put32 = [&](size_t o, uint32_t x) { memcpy(blob.data() + o, &x, 4); };
+    auto putf = [&](size_t o, float x) { memcpy(blob.data() + o, &x, 4); };
+    auto put64 = [&](size_t o, uint64_t x) { memcpy(blob.data() + o, &x, 8); };
+    put32(8, (uint32_t)depth); put32(12, (uint32_t)ncls); put32(16, aux ? 1u : 0u); put32(20, (uint32_t)n); put32(24, (uint32_t)na);
+    for (size_t i = 0; i < n; i++) {
+        const QC& c = convs[i];
+        const size_t e = kBlobHdr + i * kQEntry;
+        memcpy(blob.data() + e, spec[i].name.c_str(), spec[i].name.size() < 39 ? spec[i].name.size() : 39);
+        put32(e + 40, (uint32_t)c.cout); put32(e + 44, (uint32_t)c.cin); put32(e + 48, (uint32_t)c.kh); put32(e + 52, (uint32_t)c.kw);
+        putf(e + 56, c.x_scale); put32(e + 60, (uint32_t)c.x_zp); putf(e + 64, c.y_scale); put32(e + 68, (uint32_t)c.y_zp);
+        put64(e + 72, offs[i].w); put64(e + 80, offs[i].ws); put64(e + 88, offs[i].b);
+        memcpy(blob.data() + offs[i].w, c.w, (size_t)c.cout * c.cin * c.kh * c.kw);
+        memcpy(blob.data() + offs[i].ws, c.w_scale.data(), (size_t)c.cout * 4);
+        memcpy(blob.data() + offs[i].b, c.bias.data(), (size_t)c.cout * 4);
+    }
+    for (size_t i = 0; i < na; i++) {
+        const size_t e = kBlobHdr + n * kQEntry + i * kQAdd;
+        putf(e, adds[i].a_scale); put32(e + 4, (uint32_t)adds[i].a_zp); putf(e + 8, adds[i].b_scale); put32(e + 12, (uint32_t)adds[i].b_zp);
+        putf(e + 16, adds[i].c_scale); put32(e + 20, (uint32_t)adds[i].c_zp);
+    }
+    info.depth = depth;
+    info.num_classes = ncls;
+    info.aux = aux;
+    return 0;
+}
+
+}  // namespace infur

@@ -18,6 +18,8 @@ struct OnnxInfo {
 bool looks_like_onnx(const uint8_t* data, size_t len);
 // 0 = ok; 1 = malformed / unsupported file; 2 = parsed but not a model this path can run
 // (input-layout errors carry the reference's messages, predict_onnx.rs:228-262)
+// a float model gives an INFURW01 blob, a QOperator int8 model (QLinearConv nodes) an INFURQ01 one
 int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, OnnxInfo& info, std::string& err);
+int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, OnnxInfo& info, std::string& err);  // onnx_qreader.cpp
 
 }  // namespace infur

@@ -1,8 +1,10 @@
 // fuzz_formats.cpp -- sanitizer + mutation harness for everything behind `ModelCmd::Load` that parses untrusted bytes on
 // the host (SURVEY section 5 "race detection / sanitizers": the build's equivalent of the reference's clippy-only hygiene;
 // infur/src/predict_onnx.rs:288-309: a load error is a `Result`, never fatal):
-//   * onnx_reader.cpp  -- the protobuf wire-format reader / graph walker behind infur_onnx_to_blob
-//   * blob_dir.h       -- header + conv directory of the INFURW01 blob (what model_load_dev checks before touching the GPU)
+//   * onnx_reader.cpp / onnx_qreader.cpp -- the protobuf wire-format reader and the two graph walkers (float models,
+//                         QOperator int8 models) behind infur_onnx_to_blob
+//   * blob_dir.h       -- header + directory of the INFURW01 and INFURQ01 blobs (what model_load_dev / model_load_q_dev
+//                         check before touching the GPU)
 // Built by `make -C infur_amd/csrc asan` with g++ -fsanitize=address,undefined -fno-sanitize-recover; no HIP, no GPU.
 //
 //   fuzz_formats <onnx|blob> <file> <mutations> <seed>
@@ -50,13 +52,41 @@ static bool check_blob(const uint8_t* b, size_t len, std::string* err) {
     return true;
 }
 
+// INFURQ01 (quantised models): the same, with the three tensors per conv the loader copies
+static bool check_qblob(const uint8_t* b, size_t len, std::string* err) {
+    BlobHeader h;
+    std::vector<ConvSpec> g;
+    uint32_t n_adds = 0;
+    if (!qblob_parse_header(b, len, &h, &n_adds, &g, err)) return false;
+    std::vector<QBlobConv> qc;
+    std::vector<QBlobAdd> qa;
+    if (!qblob_parse_directory(b + kBlobHdr, len, g, n_adds, &qc, &qa, err)) return false;
+    volatile uint8_t sink = 0;
+    for (size_t i = 0; i < g.size(); i++) {
+        const size_t wn = (size_t)g[i].cout * g[i].cin * g[i].k * g[i].k, cn = (size_t)g[i].cout * 4;
+        sink ^= b[qc[i].w_off];
+        sink ^= b[qc[i].w_off + wn - 1];
+        sink ^= b[qc[i].ws_off];
+        sink ^= b[qc[i].ws_off + cn - 1];
+        sink ^= b[qc[i].b_off];
+        sink ^= b[qc[i].b_off + cn - 1];
+    }
+    (void)sink;
+    return true;
+}
+
+// the dispatch of infur_model_load_blob: by magic
+static bool check_any_blob(const uint8_t* b, size_t len, std::string* err) {
+    return len >= 8 && memcmp(b, "INFURQ01", 8) == 0 ? check_qblob(b, len, err) : check_blob(b, len, err);
+}
+
 static bool parse(bool onnx, const uint8_t* d, size_t len, std::string* err) {
-    if (!onnx) return check_blob(d, len, err);
+    if (!onnx) return check_any_blob(d, len, err);
     static std::vector<uint8_t> blob;  // (reused: a fresh 141 MB allocation per accepted file is all page faults under ASan)
     OnnxInfo info;
     if (onnx_to_blob(d, len, blob, info, *err) != 0) return false;
     std::string e2;
-    if (!check_blob(blob.data(), blob.size(), &e2)) {
+    if (!check_any_blob(blob.data(), blob.size(), &e2)) {
         fprintf(stderr, "the reader accepted a file but produced a blob that fails its own checks: %s\n", e2.c_str());
         abort();
     }

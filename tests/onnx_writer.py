@@ -292,3 +292,142 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
     g += f_bytes(12, value_info("aux", 1, ("N", 21, "H", "W")))
     model = f_varint(1, 6) + f_str(2, "pytorch") + f_bytes(7, g) + f_bytes(8, f_str(1, "") + f_varint(2, opset))
     return model, bn_params
+
+
+def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(), relu_after=(), w_zp=0, w_dtype=3, swap_add=None,
+               input_type=1, coord_mode="pytorch_half_pixel", drop_last=0, stem_scale=None, dq_scale=None, no_bias=(), vector_wzp=False,
+               pad_zp_conv=None, extra_qconv=False):
+    """The QOperator int8 form of the same network, as ONNX Runtime's static quantisation writes it (the shape of
+    `fcn-resnet50-12-int8.onnx`, the file the reference's tests load: predict_onnx.rs:357-381):
+    QuantizeLinear -> QLinearConv (ReLU folded) -> MaxPool (u8) -> bottlenecks (QLinearConv x3 [+ downsample], com.microsoft
+    QLinearAdd) -> heads (QLinearConv, QLinearConv, DequantizeLinear, Resize).
+
+    convs / adds: infur_amd.weights.QConv / QAdd lists in blob order; specs: infur_amd.weights.graph(...).
+    per_tensor_scale: conv names whose w_scale is written as a scalar (all channels must then share it);
+    relu_after: conv names followed by an explicit (redundant) Relu on the u8 tensor; swap_add: True / False / None (random)
+    operand order of QLinearAdd; the remaining switches produce the files the reader must REJECT."""
+    rng = rng or np.random.default_rng(0)
+    items = list(zip(specs, convs))
+    if drop_last:
+        items = items[:-drop_last]
+    by_name = {s.name: (s, c) for s, c in items}
+    inits, nodes = [], []
+    uid = [0]
+
+    def fresh(prefix):
+        uid[0] += 1
+        return f"{prefix}_{uid[0]}"
+
+    def emit(op, ins, outs, attrs=(), domain=None):
+        b = node(op, ins, outs, attrs)
+        if domain:
+            b += f_str(7, domain)
+        nodes.append(f_bytes(1, b))
+
+    def scalar_f(name, v):
+        inits.append(tensor(name, np.asarray(v, np.float32).reshape(())))
+        return name
+
+    def scalar_u8(name, v):
+        inits.append(tensor(name, np.asarray(v, np.uint8).reshape(()), dtype=2))
+        return name
+
+    def qconv(name, x):
+        if name not in by_name:
+            return None
+        s, c = by_name[name]
+        xs, xz = scalar_f(name + ".x_scale", stem_scale if (stem_scale and s.role == "stem") else c.x_scale), scalar_u8(name + ".x_zp", pad_zp_conv[1] if pad_zp_conv and pad_zp_conv[0] == name else c.x_zp)
+        ys, yz = scalar_f(name + ".y_scale", c.y_scale), scalar_u8(name + ".y_zp", c.y_zp)
+        w = np.ascontiguousarray(c.w, np.int8)
+        if w_dtype == 2:
+            inits.append(tensor(name + ".weight", (w.astype(np.int16) + 128).astype(np.uint8), dtype=2))
+        else:
+            inits.append(tensor(name + ".weight", w, dtype=3))
+        if name in per_tensor_scale:
+            inits.append(tensor(name + ".w_scale", np.asarray(c.w_scale[0], np.float32).reshape(())))
+        else:
+            inits.append(tensor(name + ".w_scale", np.asarray(c.w_scale, np.float32)))
+        zp = np.full((s.cout,) if vector_wzp else (), w_zp, np.int8)
+        inits.append(tensor(name + ".w_zp", zp, dtype=w_dtype if w_dtype == 2 else 3))
+        ins = [x, xs, xz, name + ".weight", name + ".w_scale", name + ".w_zp", ys, yz]
+        if name not in no_bias:
+            inits.append(tensor(name + ".bias", np.asarray(c.bias, np.int32), dtype=6))
+            ins.append(name + ".bias")
+        out = fresh("qconv")
+        emit("QLinearConv", ins, [out], [attr_ints("dilations", [s.dil, s.dil]), attr_int("group", 1), attr_ints("kernel_shape", [s.k, s.k]),
+                                          attr_ints("pads", [s.pad] * 4), attr_ints("strides", [s.stride, s.stride])])
+        if name in relu_after:
+            r = fresh("relu")
+            emit("Relu", [out], [r])
+            out = r
+        return out
+
+    stem_c = by_name["backbone.conv1"][1]
+    q = fresh("q")
+    emit("QuantizeLinear", ["input", scalar_f("input.scale", stem_c.x_scale), scalar_u8("input.zp", stem_c.x_zp)], [q])
+    x = qconv("backbone.conv1", q)
+    o = fresh("pool")
+    emit("MaxPool", [x], [o], [attr_ints("kernel_shape", [3, 3]), attr_ints("pads", [1, 1, 1, 1]), attr_ints("strides", [2, 2]), attr_int("ceil_mode", 0)])
+    x = o
+    l3 = None
+    blocks = sorted({s.name.rsplit(".", 1)[0] for s, _ in items if s.role == "conv1"}, key=lambda p: [int(v) if v.isdigit() else v for v in p.replace("layer", "layer.").split(".")])
+    add_it = iter(adds)
+    for p in blocks:
+        start = len(nodes)
+        t = qconv(p + ".conv1", x)
+        t = qconv(p + ".conv2", t)
+        t = qconv(p + ".conv3", t)
+        idt, ds_nodes = x, (0, 0)
+        if (p + ".downsample.0") in by_name:
+            d0 = len(nodes)
+            idt = qconv(p + ".downsample.0", x)
+            ds_nodes = (d0, len(nodes))
+        if order == "ds_first" and ds_nodes[1] > ds_nodes[0]:
+            blk = nodes[start:]
+            nodes[start:] = blk[ds_nodes[0] - start:ds_nodes[1] - start] + blk[:ds_nodes[0] - start] + blk[ds_nodes[1] - start:]
+        if t is None:
+            break
+        a = next(add_it)
+        A = [t, scalar_f(p + ".add.a_scale", a.a_scale), scalar_u8(p + ".add.a_zp", a.a_zp)]
+        B = [idt, scalar_f(p + ".add.b_scale", a.b_scale), scalar_u8(p + ".add.b_zp", a.b_zp)]
+        sw = rng.random() < 0.5 if swap_add is None else swap_add
+        o = fresh("qadd")
+        emit("QLinearAdd", (B + A if sw else A + B) + [scalar_f(p + ".add.c_scale", a.c_scale), scalar_u8(p + ".add.c_zp", a.c_zp)], [o], domain="com.microsoft")
+        x = o
+        if p.startswith("backbone.layer3."):
+            l3 = x
+
+    def head(prefix, feat, out_name):
+        h = qconv(prefix + ".0", feat)
+        lo = qconv(prefix + ".4", h) if h is not None else None
+        if lo is None:
+            return
+        c = by_name[prefix + ".4"][1]
+        dq = fresh("dq")
+        emit("DequantizeLinear", [lo, scalar_f(prefix + ".dq.scale", dq_scale or c.y_scale), scalar_u8(prefix + ".dq.zp", c.y_zp)], [dq])
+        inits.append(tensor(out_name + ".scales", np.array([1, 1, 8, 8], np.float32)))
+        attrs = [attr_str("mode", "linear")]
+        if coord_mode is not None:
+            attrs.append(attr_str("coordinate_transformation_mode", coord_mode))
+        emit("Resize", [dq, "", out_name + ".scales"], [out_name], attrs)
+
+    head("classifier", x, "out")
+    head("aux_classifier", l3, "aux")
+    if extra_qconv:
+        c = by_name["classifier.4"][1]
+        inits.append(tensor("extra.weight", np.zeros((4, 21, 1, 1), np.int8), dtype=3))
+        inits.append(tensor("extra.w_scale", np.ones((4,), np.float32)))
+        inits.append(tensor("extra.w_zp", np.zeros((), np.int8), dtype=3))
+        emit("QLinearConv", [l3, "classifier.4.y_scale", "classifier.4.y_zp", "extra.weight", "extra.w_scale", "extra.w_zp", "classifier.4.y_scale", "classifier.4.y_zp"],
+             ["extra_out"], [attr_ints("kernel_shape", [1, 1])])
+    if order == "shuffled":
+        perm = rng.permutation(len(nodes))
+        nodes = [nodes[i] for i in perm]
+    ncls = by_name["classifier.4"][0].cout if "classifier.4" in by_name else 21
+    g = b"".join(nodes) + f_str(2, "onnxruntime-quantized")
+    g += b"".join(f_bytes(5, t) for t in inits)
+    g += f_bytes(11, value_info("input", input_type, ("N", 3, "H", "W")))
+    g += f_bytes(12, value_info("out", 1, ("N", ncls, "H", "W")))
+    g += f_bytes(12, value_info("aux", 1, ("N", ncls, "H", "W")))
+    return (f_varint(1, 6) + f_str(2, "onnx.quantize") + f_bytes(7, g) + f_bytes(8, f_str(1, "") + f_varint(2, 12)) +
+            f_bytes(8, f_str(1, "com.microsoft") + f_varint(2, 1)))

@@ -18,6 +18,7 @@ CSRC = os.path.join(ROOT, "infur_amd", "csrc")
 BIN = os.path.join(CSRC, "build", "fuzz_formats_asan")
 
 N_BLOB, N_ONNX_PER_PROC, ONNX_PROCS = 8000, 700, 3  # 8000 + 2100 mutations
+N_QBLOB, N_QONNX_PER_PROC = 4000, 500                # + 4000 + 1000 on the quantised formats
 
 
 @pytest.fixture(scope="module")
@@ -57,3 +58,33 @@ def test_exporter_file_survives_mutation(harness, exported50, tmp_path):
     print(f"exporter file: {tot_acc} mutations accepted, {tot_rej} rejected with a format error")
     assert tot_acc + tot_rej == N_ONNX_PER_PROC * ONNX_PROCS and tot_rej > 300 and tot_acc > 100
     assert N_BLOB + N_ONNX_PER_PROC * ONNX_PROCS >= 10000
+
+
+def test_quantised_blob_and_qoperator_file_survive_mutation(harness, tmp_path):
+    """the INFURQ01 directory checks and the QOperator graph walker (onnx_qreader.cpp), same harness"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import onnx_writer as OW
+    from test_onnx_quant_cpu import random_qmodel
+
+    from infur_amd import weights as W
+
+    specs, convs, adds = random_qmodel(seed=11)
+    pb = tmp_path / "r50.qblob"
+    pb.write_bytes(W.pack_qblob(convs, adds, 50, 21, True))
+    po = tmp_path / "r50_int8.onnx"
+    po.write_bytes(OW.fcn_qmodel(convs, adds, specs))
+    procs = [subprocess.Popen([harness, "onnx", str(po), str(N_QONNX_PER_PROC), str(5000 + 31 * k)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for k in range(2)]
+    r = subprocess.run([harness, "blob", str(pb), str(N_QBLOB), "0xC0FFEE"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    acc, rej = counts(r.stdout)
+    assert acc + rej == N_QBLOB and rej > 100 and acc > 100, (acc, rej)
+    tot_acc = tot_rej = 0
+    for pr in procs:
+        out, err = pr.communicate(timeout=1500)
+        assert pr.returncode == 0, out[-1000:] + err[-4000:]
+        a, rj = counts(out)
+        tot_acc += a
+        tot_rej += rj
+    print(f"QOperator file: {tot_acc} mutations accepted, {tot_rej} rejected with a format error")
+    assert tot_acc + tot_rej == 2 * N_QONNX_PER_PROC and tot_rej > 150 and tot_acc > 30

@@ -103,3 +103,28 @@ def test_switching_between_float_and_quantised_models(qblob, blob50, oracle):
         m.control(ModelCmd.LoadBlob(blob50))
         again, _ = FramePath(c).advance(fr, 1.0)
         assert (again == ref_f).all() and rq.shape == ref_f.shape
+
+
+def test_loading_the_qoperator_onnx_file_equals_the_blob(qblob, oracle, tmp_path):
+    """ModelCmd::Load("...-int8.onnx") (predict_onnx.rs:288-309 with the file of predict_onnx.rs:357-381): the QOperator graph is
+    walked by its edges into the same INFURQ01 bytes, so frames come out identical; the file's own tensor names are reported"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import onnx_writer as OW
+    from oracle import infur_qoracle as Q
+
+    meta, convs, adds = W.unpack_qblob(qblob)
+    p = tmp_path / "fcn-resnet50-int8.onnx"
+    p.write_bytes(OW.fcn_qmodel(convs, adds, W.graph(50), order="shuffled", rng=np.random.default_rng(3)))
+    fr = W.synth_frame(88, 120, index=2)
+    ref_lo, ref_aux = Q.qforward(qblob, oracle.pack_normalize(fr))
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.Load(str(p)))
+        info = m.get_info()
+        assert info.input_name == "input" and info.output_names == ["out", "aux"] and info.depth == 50
+        rgba, _ = FramePath(c).advance(fr, 1.0)
+        lo, la = m.lowres()
+        assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
+        assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 88, 120))).all()

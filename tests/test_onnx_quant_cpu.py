@@ -1,0 +1,151 @@
+"""ModelCmd::Load of the QUANTISED model file (`fcn-resnet50-12-int8.onnx` is what the reference's tests load:
+infur-test-gen/build.rs:88-93, predict_onnx.rs:357-381): the host-only QOperator ONNX -> INFURQ01 converter, the INFURQ01
+container itself and the integer oracle's operator arithmetic.  No GPU.  Files are fabricated by tests/onnx_writer.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import onnx_writer as OW  # noqa: E402
+from test_onnx_cpu import convert  # noqa: E402
+
+from infur_amd import weights as W
+
+
+def random_qmodel(depth=50, aux=True, ncls=21, seed=0, per_tensor=()):
+    """structurally valid quantised parameters with arbitrary values (the converter moves bytes, it does not run them)"""
+    rng = np.random.default_rng(seed)
+    specs = W.graph(depth, ncls, aux)
+    convs, adds = [], []
+    for s in specs:
+        w = rng.integers(-127, 128, (s.cout, s.cin, s.k, s.k), dtype=np.int8)
+        ws = (rng.random(s.cout).astype(np.float32) + np.float32(0.5)) * np.float32(1e-3)
+        if s.name in per_tensor:
+            ws[:] = ws[0]
+        x_zp = int(rng.integers(0, 256)) if (s.pad == 0 or s.role == "stem") else 0
+        convs.append(W.QConv(s.name, w, ws, rng.integers(-(1 << 20), 1 << 20, s.cout, dtype=np.int32), float(np.float32(rng.random() + 0.01)), x_zp,
+                             float(np.float32(rng.random() + 0.01)), int(rng.integers(0, 256))))
+        if s.role == "conv3":
+            adds.append(W.QAdd(convs[-1].y_scale, convs[-1].y_zp, float(np.float32(rng.random() + 0.01)), int(rng.integers(0, 256)),
+                               float(np.float32(rng.random() + 0.01)), int(rng.integers(0, 256))))
+    return specs, convs, adds
+
+
+@pytest.fixture(scope="module")
+def q50():
+    return random_qmodel(per_tensor=("backbone.layer2.1.conv2", "classifier.4"))
+
+
+def test_infurq01_container_round_trips():
+    specs, convs, adds = random_qmodel(seed=3)
+    blob = W.pack_qblob(convs, adds, 50, 21, True)
+    meta, c2, a2 = W.unpack_qblob(blob)
+    assert meta == {"depth": 50, "num_classes": 21, "aux": True, "n_convs": 57, "n_adds": 16}
+    for a, b in zip(convs, c2):
+        assert a.name == b.name and (a.w == b.w).all() and (a.w_scale == b.w_scale).all() and (a.bias == b.bias).all()
+        assert (np.float32(a.x_scale), a.x_zp, np.float32(a.y_scale), a.y_zp) == (np.float32(b.x_scale), b.x_zp, np.float32(b.y_scale), b.y_zp)
+    assert [tuple(np.float32(v) for v in vars(a).values()) for a in adds] == [tuple(np.float32(v) for v in vars(a).values()) for a in a2]
+    assert W.pack_qblob(c2, a2, 50, 21, True) == blob
+    with pytest.raises(ValueError):
+        W.unpack_qblob(b"INFURW01" + blob[8:])
+
+
+@pytest.mark.parametrize("order,swap", [("topo", False), ("shuffled", None), ("ds_first", True)])
+def test_qoperator_model_converts_to_the_same_blob_bit_for_bit(lib, q50, order, swap):
+    specs, convs, adds = q50
+    model = OW.fcn_qmodel(convs, adds, specs, order=order, swap_add=swap, rng=np.random.default_rng(7),
+                          per_tensor_scale=("backbone.layer2.1.conv2", "classifier.4"), relu_after=())
+    rc, err, out = convert(lib, model)
+    assert rc == 0, err
+    assert out == W.pack_qblob(convs, adds, 50, 21, True)
+
+
+def test_variants_no_aux_r101_redundant_relu_missing_bias(lib):
+    specs, convs, adds = random_qmodel(depth=101, aux=False, ncls=7, seed=5)
+    zero_zp = [c.name for c in convs if c.y_zp == 0]
+    for c in convs[:6]:
+        c.y_zp = 0
+    adds[0].a_zp = convs[3].y_zp  # (layer1.0.conv3 is conv #3)
+    convs[2].bias = np.zeros_like(convs[2].bias)
+    model = OW.fcn_qmodel(convs, adds, specs, relu_after=tuple(c.name for c in convs[:6]), no_bias=(convs[2].name,), vector_wzp=True)
+    rc, err, out = convert(lib, model)
+    assert rc == 0, err
+    assert out == W.pack_qblob(convs, adds, 101, 7, False), zero_zp
+    meta, _, _ = W.unpack_qblob(out)
+    assert meta["depth"] == 101 and not meta["aux"] and meta["n_convs"] == 106 and meta["n_adds"] == 33
+
+
+@pytest.mark.parametrize("kwargs,msg", [
+    (dict(w_zp=3), "non-zero weight zero point"),
+    (dict(w_dtype=2), "UINT8 weights"),
+    (dict(input_type=2), "only a Float"),
+    (dict(coord_mode="align_corners"), "align_corners"),
+    (dict(drop_last=1), "QLinearConv nodes"),
+    (dict(stem_scale=0.123), "differ from the image's QuantizeLinear"),
+    (dict(dq_scale=0.5), "DequantizeLinear must use"),
+    (dict(pad_zp_conv=("backbone.layer1.0.conv2", 9)), "pads an input whose zero point"),
+    (dict(relu_after=("backbone.layer3.0.conv3",)), "Relu follows"),
+    (dict(extra_qconv=True), "QLinearConv nodes"),
+])
+def test_files_the_reader_must_reject(lib, q50, kwargs, msg):
+    specs, convs, adds = q50
+    if "relu_after" in kwargs:
+        assert next(c for c in convs if c.name == "backbone.layer3.0.conv3").y_zp != 0
+    rc, err, out = convert(lib, OW.fcn_qmodel(convs, adds, specs, **kwargs))
+    assert rc != 0 and out is None and msg in err, err
+
+
+def test_wrong_shapes_and_dynamic_quantisation_are_format_errors(lib, q50):
+    specs, convs, adds = q50
+    bad = list(convs)
+    c = bad[6]
+    assert c.name == "backbone.layer1.1.conv2"
+    bad[6] = W.QConv(c.name, c.w[:, :, :1, :1].copy(), c.w_scale, c.bias, c.x_scale, c.x_zp, c.y_scale, c.y_zp)  # a 3x3 written as 1x1
+    rc, err, _ = convert(lib, OW.fcn_qmodel(bad, adds, specs))
+    assert rc != 0 and "is [64,64,1,1]" in err and "expected [64,64,3,3]" in err, err
+    model = OW.fcn_qmodel(convs, adds, specs)
+    rc, err, _ = convert(lib, model.replace(b"QLinearAdd", b"QLinearMul"))
+    assert rc != 0 and "QLinearMul" in err, err
+    # truncations of a valid file never crash and never succeed
+    for cut in (len(model) // 3, len(model) - 100, 40):
+        rc, err, out = convert(lib, model[:cut])
+        assert rc != 0 and out is None
+
+
+def test_operator_arithmetic_of_the_integer_oracle():
+    """the oracle's requantisation against hand-computed values: round half to even, saturation, the f32 multiplier"""
+    from oracle import infur_qoracle as Q
+
+    assert Q.quantize_linear(np.array([0.5, 1.5, 2.5, -0.5, 300.0, -300.0], np.float32), 1.0, 0).tolist() == [0, 2, 2, 0, 255, 0]
+    assert Q.quantize_linear(np.array([0.05, -0.05], np.float32), 0.1, 128).tolist() == [128, 128]  # 0.5 -> 0, -0.5 -> -0
+    acc = np.array([[[5]], [[-5]], [[1000000]]], np.int64)
+    assert Q.requantize(acc, np.array([0.5, 0.5, 0.5], np.float32), 10).ravel().tolist() == [12, 8, 255]  # 2.5 -> 2, -2.5 -> -2
+    a = np.array([[[200]]], np.uint8)
+    b = np.array([[[100]]], np.uint8)
+    p = W.QAdd(0.5, 0, 0.25, 100, 0.125, 3)
+    assert Q.qlinear_add(a, b, p).ravel().tolist() == [255]  # 200 * 4 + 0 + 3 saturates
+    p = W.QAdd(0.5, 0, 0.25, 100, 1.0, 3)
+    assert Q.qlinear_add(a, b, p).ravel().tolist() == [103]
+    c = W.QConv("x", np.zeros((2, 1, 1, 1), np.int8), np.array([0.1, 0.3], np.float32), np.zeros(2, np.int32), 0.7, 0, 0.9, 0)
+    m = Q.conv_mult(c)
+    assert m.dtype == np.float32 and m.tolist() == [float(np.float32(np.float32(0.7) * np.float32(0.1)) / np.float32(0.9)),
+                                                     float(np.float32(np.float32(0.7) * np.float32(0.3)) / np.float32(0.9))]
+
+
+def test_tiny_quantised_forward_matches_a_direct_integer_evaluation():
+    """qconv (float64 conv2d on integers) against an explicit integer loop, padding included"""
+    from oracle import infur_qoracle as Q
+
+    rng = np.random.default_rng(1)
+    spec = next(x for x in W.graph(50) if x.role == "conv2" and x.stride == 2)
+    x = rng.integers(0, 256, (spec.cin, 9, 11), dtype=np.uint8)
+    c = W.QConv(spec.name, rng.integers(-127, 128, (spec.cout, spec.cin, 3, 3), dtype=np.int8), np.ones(spec.cout, np.float32),
+                rng.integers(-1000, 1000, spec.cout, dtype=np.int32), 1.0, 0, 1.0, 0)
+    acc = Q.qconv(x, c, spec)
+    xp = np.pad(x.astype(np.int64), ((0, 0), (spec.pad, spec.pad), (spec.pad, spec.pad)))
+    oh, ow = acc.shape[1:]
+    for (o, y, xx) in [(0, 0, 0), (5, oh - 1, ow - 1), (spec.cout - 1, 2, 3)]:
+        win = xp[:, y * 2:y * 2 + 3, xx * 2:xx * 2 + 3]
+        assert acc[o, y, xx] == int((win * c.w[o].astype(np.int64)).sum()) + int(c.bias[o])
