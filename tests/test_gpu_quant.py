@@ -123,7 +123,7 @@ def test_loading_the_qoperator_onnx_file_equals_the_blob(qblob, oracle, tmp_path
     with Context(device=0) as c:
         m = Model(c).control(ModelCmd.Load(str(p)))
         info = m.get_info()
-        assert info.input_name == "input" and info.output_names == ["out", "aux"] and info.depth == 50
+        assert info.input_names == ["input"] and info.output_names == ["out", "aux"] and info.depth == 50
         rgba, _ = FramePath(c).advance(fr, 1.0)
         lo, la = m.lowres()
         assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
