@@ -965,6 +965,12 @@ static const CfgInfo kCfgs[] = {
     // the 4K classifier.0.  What did help is WHERE the DMA instructions are issued inside the step: the `dmai` form above,
     // +6-8 % on the MFMA-bound layers.  Beyond that the gap to the peak is mostly the package clock: 1.99 GHz on real data
     // against 2.38 GHz on all-zero operands for the SAME binary -- scripts/zero_data_probe.py, profiles/r02_dvfs_probe.md.)
+    // (round 3, both measured on the 4K FCN-ResNet101 and dropped: (1) FOUR waves of 128 x 128 on the `dmai` tile -- a third less
+    // fragment-read traffic per FLOP, the whole 512-register file per wave -- is 20 % SLOWER on every MFMA-bound layer (layer3 conv2
+    // 150 -> 184 us, classifier.0 1973 -> 2295): with one wave per SIMD nothing runs while that wave sits at a DMA issue or a
+    // barrier; (2) walking K with the TAPS INSIDE each 128-byte channel chunk -- the nine shifted windows of a chunk back to
+    // back, so that L2 serves their overlap instead of the 9x re-fetch the counters show -- changes nothing (154.7 vs 155.6 us):
+    // those re-reads come out of the Infinity Cache and the loop is not waiting for them.)
     // (128x128 and 128x256 DMA tiles were measured too: slower than the register-staged forms on every layer of the 4K
     // FCN-ResNet101, including the HBM-bound 1x1 convs they were meant for -- 0.199 / 0.208 ms vs 0.170 on layer3 conv3)
 };
