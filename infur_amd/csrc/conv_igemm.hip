@@ -584,14 +584,19 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
 #ifdef KTRACE
     const unsigned long long kt_loop = __builtin_amdgcn_s_memtime();
 #endif
-    // epilogue geometry: a wave's 32-pixel row block is written out with LPR lanes (4 channels each)
-    // on every pixel row, RPI rows per instruction
-    constexpr int LPR = TN * 8;
+    // epilogue geometry: a wave's 32-pixel row block is written out with LPR lanes (CPL channels each)
+    // on every pixel row, RPI rows per instruction.  CPL = 4 (16 bytes of f32 read from the staging row); a u8 output takes
+    // 16 channels per lane: its 16-byte stores and residual loads are a quarter of the instructions of the 4-byte form
+    // (which ran the quantised 1x1 expansions at 2 TB/s, instruction-bound in the epilogue)
+    constexpr bool Q8 = I8 && std::is_same<OutT, unsigned char>::value;
+    constexpr int CPL = Q8 ? 16 : 4;
+    constexpr int LPR = TN * 32 / CPL;
     constexpr int RPI = 64 / LPR;
     const int e_row = lane / LPR, e_col = lane % LPR;
-    const int e_n = n0 + wn * TN * 32 + e_col * 4;
+    const int e_n = n0 + wn * TN * 32 + e_col * CPL;
     const T* res = static_cast<const T*>(a.res);
-    using ResV = typename std::conditional<std::is_same<T, float>::value, float4, typename std::conditional<I8, unsigned, f16x4>::type>::type;
+    using ResV = typename std::conditional<std::is_same<T, float>::value, float4,
+                                           typename std::conditional<Q8, u32x4, typename std::conditional<I8, unsigned, f16x4>::type>::type>::type;
     ResV rres[RESPF ? TM : 1][RESPF ? 32 / RPI : 1];
     if constexpr (RESPF) {
 #pragma unroll
@@ -725,11 +730,16 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         const bool n_ok = n < a.Cout;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_bias && n_ok) bv = *reinterpret_cast<const float4*>(a.bias + n);
-        int qb[4] = {0, 0, 0, 0};          // I8: folded bias and requantisation multiplier of this lane's 4 channels
-        float qm[4] = {0.f, 0.f, 0.f, 0.f};
+        int qb[CPL];    // I8: folded bias and requantisation multiplier of this lane's channels
+        float qm[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; t++) {
+            qb[t] = 0;
+            qm[t] = 0.f;
+        }
         if constexpr (I8) {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < CPL; t++)
                 if (n + t < a.Cout) {
                     qb[t] = a.q_bias[n + t];
                     qm[t] = a.q_mult[n + t];
@@ -772,8 +782,37 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             for (int it = 0; it < 32 / RPI; it++) {
                 const int row = it * RPI + rrow;
                 const int m = mb + row;
-                float4 v = *reinterpret_cast<const float4*>(stage + row * ROWB + rcol * 16);
-                if constexpr (I8) {
+                float4 v = *reinterpret_cast<const float4*>(stage + row * ROWB + rcol * (CPL * 4));
+                if constexpr (Q8) {
+                    // (the launcher admits a u8 output only with Cout % 16 == 0: channel padding of the quantised tensors)
+                    i32x4q ai[4];
+                    ai[0] = __builtin_bit_cast(i32x4q, v);
+#pragma unroll
+                    for (int t4 = 1; t4 < 4; t4++) ai[t4] = *reinterpret_cast<const i32x4q*>(stage + row * ROWB + rcol * 64 + t4 * 16);
+                    if (m < M && n_ok) {
+                        u32x4 rv = {0u, 0u, 0u, 0u};
+                        const bool has_res = RESPF || res;
+                        if (has_res) {
+                            if constexpr (RESPF)
+                                rv = rres[i][it];
+                            else
+                                rv = rlate[it];
+                        }
+                        u32x4 pk;
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; t4++) {
+                            unsigned w = 0;
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                int q = q_requant(ai[t4][t] + qb[4 * t4 + t], qm[4 * t4 + t], a.q_yzp);
+                                if (has_res) q = q_add(q, a.q_yzp, a.q_ra, (int)((rv[t4] >> (8 * t)) & 0xffu), a.q_bzp, a.q_rb, a.q_czp);
+                                w |= (unsigned)q << (8 * t);
+                            }
+                            pk[t4] = w;
+                        }
+                        *reinterpret_cast<u32x4*>(out + (size_t)m * a.Cout + n) = pk;
+                    }
+                } else if constexpr (I8) {
                     if (m < M && n_ok) {
                         const size_t o = (size_t)m * a.Cout + n;
                         const i32x4q ai = __builtin_bit_cast(i32x4q, v);
@@ -789,7 +828,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
 #pragma unroll
                             for (int t = 0; t < 4; t++) q[t] = q_add(q[t], a.q_yzp, a.q_ra, (int)((rv >> (8 * t)) & 0xffu), a.q_bzp, a.q_rb, a.q_czp);
                         }
-                        if constexpr (std::is_same<OutT, float>::value) {
+                        {  // f32 output: the dequantised logits
                             float4 d;
                             d.x = (float)(q[0] - a.q_yzp) * a.q_dq; d.y = (float)(q[1] - a.q_yzp) * a.q_dq;
                             d.z = (float)(q[2] - a.q_yzp) * a.q_dq; d.w = (float)(q[3] - a.q_yzp) * a.q_dq;
@@ -801,8 +840,6 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                                 for (int t = 0; t < 4; t++)
                                     if (n + t < a.Cout) out[o + t] = dd[t];
                             }
-                        } else {
-                            *reinterpret_cast<unsigned*>(out + o) = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
                         }
                     }
                 } else if (m < M && n_ok) {
@@ -906,6 +943,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     constexpr bool kI8 = std::is_same<T, signed char>::value;
     constexpr bool kSameType = std::is_same<T, OutT>::value || (kI8 && std::is_same<OutT, unsigned char>::value);
     if (kI8 && a.in2) return hipErrorInvalidValue;  // (the two convolutions of a quantised block requantise separately)
+    if (kI8 && std::is_same<OutT, unsigned char>::value && (a.Cout & 15)) return hipErrorInvalidValue;  // 16-byte epilogue stores
     if constexpr (kSameType) {
         if (a.in2) {
             if (!g1 || a.stride != 1 || a.res) return hipErrorInvalidValue;
