@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "qepilogue.h"
 
 namespace infur {
 
@@ -65,26 +66,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4q __attribute__((ext_vector_type(4)));
 typedef int i32x16q __attribute__((ext_vector_type(16)));
 
-// ---- quantised epilogue (mode 4): every floating-point step is ONE f32 operation, never contracted -- the arithmetic is
-//      defined bit for bit (oracle/infur_qoracle.py) ----
-// QLinearConv: sat_u8(round_half_even(f32(acc) * mult) + zp)
-__device__ __forceinline__ int q_requant(const int acc, const float mult, const int yzp) {
-#pragma clang fp contract(off)
-    float t = (float)acc * mult;
-    t = __builtin_rintf(t) + (float)yzp;
-    t = __builtin_fminf(__builtin_fmaxf(t, 0.f), 255.f);
-    return (int)t;
-}
-// QLinearAdd: sat_u8(round(f32(a - a_zp) * ra + f32(b - b_zp) * rb) + c_zp)
-__device__ __forceinline__ int q_add(const int a, const int azp, const float ra, const int b, const int bzp, const float rb, const int czp) {
-#pragma clang fp contract(off)
-    const float ta = (float)(a - azp) * ra;
-    const float tb = (float)(b - bzp) * rb;
-    float t = ta + tb;
-    t = __builtin_rintf(t) + (float)czp;
-    t = __builtin_fminf(__builtin_fmaxf(t, 0.f), 255.f);
-    return (int)t;
-}
+// (quantised epilogue, mode 4: qepilogue.h)
 
 // four f32 (one staged 16-byte chunk) * scale -> 4 x f16 hi at dst, 4 x f16 lo at dst + 64
 // (round to nearest even twice: |x - hi| <= 2^-11 |x| is exact in f32, so hi + lo = x to 2^-22)
@@ -745,6 +727,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                     qm[t] = a.q_mult[n + t];
                 }
         }
+        const float q_yzpf = (float)a.q_yzp, q_lo = -q_yzpf, q_hi = 255.f - q_yzpf, q_bzpf = (float)a.q_bzp, q_czpf = (float)a.q_czp;
         float vmax = 0.f;  // SPLIT: largest |output| of this lane (range monitor)
 #pragma unroll
         for (int i = 0; i < TM; i++) {
@@ -804,9 +787,9 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                             unsigned w = 0;
 #pragma unroll
                             for (int t = 0; t < 4; t++) {
-                                int q = q_requant(ai[t4][t] + qb[4 * t4 + t], qm[4 * t4 + t], a.q_yzp);
-                                if (has_res) q = q_add(q, a.q_yzp, a.q_ra, (int)((rv[t4] >> (8 * t)) & 0xffu), a.q_bzp, a.q_rb, a.q_czp);
-                                w |= (unsigned)q << (8 * t);
+                                const float d = q_requant_c(ai[t4][t] + qb[4 * t4 + t], qm[4 * t4 + t], q_lo, q_hi);  // y - y_zp
+                                const float y = has_res ? q_add_c(d, a.q_ra, q_byte(rv[t4], t), q_bzpf, a.q_rb, q_czpf) : d + q_yzpf;
+                                w = q_pack(y, t, w);
                             }
                             pk[t4] = w;
                         }
@@ -816,22 +799,14 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                     if (m < M && n_ok) {
                         const size_t o = (size_t)m * a.Cout + n;
                         const i32x4q ai = __builtin_bit_cast(i32x4q, v);
-                        int q[4];
+                        float q[4];  // y - y_zp
 #pragma unroll
-                        for (int t = 0; t < 4; t++) q[t] = q_requant(ai[t] + qb[t], qm[t], a.q_yzp);
-                        if (RESPF || res) {
-                            unsigned rv;
-                            if constexpr (RESPF)
-                                rv = rres[i][it];
-                            else
-                                rv = rlate[it];
-#pragma unroll
-                            for (int t = 0; t < 4; t++) q[t] = q_add(q[t], a.q_yzp, a.q_ra, (int)((rv >> (8 * t)) & 0xffu), a.q_bzp, a.q_rb, a.q_czp);
-                        }
-                        {  // f32 output: the dequantised logits
+                        for (int t = 0; t < 4; t++) q[t] = q_requant_c(ai[t] + qb[t], qm[t], q_lo, q_hi);
+                        {  // f32 output: the dequantised logits (a logit conv has no residual: launch_cfg)
+#pragma clang fp contract(off)
                             float4 d;
-                            d.x = (float)(q[0] - a.q_yzp) * a.q_dq; d.y = (float)(q[1] - a.q_yzp) * a.q_dq;
-                            d.z = (float)(q[2] - a.q_yzp) * a.q_dq; d.w = (float)(q[3] - a.q_yzp) * a.q_dq;
+                            // (+ 0.0f: the centred value may be -0.0 where the operator's f32(q - zp) is +0.0)
+                            d.x = (q[0] + 0.0f) * a.q_dq; d.y = (q[1] + 0.0f) * a.q_dq; d.z = (q[2] + 0.0f) * a.q_dq; d.w = (q[3] + 0.0f) * a.q_dq;
                             if ((a.Cout & 3) == 0) {
                                 *reinterpret_cast<float4*>(out + o) = d;
                             } else {  // (21 logits per pixel: rows are not 16-byte aligned, the last group is partial)
@@ -944,6 +919,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     constexpr bool kSameType = std::is_same<T, OutT>::value || (kI8 && std::is_same<OutT, unsigned char>::value);
     if (kI8 && a.in2) return hipErrorInvalidValue;  // (the two convolutions of a quantised block requantise separately)
     if (kI8 && std::is_same<OutT, unsigned char>::value && (a.Cout & 15)) return hipErrorInvalidValue;  // 16-byte epilogue stores
+    if (kI8 && std::is_same<OutT, float>::value && a.res) return hipErrorInvalidValue;  // (dequantised logits: no residual sum)
     if constexpr (kSameType) {
         if (a.in2) {
             if (!g1 || a.stride != 1 || a.res) return hipErrorInvalidValue;
@@ -1009,6 +985,11 @@ static const CfgInfo kCfgs[] = {
     // barrier; (2) walking K with the TAPS INSIDE each 128-byte channel chunk -- the nine shifted windows of a chunk back to
     // back, so that L2 serves their overlap instead of the 9x re-fetch the counters show -- changes nothing (154.7 vs 155.6 us):
     // those re-reads come out of the Infinity Cache and the loop is not waiting for them.)
+    // (round 3, quantised mode: the A-resident walk of conv1x1_areg.hip was ported to the i8 MFMA -- 128-pixel workgroups, 8 waves
+    // of 32 x 64, weights through a ring of four LDS images, bit-exact -- and is SLOWER than the tiled forms on every 1x1 of the
+    // 1080p network (layer3 conv3 37 vs 31 us, layer4 conv3 79 vs 65, layer1 conv3 38 vs 31): with one 8-wave workgroup per CU
+    // nothing covers the per-N-tile residual loads and the requantisation VALU work, which four co-resident 4-wave workgroups
+    // of the tiled kernel overlap among themselves.  Not shipped.)
     // (128x128 and 128x256 DMA tiles were measured too: slower than the register-staged forms on every layer of the 4K
     // FCN-ResNet101, including the HBM-bound 1x1 convs they were meant for -- 0.199 / 0.208 ms vs 0.170 on layer3 conv3)
 };

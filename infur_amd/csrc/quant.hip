@@ -6,18 +6,11 @@
 // Integer arithmetic is exact; every floating-point step of a requantisation is one f32 operation, never contracted --
 // the results are defined bit for bit (oracle/infur_qoracle.py).
 #include "kernels.h"
+#include "qepilogue.h"
 
 namespace infur {
 
 namespace {
-
-__device__ __forceinline__ int q_requant8(const int acc, const float mult, const int yzp) {
-#pragma clang fp contract(off)
-    float t = (float)acc * mult;
-    t = __builtin_rintf(t) + (float)yzp;
-    t = __builtin_fminf(__builtin_fmaxf(t, 0.f), 255.f);
-    return (int)t;
-}
 
 // ---- stem: frame bytes -> quantised image (table) -> 7x7/2 convolution as 49 four-way dot products per output channel ----
 // A workgroup owns 8 x 32 output pixels; the 21 x 69 input patch sits in LDS as one dword per pixel: (r, g, b, 0) with 128
@@ -56,6 +49,7 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31;
     const int oy = oy0 + ty, ox = ox0 + tx;
+    const float q_yzpf = (float)y_zp, q_lo = -q_yzpf, q_hi = 255.f - q_yzpf;
     int xw[49];
 #pragma unroll
     for (int ky = 0; ky < 7; ky++)
@@ -72,7 +66,7 @@ __global__ void __launch_bounds__(256)
             int acc = q_bias[c0 + c];
 #pragma unroll
             for (int t = 0; t < 49; t++) acc = __builtin_amdgcn_sdot4(xw[t], wr[t], acc, false);
-            pk[c >> 2] |= (unsigned)q_requant8(acc, q_mult[c0 + c], y_zp) << (8 * (c & 3));
+            pk[c >> 2] = q_pack(q_requant_c(acc, q_mult[c0 + c], q_lo, q_hi) + q_yzpf, c & 3, pk[c >> 2]);
         }
         *reinterpret_cast<uint4*>(o + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
