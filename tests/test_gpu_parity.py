@@ -423,11 +423,13 @@ def test_model_load_from_onnx_file(blob50, tmp_path, oracle_model):
     m.advance(fr, out)
     lo2, la2 = m.lowres()
     assert (lo.view(np.uint32) == lo2.view(np.uint32)).all() and (la.view(np.uint32) == la2.view(np.uint32)).all()
-    bad = tmp_path / "int8.onnx"
-    bad.write_bytes(OW.fcn_model(tensors, W.graph(50), conv_op="QLinearConv")[0])
-    with pytest.raises(ModelCmdError) as e:
-        m.control(ModelCmd.Load(str(bad)))
-    assert e.value.code == _lib.E_MODEL_FORMAT and "quantised" in str(e.value)
+    # a file that is neither: float tensors under quantised operators (a well-formed QOperator file loads: test_gpu_quant.py)
+    for op, msg in (("QLinearConv", "QuantizeLinear"), ("ConvInteger", "dynamically quantised")):
+        bad = tmp_path / "int8.onnx"
+        bad.write_bytes(OW.fcn_model(tensors, W.graph(50), conv_op=op)[0])
+        with pytest.raises(ModelCmdError) as e:
+            m.control(ModelCmd.Load(str(bad)))
+        assert e.value.code == _lib.E_MODEL_FORMAT and msg in str(e.value)
     c2.close()
 
 

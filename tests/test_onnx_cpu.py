@@ -73,7 +73,8 @@ def test_input_checks_carry_the_reference_messages(lib, tensors50):
         (dict(input_dims=("N", "H", "W", 3)), "an NHWC image input must reach the stem convolution through one Transpose"),
         (dict(input_dims=("N", "H", "W", 3), front=("transpose_bad",)), "perm = [0,3,1,2]"),
         (dict(front=("cast",)), "expected exactly one Conv after the image input"),   # a Float input needs no Cast
-        (dict(conv_op="QLinearConv"), "quantised model"),                        # the int8 zoo file of infur-test-gen
+        (dict(conv_op="ConvInteger"), "dynamically quantised model"),            # (the static QOperator form loads: test_onnx_quant_cpu.py)
+        (dict(conv_op="QLinearConv"), "expected exactly one QuantizeLinear"),    # float tensors under quantised operators
         (dict(drop_last=3), "Conv nodes"),
     ]
     for kw, msg in cases:
