@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side measurements of BASELINE configs[2] (1080p stream at scale 0.5, PCIe inclusive) and "
                          "configs[4] (4K FCN-ResNet101 f16)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s", "f32x"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s", "f32x", "i8"],
                     help="conv-stack arithmetic: f32 (BASELINE configs[1], the default and the parity mode) or f16 "
                          "operands with f32 accumulation (configs[4]'s mode)")
     ap.add_argument("--winograd-min-cin", type=int, default=0,
@@ -300,13 +300,20 @@ def main():
     # of different frames overlap where one of them leaves CUs idle (tails of a launch, HBM-bound next to MFMA-bound)
     K = max(1, a.contexts_per_gpu)
     streams = [torch.cuda.Stream() for _ in range(K)]
-    ctxs = [Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=st.cuda_stream, dtype=a.dtype,
+    # --dtype i8: the QUANTISED model (INFURQ01: u8 x s8 on the i8 MFMA); a quantised model defines its own arithmetic, the
+    # context's compute dtype does not matter to it
+    ctxs = [Context(device=dev, compute_aux=not a.no_aux, profile=not a.no_profile, stream=st.cuda_stream, dtype="f32" if a.dtype == "i8" else a.dtype,
                     winograd_min_cin=a.winograd_min_cin & 0xFFFFFFFF, winograd_tile=a.winograd_tile) for st in streams]
     ctx = ctxs[0]
 
     # ---- weights: rank 0 synthesises, RCCL broadcast over xGMI, every rank repacks locally; the rank's other
     #      contexts get the repacked arena through the C ABI's group call (device-to-device on one GPU) ----
-    blob = W.synth_blob(depth=a.depth) if rank == 0 else None
+    if a.dtype == "i8":
+        from infur_amd import quantize
+
+        blob = quantize.synth_qblob(depth=a.depth) if rank == 0 else None
+    else:
+        blob = W.synth_blob(depth=a.depth) if rank == 0 else None
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -427,7 +434,8 @@ def main():
             k3 = {c.name for c in W.graph(a.depth) if c.k == 3}
             # f32s: three f16 MFMAs per product -> the ceiling for f32-equivalent FLOPs is a third of the f16 peak
             peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "f32s": PEAK_F16_MFMA_TFLOPS / 3.0,
-                    "f32x": PEAK_F16_MFMA_TFLOPS / 2.0}[a.dtype]  # f32x: one f16 MFMA + one fp8 MX MFMA (half an f16 unit per term) per product
+                    "f32x": PEAK_F16_MFMA_TFLOPS / 2.0,  # f32x: one f16 MFMA + one fp8 MX MFMA (half an f16 unit per term) per product
+                    "i8": 2.0 * PEAK_F16_MFMA_TFLOPS}[a.dtype]  # dense i8 MFMA: twice the f16 rate (TOP/s; >= 3944 measured in the guide)
             CONV_KERNELS = ("conv_igemm_", "conv1x1_")  # tiled implicit GEMM; A-resident 1x1 and the fused conv3 -> next conv1 pair (f16 mode)
             conv = [r for r in recs if r["kernel"].startswith(CONV_KERNELS)]
             # dominant kernel = the tile configuration of conv_igemm that takes the most time in a frame over the
@@ -455,8 +463,8 @@ def main():
                 bm, bn = parts[0], parts[1]
                 nbuf = {"1buf": "1", "1frag": "3", "dma": "4", "dmai": "5"}.get(parts[2], "2") if len(parts) > 2 else "2"
                 waves = {"128,256": "2, 4", "256,128": "4, 2", "256,32": "4, 1", "256,256": "2, 4"}.get(f"{bm},{bn}", "2, 2")
-                el = "_Float16, _Float16" if a.dtype == "f16" else "float, float"
-                split = {"f32": "false", "f16": "false", "f32s": "true", "f32x": "true"}[a.dtype]
+                el = {"f16": "_Float16, _Float16", "i8": "signed char, unsigned char"}.get(a.dtype, "float, float")
+                split = {"f32": "false", "f16": "false", "f32s": "true", "f32x": "true", "i8": "false"}[a.dtype]
                 # all instantiations of this tile (plain / 1x1-GEMM addressing / residual prefetch), launch-weighted
                 pre = f"conv_igemm_kernel<{el}, {bm}, {bn}, {waves}, {nbuf}, {split}"
                 ts = [t for k, t in json.load(open(tj))["kernels"].items() if k.startswith(pre)]

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinfur_hip.so")
+# INFUR_LIB_PATH: an instrumentation build of the same ABI (scripts/ktrace.py: `make ktrace` -> libinfur_hip_ktrace.so)
+LIB_PATH = os.environ.get("INFUR_LIB_PATH") or os.path.join(_HERE, "libinfur_hip.so")
 
 ABI_VERSION = 3  # INFUR_ABI_VERSION of include/infur_hip.h
 

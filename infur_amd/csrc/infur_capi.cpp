@@ -1900,6 +1900,8 @@ int32_t infur_stream_add_lane(infur_stream* st, infur_ctx* other) {
         other->opt.winograd_min_cin != c->opt.winograd_min_cin || other->opt.compute_aux != c->opt.compute_aux)
         return fail(c, INFUR_E_INVALID_ARG, "a lane must share the stream's compute_dtype / winograd_tile / winograd_min_cin / compute_aux: its frames would otherwise differ");
     if (!other->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "the lane's context has no model loaded (replicate it first: infur_group_weights_broadcast)");
+    if (c->loaded && other->quant != c->quant)
+        return fail(c, INFUR_E_INVALID_ARG, "a lane must hold the stream's model: one of the two contexts has a quantised model, the other a float one");
     st->lanes.push_back(other);
     other->streams.push_back(st);
     return INFUR_OK;

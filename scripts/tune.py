@@ -16,8 +16,9 @@ JOBS = [  # (dtype, depth, (w, h), factor)
     ("f16", 50, (1920, 1080), 1.0), ("f16", 101, (3840, 2160), 1.0),
     ("f32s", 50, (1920, 1080), 1.0), ("f32s", 50, (1920, 1080), 0.5), ("f32s", 50, (640, 480), 1.0),
     ("f32x", 50, (1920, 1080), 1.0), ("f32x", 50, (1920, 1080), 0.5),
+    ("i8", 50, (1920, 1080), 1.0), ("i8", 50, (1920, 1080), 0.5), ("i8", 50, (640, 480), 1.0),  # the quantised model (INFURQ01)
 ]
-MODE = {"f32": "0", "f16": "1", "f32s": "2", "f32x": "3"}  # the `mode` column of the database
+MODE = {"f32": "0", "f16": "1", "f32s": "2", "f32x": "3", "i8": "4"}  # the `mode` column of the database
 
 
 def main():
@@ -37,10 +38,15 @@ def main():
     for dtype, depth, (w, h), factor in JOBS:
         if only and dtype not in only:
             continue
-        blob = blobs.setdefault(depth, W.synth_blob(depth=depth))
+        if dtype == "i8":
+            from infur_amd import quantize
+
+            blob = blobs.setdefault(("q", depth), quantize.synth_qblob(depth=depth))
+        else:
+            blob = blobs.setdefault(depth, W.synth_blob(depth=depth))
         fr = W.synth_frame(h, w)
         for _ in range(ROUNDS):
-            c = P.Context(device=0, dtype=dtype)
+            c = P.Context(device=0, dtype="f32" if dtype == "i8" else dtype)
             P.Model(c).control(P.ModelCmd.LoadBlob(blob))
             P.FramePath(c).advance(fr, factor)
             for ln in c.tuning_text().splitlines():

@@ -128,3 +128,59 @@ def test_loading_the_qoperator_onnx_file_equals_the_blob(qblob, oracle, tmp_path
         lo, la = m.lowres()
         assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
         assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 88, 120))).all()
+
+
+def test_quantised_model_through_group_stream_and_batch(qblob, oracle):
+    """the rest of the API surface with a quantised model: replication to other contexts (infur_group_weights_broadcast copies
+    the quantisation tables with the arena), the sharded batch, the streaming ring with a second lane -- masks equal the
+    single-context ones, which are the oracle's"""
+    from infur_amd.app import StreamPath
+    from infur_amd.processors import Group
+    from oracle import infur_qoracle as Q
+
+    imgs = [W.synth_frame(64 + 16 * (i % 2), 96, index=i) for i in range(5)]
+    ctxs = [Context(device=0) for _ in range(3)]
+    try:
+        Model(ctxs[0]).control(ModelCmd.LoadBlob(qblob))
+        ref = FramePath(ctxs[0]).advance_batch(imgs, 1.0)
+        lo, _ = Q.qforward(qblob, oracle.pack_normalize(imgs[0]))
+        assert (ref[0] == oracle.colorcode(oracle.upsample_bilinear(lo, *imgs[0].shape[:2]))).all()
+        with Group(ctxs) as g:
+            g.weights_broadcast(root=0)
+            got = g.advance_batch(imgs, 1.0)
+            assert len(got) == 5 and all((a == b).all() for a, b in zip(got, ref))
+        for c in ctxs[1:]:
+            solo, _ = FramePath(c).advance(imgs[1], 1.0)
+            assert (solo == ref[1]).all()
+        sp = StreamPath(ctxs[0], depth=3)
+        sp.add_lane(ctxs[1])
+        out = list(sp.run([(i, im) for i, im in enumerate(imgs)], 1.0))
+        assert [o[0] for o in out] == list(range(5)) and all((o[1] == r).all() for o, r in zip(out, ref))
+        sp.close()
+        # a float model on one context and a quantised one on the other are different arithmetic: not a lane
+        f = Context(device=0)
+        Model(f).control(ModelCmd.LoadBlob(W.synth_blob(depth=50)))
+        sp2 = StreamPath(f, depth=2)
+        with pytest.raises(Exception):
+            sp2.add_lane(ctxs[2])
+        sp2.close()
+        f.close()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_resnet101_quantised_is_bit_exact(oracle):
+    from oracle import infur_qoracle as Q
+
+    qb = Q.synth_qblob(depth=101)
+    fr = W.synth_frame(72, 88, index=4)
+    taps = {}
+    ref_lo, ref_aux = Q.qforward(qb, oracle.pack_normalize(fr), taps)
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(qb))
+        assert m.get_info().depth == 101
+        rgba, _ = FramePath(c).advance(fr, 1.0)
+        lo, la = m.lowres()
+        assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
+        assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 72, 88))).all()
