@@ -14,15 +14,21 @@ rows = [("1080p FCN-ResNet50, scale 1.0 (BASELINE configs[1])", 50, 1920, 1080, 
         ("1080p FCN-ResNet101", 101, 1920, 1080, 1.0, 32),
         ("4K FCN-ResNet50", 50, 3840, 2160, 1.0, 16),
         ("4K FCN-ResNet101 (configs[4] is the f16 column)", 101, 3840, 2160, 1.0, 12)]
-blobs = {}
-print("| workload | f32 (MFMA f32) | f32s (split) | f16 |\n|---|---|---|---|")
+blobs, qblobs = {}, {}
+print("| workload | f32 (MFMA f32) | f32s (split) | f32x | f16 | int8 (quantised model) |\n|---|---|---|---|---|---|")
 for name, depth, w, h, scale, n in rows:
     blob = blobs.setdefault(depth, W.synth_blob(depth=depth))
     d_in = [torch.from_numpy(W.synth_frame(h, w, index=i)).cuda() for i in range(4)]
     oh, ow = (int(h * scale), int(w * scale))
     d_out = [torch.empty((oh, ow, 4), dtype=torch.uint8, device="cuda") for _ in d_in]
     cells = []
-    for dt in ("f32", "f32s", "f16"):
-        fps, _ = bench.resident_rate(a, 0, dt, blob, d_in, d_out, w, h, scale, n)
+    for dt in ("f32", "f32s", "f32x", "f16", "i8"):
+        if dt == "i8":  # the QOperator int8 form of the same network (another model file: its own arithmetic)
+            from infur_amd import quantize
+
+            qb = qblobs.setdefault(depth, quantize.synth_qblob(depth=depth))
+            fps, _ = bench.resident_rate(a, 0, "f32", qb, d_in, d_out, w, h, scale, n)
+        else:
+            fps, _ = bench.resident_rate(a, 0, dt, blob, d_in, d_out, w, h, scale, n)
         cells.append(f"{fps:.1f}")
     print(f"| {name} | " + " | ".join(cells) + " |", flush=True)
