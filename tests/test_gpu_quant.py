@@ -184,3 +184,41 @@ def test_resnet101_quantised_is_bit_exact(oracle):
         lo, la = m.lowres()
         assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
         assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 72, 88))).all()
+
+
+@pytest.mark.parametrize("seed,size", [(0, (88, 120)), (1, (135, 241)), (2, (40, 56))])
+def test_hostile_quantisation_parameters_are_bit_exact(oracle, seed, size):
+    """tests/hostile_q.py: zero points anywhere in 0..255, power-of-two multipliers (exact .5 ties on every other accumulator:
+    only round-half-to-EVEN passes), both saturation tails populated, s8 weights down to -128, biases to 2^20, residual
+    sums whose inputs differ 4x in scale -- every layer's bytes, the logits and the mask must still equal the integer oracle"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hostile_q import hostile_qblob
+    from oracle import infur_qoracle as Q
+
+    qb = hostile_qblob(seed=seed)
+    h, w = size
+    fr = W.synth_frame(h, w, index=seed)
+    taps = {}
+    ref_lo, ref_aux = Q.qforward(qb, oracle.pack_normalize(fr), taps)
+    sat_lo = sat_hi = 0
+    with Context(device=0, keep_activations=True) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(qb))
+        rgba, _ = FramePath(c).advance(fr, 1.0)
+        lo, la = m.lowres()
+        buf = np.empty(64 << 18, np.float32)
+        for i, spec in enumerate(W.graph(50)):
+            if spec.role in ("cls", "auxcls"):
+                continue
+            ref = taps[spec.name]
+            sat_lo += int((ref == 0).sum())
+            sat_hi += int((ref == 255).sum())
+            cc, hh, ww = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+            c.check(c.L.infur_debug_read_activation(c.h, i, buf.ctypes.data, buf.size, C.byref(cc), C.byref(hh), C.byref(ww)))
+            got = buf[: cc.value * hh.value * ww.value].reshape(cc.value, hh.value, ww.value)
+            assert (got[: ref.shape[0]] == ref.astype(np.float32)).all(), (spec.name, int((got[: ref.shape[0]] != ref).sum()))
+        assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
+        assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, h, w))).all()
+    assert sat_lo > 1000 and sat_hi > 1000  # the set really reaches both clamps

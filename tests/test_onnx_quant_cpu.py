@@ -149,3 +149,31 @@ def test_tiny_quantised_forward_matches_a_direct_integer_evaluation():
     for (o, y, xx) in [(0, 0, 0), (5, oh - 1, ow - 1), (spec.cout - 1, 2, 3)]:
         win = xp[:, y * 2:y * 2 + 3, xx * 2:xx * 2 + 3]
         assert acc[o, y, xx] == int((win * c.w[o].astype(np.int64)).sum()) + int(c.bias[o])
+
+
+def test_hostile_quantised_model_is_valid_reaches_the_edges_and_survives_the_onnx_round_trip(lib):
+    """tests/hostile_q.py (the parameter set of tests/test_gpu_quant.py's hostile case): structurally valid for the reader,
+    and -- evaluated by the oracle on small frames -- it does produce exact .5 ties (thousands, in convolutions and residual sums
+    alike), both saturation tails, and non-zero zero points on both sides of residual sums, down to the heads"""
+    from hostile_q import hostile_qmodel
+    from oracle import infur_qoracle as Q
+
+    specs, convs, adds = hostile_qmodel(seed=0)
+    blob = W.pack_qblob(convs, adds, 50, 21, True)
+    rc, err, out = convert(lib, OW.fcn_qmodel(convs, adds, specs, order="shuffled", rng=np.random.default_rng(1)))
+    assert rc == 0, err
+    assert out == blob
+    assert min(c.w.min() for c in convs) == -128 and sum(a.b_zp != 0 and a.c_zp != 0 for a in adds) >= 4
+    assert all(c.x_zp == 0 for s, c in zip(specs, convs) if s.pad and s.role != "stem")
+    st = hostile_qmodel.last_stats  # what the calibration frame met on its way through the model
+    assert st["add_ties"] > 1000 and st["conv_ties"] > 1000 and st["sat_lo"] > 10000 and st["sat_hi"] > 10000, st
+    # half-to-even is what the oracle does on an exact tie
+    assert Q.requantize(np.array([[[1]], [[3]], [[-1]], [[5]]], np.int64), np.full(4, 0.5, np.float32), 10).ravel().tolist() == [10, 12, 10, 12]
+    a = np.array([[[3, 5, 7]]], np.uint8)
+    assert Q.qlinear_add(a, np.zeros_like(a), W.QAdd(1.0, 0, 1.0, 0, 2.0, 0)).ravel().tolist() == [2, 2, 4]  # 1.5, 2.5, 3.5
+    rng = np.random.default_rng(0)
+    taps = {}
+    Q.qforward(blob, (rng.standard_normal((3, 24, 32)) * 1.2).astype(np.float32), taps)
+    for name in ("backbone.layer1.0.conv1", "backbone.layer3.2.conv2", "classifier.0"):  # (conv outputs; a conv3 tap is the residual sum)
+        x = taps[name]
+        assert (x == 0).any() and (x == 255).any() and len(np.unique(x)) > 150, name
