@@ -985,11 +985,12 @@ static const CfgInfo kCfgs[] = {
     // barrier; (2) walking K with the TAPS INSIDE each 128-byte channel chunk -- the nine shifted windows of a chunk back to
     // back, so that L2 serves their overlap instead of the 9x re-fetch the counters show -- changes nothing (154.7 vs 155.6 us):
     // those re-reads come out of the Infinity Cache and the loop is not waiting for them.)
-    // (round 3, quantised mode: the A-resident walk of conv1x1_areg.hip was ported to the i8 MFMA -- 128-pixel workgroups, 8 waves
-    // of 32 x 64, weights through a ring of four LDS images, bit-exact -- and is SLOWER than the tiled forms on every 1x1 of the
-    // 1080p network (layer3 conv3 37 vs 31 us, layer4 conv3 79 vs 65, layer1 conv3 38 vs 31): with one 8-wave workgroup per CU
-    // nothing covers the per-N-tile residual loads and the requantisation VALU work, which four co-resident 4-wave workgroups
-    // of the tiled kernel overlap among themselves.  Not shipped.)
+    // (round 3, quantised mode: a first port of the A-resident walk of conv1x1_areg.hip to the i8 MFMA -- 8 waves, output through
+    // per-wave LDS slices, 134 KB of LDS = one workgroup per CU -- was slower than the tiled forms on every 1x1 (layer3 conv3 at
+    // 1080p 37 vs 31 us): nothing covered its per-N-tile residual loads and requantisation.  conv1x1_q8.hip is the second form --
+    // 16 consecutive channels per lane straight from the accumulators, no LDS staging, bias / multiplier tables in LDS -- and is
+    // configuration 15 of mode 4: it wins where M is large (4K: conv3 and downsample convs 5-12 % faster than the tiled forms;
+    // 1080p: layer1 only -- with M = 32400 there is one 32-pixel wave per SIMD and the N-split tiles have more to overlap).)
     // (128x128 and 128x256 DMA tiles were measured too: slower than the register-staged forms on every layer of the 4K
     // FCN-ResNet101, including the HBM-bound 1x1 convs they were meant for -- 0.199 / 0.208 ms vs 0.170 on layer3 conv3)
 };
@@ -1031,7 +1032,7 @@ bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32) 
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     if (mode == 3) mode = 2;  // the fp8 cross-term form stages like the split mode
     if (cfg >= 13 && mode != 1 && mode != 4) return false;  // LDS-DMA staging: byte operands that need no conversion (f16, i8)
-    if (cfg == 15) return conv1x1_areg_valid(a, mode, out_f32);  // (f16 output only: not the f32 logits of a 1x1 classifier)
+    if (cfg == 15) return mode == 4 ? conv1x1_q8_valid(a, mode, out_f32) : conv1x1_areg_valid(a, mode, out_f32);  // (never the f32 logits)
     const int bn = kCfgs[cfg].bn;
     if (a.Cout <= 32) return bn == 32;
     if (bn == 32) return false;
@@ -1077,6 +1078,9 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 15:
             if constexpr (std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value && !SPLIT) {
                 if (conv1x1_areg_valid(a, 1, 0)) return launch_conv1x1_areg(a, s);
+            }
+            if constexpr (std::is_same<T, signed char>::value && std::is_same<OutT, unsigned char>::value) {
+                if (conv1x1_q8_valid(a, 4, 0)) return launch_conv1x1_q8(a, s);
             }
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;

@@ -71,6 +71,10 @@ const char* conv_igemm_config_name(int cfg, int mode);
 // while the workgroup walks all N tiles (conv1x1_areg.hip).  Reached through launch_conv_igemm as one more configuration.
 bool conv1x1_areg_valid(const ConvArgs& a, int mode, int out_f32);
 hipError_t launch_conv1x1_areg(const ConvArgs& a, hipStream_t s);
+// quantised models (mode 4, u8 output): activation tile in registers, 16 consecutive channels per lane straight from the
+// accumulators (conv1x1_q8.hip): configuration 15 in that mode
+bool conv1x1_q8_valid(const ConvArgs& a, int mode, int out_f32);
+hipError_t launch_conv1x1_q8(const ConvArgs& a, hipStream_t s);
 
 // Two 1x1 convolutions back to back on the same pixels, f16 (conv1x1_b2b.hip): y = ReLU(w3 * in + b3 + res) -- a
 // bottleneck's conv3 + residual -- is written once and immediately multiplied by the NEXT bottleneck's conv1 weights:
