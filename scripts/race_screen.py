@@ -15,16 +15,24 @@ from infur_amd import processors as P
 from infur_amd import weights as W
 
 RUNS = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-JOBS = [("f16", 101, 3840, 2160), ("f16", 50, 1920, 1080), ("f16", 50, 961, 541), ("f32s", 50, 1920, 1080), ("f32x", 50, 1920, 1080), ("f32", 50, 1920, 1080)]
+JOBS = [("f16", 101, 3840, 2160), ("f16", 50, 1920, 1080), ("f16", 50, 961, 541), ("f32s", 50, 1920, 1080), ("f32x", 50, 1920, 1080), ("f32", 50, 1920, 1080),
+        # the quantised model: i8 `dma` / `dmai` tiles and conv1x1_q8 (hand-counted vmcnt over DMA pieces, residual loads and stores);
+        # 2160p so that the tuner also takes conv1x1_q8 for the expansions, 1080p for the database's choices
+        ("i8", 50, 1920, 1080), ("i8", 50, 3840, 2160)]
 bad = 0
 for dtype, depth, w, h in JOBS:
-    blob = W.synth_blob(depth=depth)
+    if dtype == "i8":
+        from infur_amd import quantize
+
+        blob = quantize.synth_qblob(depth=depth)
+    else:
+        blob = W.synth_blob(depth=depth)
     fr = W.synth_frame(h, w, index=7)
     K = 3
     hashes = [[] for _ in range(K)]
 
     def work(k):
-        c = P.Context(device=0, dtype=dtype)
+        c = P.Context(device=0, dtype="f32" if dtype == "i8" else dtype)
         m = P.Model(c).control(P.ModelCmd.LoadBlob(blob))
         fp = P.FramePath(c)
         n = max(6, RUNS // (4 if w > 2000 else 1))
