@@ -222,3 +222,39 @@ def test_hostile_quantisation_parameters_are_bit_exact(oracle, seed, size):
         assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
         assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, h, w))).all()
     assert sat_lo > 1000 and sat_hi > 1000  # the set really reaches both clamps
+
+
+def test_configs0_640x480_quantised_frame_is_bit_exact(qblob, oracle):
+    """BASELINE configs[0]: the reference's own CPU-runnable case -- a 640x480 frame through the int8 model (infur-test-gen's clip
+    size + fcn-resnet50-12-int8.onnx, predict_onnx.rs:357-381) -- at full size: dequantised logits, full-resolution outputs and
+    mask equal the integer oracle bit for bit"""
+    from oracle import infur_qoracle as Q
+
+    fr = W.synth_frame(480, 640, index=11)
+    ref_lo, ref_aux = Q.qforward(qblob, oracle.pack_normalize(fr))
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(qblob))
+        out = []
+        m.advance(fr, out)
+        assert len(out) == 2 and out[0].shape == (21, 480, 640)
+        assert (out[0].view(np.uint32) == oracle.upsample_bilinear(ref_lo, 480, 640).view(np.uint32)).all()
+        rgba, _ = FramePath(c).advance(fr, 1.0)
+        lo, la = m.lowres()
+        assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
+        assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 480, 640))).all()
+
+
+def test_full_1080p_quantised_frame_is_bit_exact(qblob, oracle):
+    """the headline frame size through the quantised model: 1920x1080, every dequantised logit and every mask byte equal to the
+    integer oracle (a float model can only be compared within a tolerance at this size; this one is defined bit for bit)"""
+    from oracle import infur_qoracle as Q
+
+    fr = W.synth_frame(1080, 1920, index=5)
+    ref_lo, ref_aux = Q.qforward(qblob, oracle.pack_normalize(fr))
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(qblob))
+        rgba, _ = FramePath(c).advance(fr, 1.0)
+        lo, la = m.lowres()
+        assert lo.shape == (21, 135, 240)
+        assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
+        assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 1080, 1920))).all()
