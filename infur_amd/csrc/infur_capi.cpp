@@ -301,6 +301,9 @@ void model_free(infur_ctx* c) {
     c->qadds.clear();
     c->quant = false;
     c->d_qlut = nullptr;
+    c->d_qstem_w = nullptr;
+    c->d_qstem_lut = nullptr;
+    c->d_qstem_bias = nullptr;
     c->loaded = false;
     c->weight_bytes = 0;
     pool_release_all(c);
@@ -801,6 +804,8 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
             }
     }
     size_t total = 1024;  // the quantisation table of the image
+    constexpr size_t kQStemW = 147 * 64 * 4, kQStemLut = 768 * 4, kQStemBias = 64 * 4;  // operands of the fused stem (launch_stem_pool_q)
+    total += align_up(kQStemW, 256) + align_up(kQStemLut, 256) + align_up(kQStemBias, 256);
     for (uint32_t i = 0; i < n; i++) {
         ConvLayer& L = g[i];
         const bool logits = L.role == 'c';
@@ -820,10 +825,10 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
     uint8_t* const base = (uint8_t*)arena.p;
     size_t off = 0;
     // image quantisation table: QuantizeLinear of the reference's normalised value of every byte (predict_onnx.rs:126-137)
+    std::vector<uint8_t> ql(768);
     {
         std::vector<float> pre(768);
         build_pre_lut(pre.data());
-        std::vector<uint8_t> ql(768);
         const volatile float xs = qc[0].x_scale;
         for (int i = 0; i < 768; i++) {
             volatile float t = pre[i] / xs;  // (one f32 division, then round half to even)
@@ -836,6 +841,12 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
     }
     uint8_t* const d_qlut = base + off;
     off += 1024;
+    float* const d_qstem_w = (float*)(base + off);
+    off += align_up(kQStemW, 256);
+    float* const d_qstem_lut = (float*)(base + off);
+    off += align_up(kQStemLut, 256);
+    int32_t* const d_qstem_bias = (int32_t*)(base + off);
+    off += align_up(kQStemBias, 256);
     std::vector<int32_t> h_sum, h_bias;
     std::vector<float> h_ws, h_mult;
     for (uint32_t i = 0; i < n; i++) {
@@ -869,6 +880,16 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
                     wq[(size_t)o * 49 + t] = (int32_t)d;
                 }
             HIPCHK(c, hipMemcpyAsync(L.d_w, wq.data(), wq.size() * 4, hipMemcpyHostToDevice, c->stream));
+            // the fused form's operands: weights as f32 [k][o] with k = (ky * 7 + kx) * 3 + channel, the table as q - x_zp
+            if (L.cout != 64) return fail(c, INFUR_E_MODEL_FORMAT, "stem has %d output channels, expected 64", L.cout);
+            std::vector<float> wf(147 * 64), lf(768);
+            for (int o = 0; o < 64; o++)
+                for (int ch = 0; ch < 3; ch++)
+                    for (int t = 0; t < 49; t++) wf[(size_t)(t * 3 + ch) * 64 + o] = (float)w[((size_t)o * 3 + ch) * 49 + t];
+            for (int i = 0; i < 768; i++) lf[i] = (float)((int)ql[i] - qc[0].x_zp);
+            HIPCHK(c, hipMemcpyAsync(d_qstem_w, wf.data(), kQStemW, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_qstem_lut, lf.data(), kQStemLut, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_qstem_bias, (const uint8_t*)d_blob + qc[i].b_off, kQStemBias, hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         } else {
             HIPCHK(c, launch_repack_q(src_w, (int8_t*)L.d_w, (int32_t*)tmp.p, L.cout, L.cin, L.k, L.k, L.cout_p, L.cin_p, c->stream));
@@ -898,6 +919,9 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
     c->qadds.clear();
     for (const QBlobAdd& a : qa) c->qadds.push_back(QAddParams{a.a_scale, a.b_scale, a.c_scale, a.a_zp, a.b_zp, a.c_zp});
     c->d_qlut = d_qlut;
+    c->d_qstem_w = d_qstem_w;
+    c->d_qstem_lut = d_qstem_lut;
+    c->d_qstem_bias = d_qstem_bias;
     c->quant = true;
     c->depth = bh.depth;
     c->num_classes = bh.num_classes;
@@ -954,6 +978,13 @@ int32_t forward_q(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     const int sh = conv_out(h, 7, 2, 3, 1), sw = conv_out(w, 7, 2, 3, 1);
     const int ph = conv_out(sh, 3, 2, 1, 1), pw = conv_out(sw, 3, 2, 1, 1);
     Tensor s, x;
+    if (!c->opt.keep_activations && !c->opt.no_fuse_stem_pool) {
+        // QuantizeLinear + QLinearConv + MaxPool in one launch, exact on the f16 MFMA; the 64-channel stem tensor is never written
+        RETIF(talloc(c, ph, pw, 128, 1, &x));
+        ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool_q", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes());
+        HIPCHK(c, launch_stem_pool_q(d_bgr, h, w, c->d_qstem_w, c->d_qstem_lut, c->d_qstem_bias, stem.d_qmult, stem.y_zp, (uint8_t*)x.p, sh, sw, ph, pw,
+                                     c->stream));
+    } else {
     {
         RETIF(talloc(c, sh, sw, 64, 1, &s));
         ProfScope ps(c, stem.name, "stem_q", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)s.bytes());
@@ -966,6 +997,7 @@ int32_t forward_q(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
         HIPCHK(c, launch_maxpool_q((const uint8_t*)s.p, sh, sw, 64, (uint8_t*)x.p, ph, pw, 128, c->stream));
     }
     pool_release(c, s);
+    }
     Tensor l3;
     size_t blk = 0;
     while (c->convs[ci].role == '1') {

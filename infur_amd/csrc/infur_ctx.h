@@ -93,6 +93,10 @@ struct infur_ctx {
     bool input_u8 = false;  // the model declares a Uint8 image input: raw BGR bytes, no normalisation
     bool quant = false;     // a quantised (QOperator) model: u8 activations, s8 weights, the i8 MFMA -- whatever compute_dtype says
     std::vector<infur::QAddParams> qadds;
+    // the fused quantised stem (launch_stem_pool_q): s8 weights as f32 [147][64], q - x_zp as f32 [3][256], the operator's own bias
+    float* d_qstem_w = nullptr;
+    float* d_qstem_lut = nullptr;
+    int32_t* d_qstem_bias = nullptr;
     uint8_t* d_qlut = nullptr;  // [3][256] u8: byte value -> QuantizeLinear of the normalised value (RGB order); in d_weights
     std::vector<infur::ConvLayer> convs;
     void* d_weights = nullptr;  // single allocation holding every repacked tensor

@@ -297,6 +297,9 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
     dst->quant = root->quant;
     dst->qadds = root->qadds;
     dst->d_qlut = (uint8_t*)rebase(root->d_qlut);
+    dst->d_qstem_w = (float*)rebase(root->d_qstem_w);
+    dst->d_qstem_lut = (float*)rebase(root->d_qstem_lut);
+    dst->d_qstem_bias = (int32_t*)rebase(root->d_qstem_bias);
     dst->info = root->info;
     dst->info.n_outputs = 1 + ((root->has_aux && dst->opt.compute_aux) ? 1 : 0);
     if (dst->info.n_outputs < 2) dst->info.output_names[1][0] = 0;

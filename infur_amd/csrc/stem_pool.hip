@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "qepilogue.h"
 
 namespace infur {
 
@@ -171,10 +172,19 @@ __host__ __device__ constexpr int sp_pixoff(int row, int col) { return ((row & 1
 
 // stem tile (+bias, ReLU, * acc_scale) -> LDS -> 3x3/2 max-pool -> global; shared by the f32 and the f16-rate stems.
 // `smem` is the whole (now idle) operand LDS; every wave has passed a barrier since its last operand read.
-template <typename OutT>
+// QUANT (the quantised model's stem, stem_pool16_kernel<unsigned char, false, true>): the accumulators are EXACT integers (see
+// there); they are staged raw, pooled, and only the pooled maxima are requantised -- QLinearConv's requantisation is monotone in the
+// accumulator (positive multiplier, round, clamp), so it commutes with the max: a quarter of the requantisations of stem-then-pool
+// and the same bytes.  Output rows are 128 channels (the K step of the i8 GEMMs): 64 values + 64 zeros.
+struct StemQuant {
+    const int32_t* bias;  // the operator's own bias (the operand is q - x_zp: nothing to fold)
+    const float* mult;    // (x_s * w_s[o]) / y_s
+    int y_zp;
+};
+template <typename OutT, bool QUANT = false>
 __device__ __forceinline__ void stem_stage_and_pool(float* smem, const f32x16s (&acc)[2][2], const int (&pidx)[2], int half, float acc_scale,
                                                     const float* __restrict__ bias, OutT* __restrict__ out, int py0, int px0, int sy0, int sx0,
-                                                    int SH, int SW, int PH, int PW, unsigned* __restrict__ amax) {
+                                                    int SH, int SW, int PH, int PW, unsigned* __restrict__ amax, const StemQuant q = StemQuant{}) {
     const int tid = threadIdx.x;
     float* stage = smem;
 #pragma unroll
@@ -185,6 +195,10 @@ __device__ __forceinline__ void stem_stage_and_pool(float* smem, const f32x16s (
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int n = j * 32 + 8 * g + 4 * half;
+                if constexpr (QUANT) {
+                    *reinterpret_cast<float4*>(o + n) = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    continue;
+                }
                 const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
                 float4 v;
                 v.x = fmaxf(acc[i][j][4 * g + 0] * acc_scale + b4.x, 0.f);
@@ -217,6 +231,20 @@ __device__ __forceinline__ void stem_stage_and_pool(float* smem, const f32x16s (
                 const float4 v = *reinterpret_cast<const float4*>(stage + (sr * SP_SC + sc) * SP_STAGE + c4 * 4);
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
+        }
+        if constexpr (QUANT) {
+            const int4 b4 = *reinterpret_cast<const int4*>(q.bias + c4 * 4);
+            const float4 m4 = *reinterpret_cast<const float4*>(q.mult + c4 * 4);
+            const float yz = (float)q.y_zp, lo = -yz, hi = 255.f - yz;
+            unsigned w = 0;
+            w = q_pack(q_requant_c((int)m.x + b4.x, m4.x, lo, hi) + yz, 0, w);
+            w = q_pack(q_requant_c((int)m.y + b4.y, m4.y, lo, hi) + yz, 1, w);
+            w = q_pack(q_requant_c((int)m.z + b4.z, m4.z, lo, hi) + yz, 2, w);
+            w = q_pack(q_requant_c((int)m.w + b4.w, m4.w, lo, hi) + yz, 3, w);
+            unsigned char* o = reinterpret_cast<unsigned char*>(out) + ((size_t)py * PW + pxo) * 128 + c4 * 4;
+            *reinterpret_cast<unsigned*>(o) = w;
+            *reinterpret_cast<unsigned*>(o + 64) = 0u;  // channel padding
+            continue;
         }
         OutT* o = out + ((size_t)py * PW + pxo) * 64 + c4 * 4;
         if constexpr (sizeof(OutT) == 4) {
@@ -363,11 +391,15 @@ constexpr int S16_PATCH_H = SP_IH * S16_PSTR;  // halfs per patch plane
 constexpr int S16_W_H = 64 * S16_WSTR;         // halfs per weight plane
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
-template <typename OutT, bool SPLIT>
+// QUANT: the stem of a QUANTISED model (QuantizeLinear of the normalised image + QLinearConv 7x7/2, then the u8 max-pool) on the
+// same f16 MFMA, exactly: the table holds q - x_zp (integers in -255..255), the weights are the s8 values, both exact in f16; a
+// product is below 2^15 and the 147-term sum below 2^23, so the f32 accumulation is exact integer arithmetic.  Out-of-frame taps are
+// zero = "the zero point", QLinearConv's padding.  (quant.hip's stem_q + maxpool_q are the unfused form: 0.09 + 0.017 ms.)
+template <typename OutT, bool SPLIT, bool QUANT = false>
 __global__ void __launch_bounds__(256, 2)
     stem_pool16_kernel(const uint8_t* __restrict__ bgr, int H, int W, const float* __restrict__ wt, const float* __restrict__ bias,
                        const float* __restrict__ lut, OutT* __restrict__ out, int SH, int SW, int PH, int PW,
-                       float a_scale, float w_scale, float acc_scale, unsigned* __restrict__ amax) {
+                       float a_scale, float w_scale, float acc_scale, unsigned* __restrict__ amax, const StemQuant sq = StemQuant{}) {
     constexpr int NP = SPLIT ? 2 : 1;  // operand planes: hi (, lo)
     __shared__ __attribute__((aligned(16))) float smem[SP_LDS_FLOATS];
     _Float16* patch = reinterpret_cast<_Float16*>(smem);  // [NP][SP_IH][S16_PSTR]
@@ -481,7 +513,15 @@ __global__ void __launch_bounds__(256, 2)
             }
     }
     __syncthreads();  // every wave is done with the operands: their LDS becomes the stem tile
-    stem_stage_and_pool<OutT>(smem, acc, pidx, half, acc_scale, bias, out, py0, px0, sy0, sx0, SH, SW, PH, PW, amax);
+    stem_stage_and_pool<OutT, QUANT>(smem, acc, pidx, half, acc_scale, bias, out, py0, px0, sy0, sx0, SH, SW, PH, PW, amax, sq);
+}
+
+hipError_t launch_stem_pool_q(const uint8_t* bgr, int H, int W, const float* wt, const float* lut, const int32_t* q_bias, const float* q_mult,
+                              int y_zp, uint8_t* out, int SH, int SW, int PH, int PW, hipStream_t s) {
+    dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
+    hipLaunchKernelGGL((stem_pool16_kernel<unsigned char, false, true>), grid, dim3(256), 0, s, bgr, H, W, wt, (const float*)nullptr, lut, out, SH, SW,
+                       PH, PW, 1.0f, 1.0f, 1.0f, (unsigned*)nullptr, StemQuant{q_bias, q_mult, y_zp});
+    return hipGetLastError();
 }
 
 hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const float* bias, const float* lut, void* out,

@@ -222,6 +222,13 @@ def test_hostile_quantisation_parameters_are_bit_exact(oracle, seed, size):
         assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
         assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, h, w))).all()
     assert sat_lo > 1000 and sat_hi > 1000  # the set really reaches both clamps
+    # the product form (no kept activations): stem + max-pool fused on the f16 MFMA, pooled before requantised
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.LoadBlob(qb))
+        rgba2, _ = FramePath(c).advance(fr, 1.0)
+        lo2, la2 = m.lowres()
+        assert (lo2.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la2.view(np.uint32) == ref_aux.view(np.uint32)).all()
+        assert (rgba2 == rgba).all()
 
 
 def test_configs0_640x480_quantised_frame_is_bit_exact(qblob, oracle):
