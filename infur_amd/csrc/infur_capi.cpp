@@ -1952,6 +1952,10 @@ int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, ui
         if (rc) return fail(c, rc, "%s", infur_status_string(rc));
         infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
         if (!lane->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
+        // (a model may have been (re)loaded on one context after the lane was added: both kinds of arithmetic in one stream would
+        //  alternate frame by frame)
+        if (lane->quant != st->lanes[0]->quant || lane->depth != st->lanes[0]->depth)
+            return fail(c, INFUR_E_INVALID_ARG, "the stream's lanes hold different models (quantised / float, or different depths): replicate one model to all of them");
         const size_t depth = st->slots.size();
         if (st->head - st->tail >= depth)
             return fail(c, INFUR_E_CAPACITY, "all %zu slots are in flight: collect before submitting more", depth);
