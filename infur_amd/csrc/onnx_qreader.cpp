@@ -9,8 +9,8 @@
 //                   the downsample QLinearConv of the block's input; ReLUs are folded into the clamps (a Relu node left on a
 //                   tensor whose zero point is 0 is looked through)
 //   heads: QLinearConv 3x3 -> QLinearConv 1x1 -> DequantizeLinear -> Resize(linear, [pytorch_]half_pixel) -> output 0 / 1
-// Requirements (format errors otherwise): u8 activations (zero points UINT8), s8 weights with zero point 0 and one scale per
-// tensor or per output channel, int32 bias, group 1, every shape / stride / pad / dilation as torchvision's fcn_resnet50/101.
+// Requirements (format errors otherwise): u8 activations (zero points UINT8), INT8 or UINT8 weights whose distance from their zero
+// point (scalar or per output channel) fits 8 bits -- stored re-centred as s8 -- with one scale per tensor or per output channel, int32 bias, group 1, every shape / stride / pad / dilation as torchvision's fcn_resnet50/101.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -69,7 +69,8 @@ struct QC {  // one QLinearConv as the blob wants it
     int cout = 0, cin = 0, kh = 0, kw = 0, stride = 1, pad = 0, dil = 1;
     float x_scale = 0, y_scale = 0;
     int32_t x_zp = 0, y_zp = 0;
-    const uint8_t* w = nullptr;
+    const uint8_t* w = nullptr;   // s8 OIHW: the initializer's own bytes, or w_own when the file's weights had to be re-centred
+    std::vector<uint8_t> w_own;
     std::vector<float> w_scale;
     std::vector<int32_t> bias;
     std::string out;
@@ -88,17 +89,36 @@ bool read_qconv(const QGraph& g, int ni, QC* q, std::string* err) {
     for (auto d : wt.dims)
         if (d <= 0 || d > 65536) return bad("absurd weight shape");
     q->cout = (int)wt.dims[0]; q->cin = (int)wt.dims[1]; q->kh = (int)wt.dims[2]; q->kw = (int)wt.dims[3];
+    // weights: INT8 or UINT8 with a zero point of the same type (scalar or one per output channel).  The blob and the kernels carry
+    // s8 weights with zero point 0, so w - w_zp is formed here; it must fit s8 (UINT8 weights around 128 do, the usual case)
     size_t wn;
-    if (wt.dtype == 2) return bad("UINT8 weights are not supported (INT8 with zero point 0 is what the quantisers write for convolutions)");
-    if (!int_bytes(wt, 3, 1, &wn, &q->w)) return bad("the weight must be INT8 raw_data");
-    // weight zero point: INT8 scalar or [cout], all zero
+    const int wdt = wt.dtype;
+    const uint8_t* wraw;
+    if ((wdt != 2 && wdt != 3) || !int_bytes(wt, wdt, 1, &wn, &wraw)) return bad("the weight must be INT8 or UINT8 raw_data");
     {
         auto zi = g.inits.find(n.in[5]);
         size_t zn;
         const uint8_t* zp;
-        if (zi == g.inits.end() || !int_bytes(zi->second, 3, 1, &zn, &zp) || (zn != 1 && zn != (size_t)q->cout)) return bad("w_zero_point must be an INT8 scalar or [cout] initializer");
-        for (size_t i = 0; i < zn; i++)
-            if (zp[i] != 0) return bad("a non-zero weight zero point is not supported");
+        if (zi == g.inits.end() || !int_bytes(zi->second, wdt, 1, &zn, &zp) || (zn != 1 && zn != (size_t)q->cout))
+            return bad("w_zero_point must be a scalar or [cout] initializer of the weight's type");
+        bool all_zero = wdt == 3;
+        for (size_t i = 0; i < zn && all_zero; i++) all_zero = zp[i] == 0;
+        if (all_zero) {
+            q->w = wraw;
+        } else {
+            q->w_own.resize(wn);
+            const size_t per = wn / (size_t)q->cout;
+            for (int o = 0; o < q->cout; o++) {
+                const int z = wdt == 3 ? (int)(int8_t)zp[zn == 1 ? 0 : o] : (int)zp[zn == 1 ? 0 : o];
+                for (size_t k = 0; k < per; k++) {
+                    const size_t i = (size_t)o * per + k;
+                    const int v = (wdt == 3 ? (int)(int8_t)wraw[i] : (int)wraw[i]) - z;
+                    if (v < -128 || v > 127) return bad("w - w_zero_point does not fit 8 bits (weights this far from their zero point are not supported)");
+                    q->w_own[i] = (uint8_t)(int8_t)v;
+                }
+            }
+            q->w = nullptr;  // (set after the QC has reached its final place: w_own moves with it)
+        }
     }
     {
         auto si = g.inits.find(n.in[4]);
@@ -412,7 +432,7 @@ int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, 
         put32(e + 40, (uint32_t)c.cout); put32(e + 44, (uint32_t)c.cin); put32(e + 48, (uint32_t)c.kh); put32(e + 52, (uint32_t)c.kw);
         putf(e + 56, c.x_scale); put32(e + 60, (uint32_t)c.x_zp); putf(e + 64, c.y_scale); put32(e + 68, (uint32_t)c.y_zp);
         put64(e + 72, offs[i].w); put64(e + 80, offs[i].ws); put64(e + 88, offs[i].b);
-        memcpy(blob.data() + offs[i].w, c.w, (size_t)c.cout * c.cin * c.kh * c.kw);
+        memcpy(blob.data() + offs[i].w, c.w ? c.w : c.w_own.data(), (size_t)c.cout * c.cin * c.kh * c.kw);
         memcpy(blob.data() + offs[i].ws, c.w_scale.data(), (size_t)c.cout * 4);
         memcpy(blob.data() + offs[i].b, c.bias.data(), (size_t)c.cout * 4);
     }

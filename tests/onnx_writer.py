@@ -296,7 +296,7 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
 
 def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(), relu_after=(), w_zp=0, w_dtype=3, swap_add=None,
                input_type=1, coord_mode="pytorch_half_pixel", drop_last=0, stem_scale=None, dq_scale=None, no_bias=(), vector_wzp=False,
-               pad_zp_conv=None, extra_qconv=False):
+               pad_zp_conv=None, extra_qconv=False, shift_weights=True):
     """The QOperator int8 form of the same network, as ONNX Runtime's static quantisation writes it (the shape of
     `fcn-resnet50-12-int8.onnx`, the file the reference's tests load: predict_onnx.rs:357-381):
     QuantizeLinear -> QLinearConv (ReLU folded) -> MaxPool (u8) -> bottlenecks (QLinearConv x3 [+ downsample], com.microsoft
@@ -338,17 +338,19 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
         s, c = by_name[name]
         xs, xz = scalar_f(name + ".x_scale", stem_scale if (stem_scale and s.role == "stem") else c.x_scale), scalar_u8(name + ".x_zp", pad_zp_conv[1] if pad_zp_conv and pad_zp_conv[0] == name else c.x_zp)
         ys, yz = scalar_f(name + ".y_scale", c.y_scale), scalar_u8(name + ".y_zp", c.y_zp)
+        # the file stores w + w_zp (UINT8 or INT8): the reader re-centres it to the blob's s8 weights with zero point 0
         w = np.ascontiguousarray(c.w, np.int8)
+        stored = w.astype(np.int16) + (w_zp if shift_weights else 0)
         if w_dtype == 2:
-            inits.append(tensor(name + ".weight", (w.astype(np.int16) + 128).astype(np.uint8), dtype=2))
+            inits.append(tensor(name + ".weight", np.clip(stored, 0, 255).astype(np.uint8), dtype=2))
         else:
-            inits.append(tensor(name + ".weight", w, dtype=3))
+            inits.append(tensor(name + ".weight", np.clip(stored, -128, 127).astype(np.int8), dtype=3))
         if name in per_tensor_scale:
             inits.append(tensor(name + ".w_scale", np.asarray(c.w_scale[0], np.float32).reshape(())))
         else:
             inits.append(tensor(name + ".w_scale", np.asarray(c.w_scale, np.float32)))
-        zp = np.full((s.cout,) if vector_wzp else (), w_zp, np.int8)
-        inits.append(tensor(name + ".w_zp", zp, dtype=w_dtype if w_dtype == 2 else 3))
+        zp = np.full((s.cout,) if vector_wzp else (), w_zp, np.uint8 if w_dtype == 2 else np.int8)
+        inits.append(tensor(name + ".w_zp", zp, dtype=2 if w_dtype == 2 else 3))
         ins = [x, xs, xz, name + ".weight", name + ".w_scale", name + ".w_zp", ys, yz]
         if name not in no_bias:
             inits.append(tensor(name + ".bias", np.asarray(c.bias, np.int32), dtype=6))

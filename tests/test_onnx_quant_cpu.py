@@ -62,6 +62,20 @@ def test_qoperator_model_converts_to_the_same_blob_bit_for_bit(lib, q50, order, 
     assert out == W.pack_qblob(convs, adds, 50, 21, True)
 
 
+@pytest.mark.parametrize("w_dtype,w_zp,vec", [(2, 128, False), (2, 127, True), (3, 1, True)])
+def test_weights_around_a_zero_point_are_recentred(lib, w_dtype, w_zp, vec):
+    """UINT8 weights around 128 (what older onnxruntime quantisers write), or INT8 weights with a non-zero zero point: the
+    reader stores w - w_zp as s8, the blob equals the one packed from the s8 weights"""
+    specs, convs, adds = random_qmodel(seed=9)
+    if w_zp != 128:  # keep w + w_zp inside the stored type's range
+        for c in convs:
+            c.w = np.clip(c.w, -126, 126)
+    model = OW.fcn_qmodel(convs, adds, specs, w_dtype=w_dtype, w_zp=w_zp, vector_wzp=vec)
+    rc, err, out = convert(lib, model)
+    assert rc == 0, err
+    assert out == W.pack_qblob(convs, adds, 50, 21, True)
+
+
 def test_variants_no_aux_r101_redundant_relu_missing_bias(lib):
     specs, convs, adds = random_qmodel(depth=101, aux=False, ncls=7, seed=5)
     zero_zp = [c.name for c in convs if c.y_zp == 0]
@@ -78,8 +92,8 @@ def test_variants_no_aux_r101_redundant_relu_missing_bias(lib):
 
 
 @pytest.mark.parametrize("kwargs,msg", [
-    (dict(w_zp=3), "non-zero weight zero point"),
-    (dict(w_dtype=2), "UINT8 weights"),
+    (dict(w_zp=3, shift_weights=False), "does not fit 8 bits"),   # INT8 weights -127..127 with zero point 3: -130 exists
+    (dict(w_dtype=2, w_zp=200, shift_weights=False), "does not fit 8 bits"),  # UINT8 weights 0..127 with zero point 200
     (dict(input_type=2), "only a Float"),
     (dict(coord_mode="align_corners"), "align_corners"),
     (dict(drop_last=1), "QLinearConv nodes"),
