@@ -8,7 +8,12 @@ from infur_amd.app import StreamPath
 from infur_amd.processors import Context, FramePath, Model, ModelCmd
 
 c = Context(device=0, profile=False)
-Model(c).control(ModelCmd.LoadBlob(W.synth_blob()))
+if len(sys.argv) > 1 and sys.argv[1] == "i8":  # the quantised model through the same soak
+    from infur_amd import quantize
+
+    Model(c).control(ModelCmd.LoadBlob(quantize.synth_qblob()))
+else:
+    Model(c).control(ModelCmd.LoadBlob(W.synth_blob()))
 fp = FramePath(c)
 sizes = [(1080, 1920), (480, 640), (720, 1280), (97, 161)]
 frames = {s: W.synth_frame(*s, index=7) for s in sizes}
