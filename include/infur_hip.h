@@ -185,6 +185,15 @@ int32_t infur_model_advance_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, u
  * candidates on first use: a few hundred ms).  A GUI calls this when the scale slider settles
  * (processing.rs:220-226 marks the processor dirty at that moment).  INFUR_E_MODEL_NOT_LOADED without a model. */
 int32_t infur_model_warmup(infur_ctx* ctx, uint32_t w, uint32_t h);
+/* Optional (ABI 3, additive): replay the fused frame path (infur_frame_advance[_dev], the stream ring, the batch calls) as a
+ * hipGraph.  A frame is 55-110 kernel launches; for SMALL frames in the fast modes (640x480 through the quantised model: 0.7 ms)
+ * the host's enqueue time bounds the rate.  With replay enabled, a frame shape that has run unchanged for 6 frames (arena settled,
+ * tile configurations measured) is captured from the same enqueue code -- one graph per (input pointer, output pointer, w, h,
+ * factor, mode), at most 12 cached -- and launched as one graph from then on; any allocation, release, model or tuning change
+ * drops the cached graphs.  Results are the eager path's bits.  Ignored (eager) while options.profile or
+ * options.keep_activations is set.  infur_ctx_graph_stats: captures / replays so far, graphs cached now (any pointer may be NULL). */
+int32_t infur_ctx_set_graph_replay(infur_ctx* ctx, uint32_t enable);
+int32_t infur_ctx_graph_stats(const infur_ctx* ctx, uint64_t* captures, uint64_t* replays, uint32_t* cached);
 /* output-stride-8 logits of the last advance, [num_classes, lh, lw] f32 planar (host) */
 int32_t infur_model_lowres_dims(uint32_t h, uint32_t w, uint32_t* lh, uint32_t* lw);
 int32_t infur_model_read_lowres(infur_ctx* ctx, float* out_low, float* aux_low, uint32_t* lh,

@@ -108,6 +108,8 @@ SIGNATURES = {
     "infur_model_advance": (C.c_int32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32p]),
     "infur_model_advance_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32p]),
     "infur_model_warmup": (C.c_int32, [_vp, _u32, _u32]),
+    "infur_ctx_set_graph_replay": (C.c_int32, [_vp, _u32]),
+    "infur_ctx_graph_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(_u32)]),
     "infur_model_lowres_dims": (C.c_int32, [_u32, _u32, _u32p, _u32p]),
     "infur_model_read_lowres": (C.c_int32, [_vp, _vp, _vp, _u32p, _u32p]),
     "infur_debug_read_activation": (C.c_int32, [_vp, _u32, _vp, _sz, _u32p, _u32p, _u32p]),

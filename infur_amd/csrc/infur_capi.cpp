@@ -65,6 +65,7 @@ int32_t fail(infur_ctx* c, int32_t code, const char* fmt, ...) {
 
 int32_t ensure(infur_ctx* c, Buf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return INFUR_OK;
+    c->mem_gen++;
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;
@@ -82,6 +83,7 @@ int32_t pool_acquire(infur_ctx* c, size_t bytes, int* slot) {
     }
     if (best < 0) {
         Buf b;
+        c->mem_gen++;
         HIPCHK(c, hipMalloc(&b.p, bytes));
         b.bytes = bytes;
         c->pool.push_back(b);
@@ -107,6 +109,7 @@ void pool_release_all(infur_ctx* c) {
 }
 
 void pool_free(infur_ctx* c) {
+    c->mem_gen++;
     for (auto& b : c->pool)
         if (b.p) (void)hipFree(b.p);
     c->pool.clear();
@@ -120,6 +123,7 @@ void pool_trim(infur_ctx* c) {
     size_t kept = 0;
     for (auto& b : c->pool) {
         if (!b.used && b.p && b.last_use + kPoolTrimAfter <= c->frame_no) {
+            c->mem_gen++;
             (void)hipFree(b.p);
             b.p = nullptr;
             b.bytes = 0;
@@ -295,6 +299,7 @@ std::vector<ConvLayer> build_graph(int depth, int ncls, bool aux) {
 bool b2b_candidate(const infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1);
 
 void model_free(infur_ctx* c) {
+    c->mem_gen++;
     if (c->d_weights) (void)hipFree(c->d_weights);
     c->d_weights = nullptr;
     c->convs.clear();
@@ -557,6 +562,7 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
     for (const auto& kt : timed)
         if (kt.second <= best * 1.02f && conv_igemm_config_tile_area(kt.first) > conv_igemm_config_tile_area(*cfg)) *cfg = kt.first;
     c->tuned[key] = *cfg;
+    c->mem_gen++;  // (a new decision: frames captured as graphs before it are stale)
     return INFUR_OK;
 }
 
@@ -744,6 +750,7 @@ int32_t run_b2b(infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1, const Te
         }
         use = t_fused < t_pair;
         c->tuned[key] = use ? 1 : 0;
+        c->mem_gen++;
     }
     if (!use) {
         give_back();
@@ -851,7 +858,6 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
     std::vector<float> h_ws, h_mult;
     for (uint32_t i = 0; i < n; i++) {
         ConvLayer& L = g[i];
-        const size_t taps = (size_t)L.k * L.k;
         L.x_scale = qc[i].x_scale; L.x_zp = qc[i].x_zp; L.y_scale = qc[i].y_scale; L.y_zp = qc[i].y_zp;
         L.d_w = base + off;
         off += align_up(q_wbytes(L), 256);
@@ -1246,6 +1252,8 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
     }
 }
 
+static void graphs_drop(infur_ctx* c);
+
 void infur_ctx_destroy(infur_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -1256,6 +1264,7 @@ void infur_ctx_destroy(infur_ctx* c) {
         infur_stream_destroy(c->batch_ring);
         c->batch_ring = nullptr;
     }
+    graphs_drop(c);
     model_free(c);
     pool_free(c);
     for (Buf* b : {&c->st_in, &c->st_scaled, &c->st_rgba, &c->st_f32a, &c->st_f32b})
@@ -1725,6 +1734,52 @@ int32_t infur_bgr_to_rgba(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t
 }
 
 // ---- fused frame path ----
+// the fused frame path: Scale -> forward -> up-sample + argmax + shade, everything enqueued on c->stream (arguments validated by
+// the caller; *ow x *oh are the scaled dimensions)
+static int32_t frame_body(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode, void* d_rgba, void* d_scaled,
+                          uint32_t ow, uint32_t oh) {
+    const size_t sbytes = (size_t)ow * oh * 3, need = (size_t)ow * oh * 4;
+    const void* frame = d_bgr;
+    prof_reset(c);
+    std::vector<ProfRec> pre;
+    if (factor != 1.0f || d_scaled) {
+        void* dst = d_scaled;
+        if (!dst) {
+            RETIF(ensure(c, c->st_scaled, sbytes));
+            dst = c->st_scaled.p;
+        }
+        uint32_t a, b;
+        RETIF(infur_scale_dev(c, d_bgr, w, h, factor, mode, dst, sbytes, &a, &b));
+        frame = dst;
+        pre.swap(c->prof);  // forward() resets the records; keep the scale's
+    }
+    RETIF(forward(c, (const uint8_t*)frame, (int)ow, (int)oh));
+    c->prof.insert(c->prof.begin(), pre.begin(), pre.end());
+    {
+        const Tensor& t = c->out_low;  // only out[0] is decoded, app.rs:116
+        ProfScope ps(c, "out.resize+colorcode", "upsample_argmax_shade", 0, (double)t.bytes() + (double)need);
+        HIPCHK(c, launch_upsample_argmax_shade((const float*)t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)oh, (int)ow, c->stream));
+    }
+    return INFUR_OK;
+}
+
+// ---- hipGraph replay (infur_ctx_set_graph_replay) ----
+// A frame is 55-110 kernel launches; for small frames in the fast modes (a 640x480 frame through the quantised model: 0.74 ms)
+// the host's enqueue time is what bounds the rate.  Once a frame shape has run eagerly often enough for the arena to have settled
+// (no allocation, release or tuning decision during the last kGraphSettle frames -- the pool trims itself after 4 frames of one
+// size), the next frame with a given (input, output, shape) is CAPTURED from the very same enqueue code and replayed from then on.
+// The graph holds raw pointers into the arena: every device allocation / release, model change or tuning change bumps
+// ctx->mem_gen and drops all cached graphs.
+constexpr uint32_t kGraphSettle = 6;
+constexpr size_t kGraphCache = 12;
+
+static void graphs_drop(infur_ctx* c) {
+    for (auto& g : c->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+    c->graphs_gen = c->mem_gen;
+}
+
 int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
                                 void* d_rgba, size_t cap, void* d_scaled, uint32_t* ow, uint32_t* oh) {
     try {
@@ -1738,36 +1793,109 @@ int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uin
         if (!d_bgr) return INFUR_E_INVALID_ARG;
         const size_t sbytes = (size_t)*ow * *oh * 3, need = (size_t)*ow * *oh * 4;
         if (need == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", *ow, *oh);
-        const void* frame = d_bgr;
-        prof_reset(c);
-        std::vector<ProfRec> pre;
-        if (factor != 1.0f || d_scaled) {
-            void* dst = d_scaled;
-            if (!dst) {
-                RETIF(ensure(c, c->st_scaled, sbytes));
-                dst = c->st_scaled.p;
+        if (!c->loaded) {
+            // app.rs:127-129: no model -> the mask is cleared by the caller; the Scale stage still runs
+            if (factor != 1.0f || d_scaled) {
+                void* dst = d_scaled;
+                if (!dst) {
+                    RETIF(ensure(c, c->st_scaled, sbytes));
+                    dst = c->st_scaled.p;
+                }
+                uint32_t a, b;
+                prof_reset(c);
+                RETIF(infur_scale_dev(c, d_bgr, w, h, factor, mode, dst, sbytes, &a, &b));
             }
-            uint32_t a, b;
-            RETIF(infur_scale_dev(c, d_bgr, w, h, factor, mode, dst, sbytes, &a, &b));
-            frame = dst;
-            pre.swap(c->prof);  // forward() resets the records; keep the scale's
+            return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
         }
-        if (!c->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");  // app.rs:127-129: mask cleared
         if (!d_rgba) return INFUR_E_INVALID_ARG;
         if (cap < need) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", need, cap);
-        RETIF(forward(c, (const uint8_t*)frame, (int)*ow, (int)*oh));
-        c->prof.insert(c->prof.begin(), pre.begin(), pre.end());
-        {
-            const Tensor& t = c->out_low;  // only out[0] is decoded, app.rs:116
-            ProfScope ps(c, "out.resize+colorcode", "upsample_argmax_shade", 0, (double)t.bytes() + (double)need);
-            HIPCHK(c, launch_upsample_argmax_shade((const float*)t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)*oh, (int)*ow, c->stream));
+
+        const bool graphs_on = c->graph_replay && !c->opt.profile && !c->opt.keep_activations;
+        if (!graphs_on) return frame_body(c, d_bgr, w, h, factor, mode, d_rgba, d_scaled, *ow, *oh);
+        if (c->graphs_gen != c->mem_gen) graphs_drop(c);
+        uint32_t fbits;
+        memcpy(&fbits, &factor, 4);
+        for (auto& g : c->graphs)
+            if (g.d_bgr == d_bgr && g.d_rgba == d_rgba && g.d_scaled == d_scaled && g.w == w && g.h == h && g.mode == mode && g.factor_bits == fbits) {
+                HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
+                c->out_low = g.out_low;
+                c->aux_low = g.aux_low;
+                g.stamp = ++c->graph_clock;
+                c->graph_replays++;
+                return INFUR_OK;
+            }
+        // how long has this shape been running without the arena moving?
+        if (c->streak_w == w && c->streak_h == h && c->streak_mode == mode && c->streak_factor == fbits && c->streak_gen == c->mem_gen)
+            c->graph_streak++;
+        else
+            c->graph_streak = 0;
+        c->streak_w = w; c->streak_h = h; c->streak_mode = mode; c->streak_factor = fbits;
+        if (c->graph_streak < kGraphSettle) {
+            rc = frame_body(c, d_bgr, w, h, factor, mode, d_rgba, d_scaled, *ow, *oh);
+            c->streak_gen = c->mem_gen;  // (a frame that allocated, trimmed or tuned restarts the count)
+            return rc;
         }
-        return INFUR_OK;
+        // capture: the same enqueue code, recorded instead of executed
+        const uint64_t gen0 = c->mem_gen;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            c->graph_replay = false;  // (a stream that cannot capture: stay eager)
+            return frame_body(c, d_bgr, w, h, factor, mode, d_rgba, d_scaled, *ow, *oh);
+        }
+        rc = frame_body(c, d_bgr, w, h, factor, mode, d_rgba, d_scaled, *ow, *oh);
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (rc == INFUR_OK && ee == hipSuccess && graph && c->mem_gen == gen0 && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            if (c->graphs.size() >= kGraphCache) {  // evict the least recently used
+                size_t lru = 0;
+                for (size_t i = 1; i < c->graphs.size(); i++)
+                    if (c->graphs[i].stamp < c->graphs[lru].stamp) lru = i;
+                (void)hipGraphExecDestroy(c->graphs[lru].exec);
+                c->graphs.erase(c->graphs.begin() + (long)lru);
+            }
+            infur_ctx::FrameGraph g;
+            g.d_bgr = d_bgr; g.d_rgba = d_rgba; g.d_scaled = d_scaled; g.w = w; g.h = h; g.mode = mode; g.factor_bits = fbits;
+            g.exec = exec; g.ow = *ow; g.oh = *oh; g.out_low = c->out_low; g.aux_low = c->aux_low; g.stamp = ++c->graph_clock;
+            c->graphs.push_back(g);
+            c->graph_captures++;
+            HIPCHK(c, hipGraphLaunch(exec, c->stream));
+            return INFUR_OK;
+        }
+        // the capture did not yield a graph (something in the frame is not capturable, or it allocated after all): nothing
+        // has executed -- run this frame eagerly and stay eager
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        c->graph_replay = false;
+        return frame_body(c, d_bgr, w, h, factor, mode, d_rgba, d_scaled, *ow, *oh);
     } catch (const std::bad_alloc&) {
         return fail(c, INFUR_E_CAPACITY, "out of host memory");
     } catch (const std::exception& e) {
         return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
+}
+
+int32_t infur_ctx_set_graph_replay(infur_ctx* c, uint32_t enable) {
+    enter(c);
+    if (!c) return INFUR_E_INVALID_ARG;
+    c->graph_replay = enable != 0;
+    if (!enable) {
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        graphs_drop(c);
+    }
+    c->graph_streak = 0;
+    return INFUR_OK;
+}
+
+int32_t infur_ctx_graph_stats(const infur_ctx* c, uint64_t* captures, uint64_t* replays, uint32_t* cached) {
+    enter(c);
+    if (!c) return INFUR_E_INVALID_ARG;
+    if (captures) *captures = c->graph_captures;
+    if (replays) *replays = c->graph_replays;
+    if (cached) *cached = (uint32_t)c->graphs.size();
+    return INFUR_OK;
 }
 
 int32_t infur_frame_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
@@ -2150,6 +2278,7 @@ int32_t infur_tune_import(infur_ctx* c, const char* text, size_t len) {
             ok = ok && sscanf(ln.c_str() + off, "%d", &cfg) == 1;
             if (!ok || cfg < 0 || cfg >= conv_igemm_num_configs()) return fail(c, INFUR_E_INVALID_ARG, "bad tuning line: %s", ln.c_str());
             c->tuned[key] = cfg;
+            c->mem_gen++;
         }
         return INFUR_OK;
     } catch (const std::bad_alloc&) {

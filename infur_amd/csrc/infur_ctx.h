@@ -105,6 +105,25 @@ struct infur_ctx {
     // activation pool + results of the last forward
     std::vector<infur::Buf> pool;
     infur::Tensor out_low, aux_low;  // NHWC [lh][lw][K]
+    // ---- hipGraph replay of the fused frame path (infur_ctx_set_graph_replay; infur_capi.cpp: frame_advance_dev) ----
+    struct FrameGraph {
+        const void* d_bgr = nullptr;
+        void* d_rgba = nullptr;
+        void* d_scaled = nullptr;
+        uint32_t w = 0, h = 0, mode = 0, factor_bits = 0;
+        hipGraphExec_t exec = nullptr;
+        uint32_t ow = 0, oh = 0;
+        infur::Tensor out_low, aux_low;  // what infur_model_read_lowres sees after a replay
+        uint64_t stamp = 0;
+    };
+    bool graph_replay = false;
+    std::vector<FrameGraph> graphs;
+    uint64_t mem_gen = 0;      // bumped by every device allocation / release and model change: the cached graphs hold raw pointers
+    uint64_t graphs_gen = 0;   // mem_gen the cached graphs were captured under
+    uint32_t graph_streak = 0; // consecutive eager frames of one shape during which mem_gen did not move
+    uint64_t streak_gen = 0, graph_clock = 0;
+    uint32_t streak_w = 0, streak_h = 0, streak_mode = 0, streak_factor = 0;
+    uint64_t graph_replays = 0, graph_captures = 0;
     int last_h = 0, last_w = 0;
     uint64_t frame_no = 0;   // forward() calls so far
     uint32_t same_size = 0;  // consecutive forwards at last_h x last_w

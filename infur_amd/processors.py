@@ -104,7 +104,7 @@ class Context:
     def __init__(self, device: int = 0, compute_aux: bool = True, profile: bool = False,
                  keep_activations: bool = False, stream: Optional[int] = None, dtype: str = "f32",
                  winograd_min_cin: int = 0, winograd_tile: int = 0, autotune: bool = True, fuse_downsample: bool = True,
-                 fuse_stem_pool: bool = True, fuse_b2b: bool = True):
+                 fuse_stem_pool: bool = True, fuse_b2b: bool = True, graph_replay: bool = False):
         L = self.L = _lib.load()
         o = _lib.Options()
         L.infur_options_default(C.byref(o))
@@ -130,6 +130,14 @@ class Context:
         self.device = device
         if autotune and os.path.exists(TUNE_DB):  # measured tile configurations for the common shapes
             self.load_tuning(TUNE_DB)
+        if graph_replay:  # the fused frame path as a hipGraph once a frame shape has settled (small frames: launch-bound)
+            self.check(L.infur_ctx_set_graph_replay(h, 1))
+
+    def graph_stats(self):
+        """(graphs captured so far, frames replayed from a graph, graphs cached now)"""
+        a, b, n = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        self.check(self.L.infur_ctx_graph_stats(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     def load_tuning(self, path: str) -> None:
         txt = open(path, "rb").read()

