@@ -1774,6 +1774,7 @@ constexpr uint32_t kGraphSettle = 6;
 constexpr size_t kGraphCache = 12;
 
 static void graphs_drop(infur_ctx* c) {
+    if (!c->graphs.empty() && c->stream) (void)hipStreamSynchronize(c->stream);  // (a replay may still be in flight)
     for (auto& g : c->graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
