@@ -131,3 +131,67 @@ def synth_qblob(depth: int = 50, calib: int = 3, size: Tuple[int, int] = (96, 12
     """the seeded synthetic model, statically quantised on `calib` synthetic frames"""
     frames = [normalise(W.synth_frame(size[0], size[1], index=100 + k)) for k in range(calib)]
     return quantise_model(W.synth_blob(depth=depth), frames)
+
+
+def _load_float_blob(path: str) -> bytes:
+    """an INFURW01 blob, or a float ONNX file through the library's host-only converter (no GPU needed)"""
+    import ctypes as C
+
+    data = open(path, "rb").read()
+    if data[:8] == b"INFURW01":
+        return data
+    from . import _lib
+
+    L = _lib.load()
+    blob, n = C.c_void_p(None), C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    if L.infur_onnx_to_blob(data, len(data), C.byref(blob), C.byref(n), err, 512) != 0:
+        raise SystemExit(f"{path}: {err.value.decode()}")
+    out = C.string_at(blob, n.value)
+    L.infur_buffer_free(blob)
+    if out[:8] != b"INFURW01":
+        raise SystemExit(f"{path} is already a quantised model")
+    return out
+
+
+def main(argv=None) -> int:
+    """python -m infur_amd.quantize model.onnx|model.blob out.qblob [--frames clip.bgr24 --width W --height H] [--calib N]
+
+    Static quantisation of a float FCN-ResNet50/101 into an INFURQ01 file that ModelCmd::Load takes.  Calibration frames: raw bgr24
+    frames (ffmpeg's `-pix_fmt bgr24 -f rawvideo`, the reference's wire format: ff-video/src/decoder.rs:53-64), the first N of the
+    file; without --frames, N synthetic frames.  The float forward of the calibration runs on the CPU (torch)."""
+    import argparse
+
+    ap = argparse.ArgumentParser(prog="python -m infur_amd.quantize", description=main.__doc__)
+    ap.add_argument("model")
+    ap.add_argument("out")
+    ap.add_argument("--frames", help="raw bgr24 clip for calibration")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--calib", type=int, default=4, help="number of calibration frames")
+    a = ap.parse_args(argv)
+    blob = _load_float_blob(a.model)
+    frames = []
+    if a.frames:
+        fb = a.width * a.height * 3
+        with open(a.frames, "rb") as f:
+            for _ in range(a.calib):
+                raw = f.read(fb)
+                if len(raw) < fb:
+                    break
+                frames.append(np.frombuffer(raw, np.uint8).reshape(a.height, a.width, 3))
+        if not frames:
+            raise SystemExit(f"{a.frames} holds no complete {a.width}x{a.height} bgr24 frame")
+    else:
+        frames = [W.synth_frame(a.height, a.width, index=i) for i in range(a.calib)]
+    q = quantise_model(blob, [normalise(fr) for fr in frames])
+    with open(a.out, "wb") as f:
+        f.write(q)
+    meta, convs, adds = W.unpack_qblob(q)
+    print(f"{a.out}: FCN-ResNet{meta['depth']}, {meta['n_convs']} QLinearConv + {meta['n_adds']} QLinearAdd, {len(q) / 1e6:.1f} MB "
+          f"(float model {len(blob) / 1e6:.1f} MB), calibrated on {len(frames)} frame(s) of {a.width}x{a.height}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

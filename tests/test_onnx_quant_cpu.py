@@ -191,3 +191,26 @@ def test_hostile_quantised_model_is_valid_reaches_the_edges_and_survives_the_onn
     for name in ("backbone.layer1.0.conv1", "backbone.layer3.2.conv2", "classifier.0"):  # (conv outputs; a conv3 tap is the residual sum)
         x = taps[name]
         assert (x == 0).any() and (x == 255).any() and len(np.unique(x)) > 150, name
+
+
+def test_quantize_cli_on_an_onnx_file_with_a_raw_clip(lib, tmp_path, blob50):
+    """python -m infur_amd.quantize: float ONNX file + raw bgr24 calibration clip -> INFURQ01, identical to the library call on the
+    same frames; the result is a structurally valid quantised blob (and loads: tests/test_gpu_quant.py uses the same quantiser)"""
+    import subprocess
+
+    from infur_amd import quantize
+
+    _, tensors = W.unpack_blob(blob50)
+    model, _ = OW.fcn_model(tensors, W.graph(50))
+    (tmp_path / "fcn.onnx").write_bytes(model)
+    frames = [W.synth_frame(72, 96, index=i) for i in range(2)]
+    (tmp_path / "clip.bgr24").write_bytes(b"".join(f.tobytes() for f in frames) + b"\x00" * 100)  # (a truncated trailing frame)
+    r = subprocess.run([sys.executable, "-m", "infur_amd.quantize", str(tmp_path / "fcn.onnx"), str(tmp_path / "q.qblob"), "--frames",
+                        str(tmp_path / "clip.bgr24"), "--width", "96", "--height", "72", "--calib", "5"], capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "calibrated on 2 frame(s)" in r.stdout, r.stdout + r.stderr
+    out = (tmp_path / "q.qblob").read_bytes()
+    assert out == quantize.quantise_model(blob50, [quantize.normalise(f) for f in frames])
+    meta, convs, adds = W.unpack_qblob(out)
+    assert meta["n_convs"] == 57 and meta["n_adds"] == 16 and all(c.w.dtype == np.int8 for c in convs)
+    assert all(c.x_zp == 0 for s, c in zip(W.graph(50), convs) if s.pad and s.role != "stem")
