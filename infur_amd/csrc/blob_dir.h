@@ -75,6 +75,7 @@ struct BlobHeader {
     int depth = 0, num_classes = 0;
     bool aux = false, input_u8 = false;
     uint32_t n_convs = 0;
+    bool resize_u8 = false;  // INFURQ01 flag bit 0: the file resizes the u8 logits before it dequantises them
 };
 
 struct BlobEntry {
@@ -183,6 +184,9 @@ inline bool qblob_parse_header(const uint8_t* hdr, size_t len, BlobHeader* h, ui
     h->aux = h32[2] != 0;
     h->n_convs = h32[3];
     h->input_u8 = false;
+    // flags (offset 28): bit 0 = Resize runs on the u8 logits, DequantizeLinear after it (QLinearConv -> Resize -> DequantizeLinear)
+    if (h32[5] > 1) { *err = blob_msg("unknown flags %#x in the quantised weight blob", h32[5]); return false; }
+    h->resize_u8 = (h32[5] & 1) != 0;
     *n_adds = h32[4];
     *graph = graph_spec(h->depth, h->num_classes, h->aux);
     if (h->n_convs != graph->size()) { *err = blob_msg("blob has %u convs, graph needs %zu", h->n_convs, graph->size()); return false; }

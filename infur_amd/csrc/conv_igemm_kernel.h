@@ -812,8 +812,9 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                         {  // f32 output: the dequantised logits (a logit conv has no residual: launch_cfg)
 #pragma clang fp contract(off)
                             float4 d;
-                            // (+ 0.0f: the centred value may be -0.0 where the operator's f32(q - zp) is +0.0)
-                            d.x = (q[0] + 0.0f) * a.q_dq; d.y = (q[1] + 0.0f) * a.q_dq; d.z = (q[2] + 0.0f) * a.q_dq; d.w = (q[3] + 0.0f) * a.q_dq;
+                            // (+ q_dq_off, 0.0f for DequantizeLinear: the centred value may be -0.0 where the operator's f32(q - zp) is +0.0)
+                            d.x = (q[0] + a.q_dq_off) * a.q_dq; d.y = (q[1] + a.q_dq_off) * a.q_dq;
+                            d.z = (q[2] + a.q_dq_off) * a.q_dq; d.w = (q[3] + a.q_dq_off) * a.q_dq;
                             if ((a.Cout & 3) == 0) {
                                 *reinterpret_cast<float4*>(out + o) = d;
                             } else {  // (21 logits per pixel: rows are not 16-byte aligned, the last group is partial)

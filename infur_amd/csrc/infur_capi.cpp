@@ -309,12 +309,25 @@ void model_free(infur_ctx* c) {
     c->d_qstem_w = nullptr;
     c->d_qstem_lut = nullptr;
     c->d_qstem_bias = nullptr;
+    c->q_resize_u8 = false;
     c->loaded = false;
     c->weight_bytes = 0;
     pool_release_all(c);
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// the post stage's view of head k (0 = out, 1 = aux): plain logits, or u8 codes to be dequantised after the interpolation
+static UpQuant head_quant(const infur_ctx* c, int k) {
+    UpQuant q;
+    if (c->quant && c->q_resize_u8) {
+        q.on = 1;
+        q.zp = c->q_head_zp[k];
+        q.scale = c->q_head_scale[k];
+    }
+    return q;
+}
+
 
 // INFUR_DTYPE_F32_SPLIT: scale every conv's GEMM weights (and Winograd-domain weights) by the power of
 // two that puts max |w| in [2^13, 2^14) -- lo = w - hi then stays a normal f16 for all weights within
@@ -928,6 +941,13 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
     c->d_qstem_w = d_qstem_w;
     c->d_qstem_lut = d_qstem_lut;
     c->d_qstem_bias = d_qstem_bias;
+    c->q_resize_u8 = bh.resize_u8;
+    for (const ConvLayer& L : c->convs)
+        if (L.role == 'c') {
+            const int k = L.name.rfind("aux_", 0) == 0 ? 1 : 0;
+            c->q_head_zp[k] = (float)L.y_zp;
+            c->q_head_scale[k] = L.y_scale;
+        }
     c->quant = true;
     c->depth = bh.depth;
     c->num_classes = bh.num_classes;
@@ -960,6 +980,10 @@ int32_t run_qconv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tens
     a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = L.cout_p;
     a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = 0;
     a.q_mult = L.d_qmult; a.q_bias = L.d_qbias; a.q_yzp = L.y_zp; a.q_dq = L.y_scale;
+    if (out_f32 && c->q_resize_u8) {  // the file resizes the codes: leave them (as floats) for the post kernels to interpolate
+        a.q_dq = 1.0f;
+        a.q_dq_off = (float)L.y_zp;
+    }
     if (res) {
         if (!add || res->c != L.cout_p || res->h != oh || res->w != ow) return fail(c, INFUR_E_SHAPE, "residual of '%s' has the wrong shape", L.name.c_str());
         volatile float ra = add->a_scale / add->c_scale, rb = add->b_scale / add->c_scale;  // f32 divisions, as MLAS' QLinearAdd
@@ -1517,11 +1541,11 @@ int32_t infur_model_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uin
         const double up_bytes = (double)c->out_low.bytes() + 4.0 * (double)K * h * w;
         if (d_out) {
             ProfScope ps(c, "out.resize", "upsample_planar", 0, up_bytes);
-            HIPCHK(c, launch_upsample_planar((const float*)c->out_low.p, c->out_low.h, c->out_low.w, K, (float*)d_out, (int)h, (int)w, c->stream));
+            HIPCHK(c, launch_upsample_planar((const float*)c->out_low.p, c->out_low.h, c->out_low.w, K, (float*)d_out, (int)h, (int)w, c->stream, head_quant(c, 0)));
         }
         if (d_aux) {
             ProfScope ps(c, "aux.resize", "upsample_planar", 0, up_bytes);
-            HIPCHK(c, launch_upsample_planar((const float*)c->aux_low.p, c->aux_low.h, c->aux_low.w, K, (float*)d_aux, (int)h, (int)w, c->stream));
+            HIPCHK(c, launch_upsample_planar((const float*)c->aux_low.p, c->aux_low.h, c->aux_low.w, K, (float*)d_aux, (int)h, (int)w, c->stream, head_quant(c, 1)));
         }
         if (n_outputs) *n_outputs = c->info.n_outputs;
         return INFUR_OK;
@@ -1601,6 +1625,13 @@ int32_t infur_model_read_lowres(infur_ctx* c, float* out_low, float* aux_low, ui
             HIPCHK(c, launch_nhwc_to_planar(src.p, src.es == 2, src.h, src.w, src.c, (float*)c->st_f32a.p, c->stream));
             HIPCHK(c, hipMemcpyAsync(dst, c->st_f32a.p, bytes, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->quant && c->q_resize_u8) {  // the device tensor holds the codes: DequantizeLinear here, (q - zp) * scale
+                const volatile float zp = c->q_head_zp[i], sc = c->q_head_scale[i];
+                for (size_t k = 0; k < t.elems(); k++) {
+                    volatile float d = dst[k] - zp;
+                    dst[k] = d * sc;
+                }
+            }
         }
         return INFUR_OK;
     } catch (const std::bad_alloc&) {
@@ -1758,7 +1789,7 @@ static int32_t frame_body(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t 
     {
         const Tensor& t = c->out_low;  // only out[0] is decoded, app.rs:116
         ProfScope ps(c, "out.resize+colorcode", "upsample_argmax_shade", 0, (double)t.bytes() + (double)need);
-        HIPCHK(c, launch_upsample_argmax_shade((const float*)t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)oh, (int)ow, c->stream));
+        HIPCHK(c, launch_upsample_argmax_shade((const float*)t.p, t.h, t.w, t.c, c->d_color_lut, (uint32_t*)d_rgba, (int)oh, (int)ow, c->stream, head_quant(c, 0)));
     }
     return INFUR_OK;
 }

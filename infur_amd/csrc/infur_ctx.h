@@ -97,6 +97,10 @@ struct infur_ctx {
     float* d_qstem_w = nullptr;
     float* d_qstem_lut = nullptr;
     int32_t* d_qstem_bias = nullptr;
+    // quantised model whose file resizes the u8 logits before DequantizeLinear: out_low / aux_low hold the CODES, the post kernels
+    // dequantise after the interpolation (kernels.h: UpQuant); [0] = out, [1] = aux
+    bool q_resize_u8 = false;
+    float q_head_zp[2] = {0.f, 0.f}, q_head_scale[2] = {1.f, 1.f};
     uint8_t* d_qlut = nullptr;  // [3][256] u8: byte value -> QuantizeLinear of the normalised value (RGB order); in d_weights
     std::vector<infur::ConvLayer> convs;
     void* d_weights = nullptr;  // single allocation holding every repacked tensor

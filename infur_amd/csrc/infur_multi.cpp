@@ -300,6 +300,11 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
     dst->d_qstem_w = (float*)rebase(root->d_qstem_w);
     dst->d_qstem_lut = (float*)rebase(root->d_qstem_lut);
     dst->d_qstem_bias = (int32_t*)rebase(root->d_qstem_bias);
+    dst->q_resize_u8 = root->q_resize_u8;
+    for (int k = 0; k < 2; k++) {
+        dst->q_head_zp[k] = root->q_head_zp[k];
+        dst->q_head_scale[k] = root->q_head_scale[k];
+    }
     dst->info = root->info;
     dst->info.n_outputs = 1 + ((root->has_aux && dst->opt.compute_aux) ? 1 : 0);
     if (dst->info.n_outputs < 2) dst->info.output_names[1][0] = 0;

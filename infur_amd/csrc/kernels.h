@@ -44,6 +44,9 @@ struct ConvArgs {
     const int32_t* q_bias = nullptr;
     int q_yzp = 0, q_bzp = 0, q_czp = 0;
     float q_ra = 0.f, q_rb = 0.f, q_dq = 0.f;
+    // f32 output: (y - q_yzp + q_dq_off) * q_dq.  DequantizeLinear: off 0, dq = y_scale; the codes themselves (models that Resize
+    // before they dequantise): off = q_yzp, dq = 1
+    float q_dq_off = 0.f;
     // two-source 1x1 GEMM (a bottleneck's conv3 and its downsample branch as ONE launch, no residual tensor):
     // out = W[:, :Cin] * in  +  W[:, Cin:] * in2(stride2)  + bias.  in2 == nullptr: ordinary convolution.
     // Requires KH = KW = 1, pad = 0, stride = 1; wt rows are Cin + Cin2 long; OH x OW = ceil(H2/stride2) x ...
@@ -174,10 +177,17 @@ hipError_t launch_bgr_to_rgba(const uint8_t* bgr, int W, int H, uint32_t* rgba, 
 hipError_t launch_nhwc_to_planar(const void* in, int f16, int H, int W, int C, float* out,
                                  hipStream_t s);
 
+// quantised models that Resize their u8 logits before DequantizeLinear (prepost.hip: up_post): the low-res tensor holds the
+// codes, every interpolated value v becomes (trunc(v) - zp) * scale.  on == 0: plain float interpolation.
+struct UpQuant {
+    int on = 0;
+    float zp = 0.f, scale = 1.f;
+};
+
 // bilinear up-sample (ONNX Resize linear / pytorch_half_pixel) of NHWC low-res logits to
 // planar [K][OH][OW] f32
 hipError_t launch_upsample_planar(const float* low, int LH, int LW, int K, float* out, int OH,
-                                  int OW, hipStream_t s);
+                                  int OW, hipStream_t s, const UpQuant uq = UpQuant());
 
 // ColorCode over planar [K][H][W] f32 -> premultiplied RGBA8.  lut: [20][256] uchar4
 hipError_t launch_colorcode_planar(const float* khw, int K, int H, int W, const uint32_t* lut,
@@ -187,6 +197,6 @@ hipError_t launch_colorcode_planar(const float* khw, int K, int H, int W, const 
 // materialises the full-resolution logits.  Bit-identical to upsample_planar -> colorcode.
 hipError_t launch_upsample_argmax_shade(const float* low, int LH, int LW, int K,
                                         const uint32_t* lut, uint32_t* rgba, int OH, int OW,
-                                        hipStream_t s);
+                                        hipStream_t s, const UpQuant uq = UpQuant());
 
 }  // namespace infur

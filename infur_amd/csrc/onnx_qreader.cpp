@@ -8,7 +8,8 @@
 //   per bottleneck: QLinearConv 1x1 -> QLinearConv 3x3 -> QLinearConv 1x1 -> QLinearAdd(com.microsoft) with the identity or
 //                   the downsample QLinearConv of the block's input; ReLUs are folded into the clamps (a Relu node left on a
 //                   tensor whose zero point is 0 is looked through)
-//   heads: QLinearConv 3x3 -> QLinearConv 1x1 -> DequantizeLinear -> Resize(linear, [pytorch_]half_pixel) -> output 0 / 1
+//   heads: QLinearConv 3x3 -> QLinearConv 1x1 -> DequantizeLinear -> Resize(linear, [pytorch_]half_pixel) -> output 0 / 1,
+//          or ... -> Resize (on the u8 codes) -> DequantizeLinear -> output (blob flag bit 0)
 // Requirements (format errors otherwise): u8 activations (zero points UINT8), INT8 or UINT8 weights whose distance from their zero
 // point (scalar or per output channel) fits 8 bits -- stored re-centred as s8 -- with one scale per tensor or per output channel, int32 bias, group 1, every shape / stride / pad / dilation as torchvision's fcn_resnet50/101.
 #include <cstdint>
@@ -344,6 +345,8 @@ int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, 
         }
     }
     // ---- heads: QLinearConv 3x3 -> QLinearConv 1x1 -> DequantizeLinear -> Resize -> graph output #k ----
+    bool resize_u8 = false;
+    int n_heads_seen = 0;
     auto head = [&](const std::string& feat, size_t out_index, const char* what) {
         const std::vector<int> u = users(feat);
         int ih = -1;
@@ -357,23 +360,40 @@ int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, 
         int k1, kd, kr;
         if (!take(ih, &h0)) return 2;
         if (!sole(h0.out, "QLinearConv", what, &k1) || !take(k1, &h1)) return 2;
-        if (!sole(h1.out, "DequantizeLinear", what, &kd)) return 2;
+        // two forms: DequantizeLinear -> Resize (the float logits are resized), or Resize -> DequantizeLinear (onnxruntime's
+        // QOperator quantiser keeps Resize on the u8 tensor: the codes are resized, then dequantised)
+        const std::vector<int> uh = users(h1.out);
+        if (uh.size() != 1 || (g.nodes[uh[0]].op != "DequantizeLinear" && g.nodes[uh[0]].op != "Resize")) {
+            err = std::string(what) + ": the logit QLinearConv must feed exactly one DequantizeLinear or Resize"; return 2;
+        }
+        const bool resize_first = g.nodes[uh[0]].op == "Resize";
+        std::string last;
+        if (resize_first) {
+            kr = uh[0];
+            if (!sole(g.nodes[kr].out.empty() ? std::string() : g.nodes[kr].out[0], "DequantizeLinear", what, &kd)) return 2;
+            last = g.nodes[kd].out.empty() ? std::string() : g.nodes[kd].out[0];
+        } else {
+            kd = uh[0];
+            const std::vector<int> ur = users(g.nodes[kd].out.empty() ? std::string() : g.nodes[kd].out[0]);
+            if (ur.size() != 1 || g.nodes[ur[0]].op != "Resize") { err = std::string(what) + ": the dequantised logits must feed exactly one Resize"; return 2; }
+            kr = ur[0];
+            last = g.nodes[kr].out.empty() ? std::string() : g.nodes[kr].out[0];
+        }
+        if (n_heads_seen++ == 0) resize_u8 = resize_first;
+        else if (resize_u8 != resize_first) { err = "the two heads order Resize and DequantizeLinear differently"; return 2; }
         const Node& dq = g.nodes[kd];
         float ds_;
         int32_t dz;
         if (dq.in.size() < 3 || !scalar_f32(g, dq.in[1], &ds_) || !scalar_u8(g, dq.in[2], &dz) || ds_ != h1.y_scale || dz != h1.y_zp) {
             err = std::string(what) + ": DequantizeLinear must use the logit conv's y_scale / y_zero_point"; return 2;
         }
-        const std::vector<int> ur = users(dq.out[0]);
-        if (ur.size() != 1 || g.nodes[ur[0]].op != "Resize") { err = std::string(what) + ": the dequantised logits must feed exactly one Resize"; return 2; }
-        kr = ur[0];
         const Node& R = g.nodes[kr];
         auto md = R.strs.find("mode");
         if (md == R.strs.end() || md->second != "linear") { err = std::string(what) + ": Resize mode must be linear"; return 2; }
         auto cm = R.strs.find("coordinate_transformation_mode");
         const std::string cmode = cm == R.strs.end() ? "half_pixel" : cm->second;
         if (cmode != "pytorch_half_pixel" && cmode != "half_pixel") { err = std::string(what) + ": Resize coordinate_transformation_mode '" + cmode + "' is not align_corners=False bilinear"; return 2; }
-        if (out_index >= outputs.size() || R.out.empty() || origin(outputs[out_index].name) != R.out[0]) { err = std::string(what) + ": its up-sampled logits are not graph output #" + std::to_string(out_index); return 2; }
+        if (out_index >= outputs.size() || last.empty() || origin(outputs[out_index].name) != last) { err = std::string(what) + ": its up-sampled logits are not graph output #" + std::to_string(out_index); return 2; }
         convs.push_back(h0); convs.push_back(h1);
         return 0;
     };
@@ -425,6 +445,7 @@ int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, 
     auto putf = [&](size_t o, float x) { memcpy(blob.data() + o, &x, 4); };
     auto put64 = [&](size_t o, uint64_t x) { memcpy(blob.data() + o, &x, 8); };
     put32(8, (uint32_t)depth); put32(12, (uint32_t)ncls); put32(16, aux ? 1u : 0u); put32(20, (uint32_t)n); put32(24, (uint32_t)na);
+    put32(28, resize_u8 ? 1u : 0u);  // flags
     for (size_t i = 0; i < n; i++) {
         const QC& c = convs[i];
         const size_t e = kBlobHdr + i * kQEntry;

@@ -239,10 +239,16 @@ __device__ __forceinline__ float bilerp(float X11, float X21, float X12, float X
     return v;
 }
 
+// Quantised models whose file resizes the u8 logits BEFORE it dequantises them (QLinearConv -> Resize -> DequantizeLinear, what
+// onnxruntime's QOperator quantiser writes when Resize is on its list): the low-res tensor then holds the u8 CODES as floats, the
+// interpolation is ONNX Runtime's UpsampleBilinear<uint8_t> -- the float expression above, static_cast to uint8_t = truncation --
+// and DequantizeLinear follows per output value: (trunc(v) - zp) * scale.  on == 0: the interpolated value itself.
+__device__ __forceinline__ float up_post(const float v, const UpQuant q) { return q.on ? (truncf(v) - q.zp) * q.scale : v; }
+
 // one thread per output pixel, loops over classes; writes planar [K][OH][OW]
 __global__ void __launch_bounds__(256)
     upsample_planar_kernel(const float* __restrict__ low, int LH, int LW, int K, float* __restrict__ out,
-                           int OH, int OW) {
+                           int OH, int OW, const UpQuant uq) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= OW || y >= OH) return;
@@ -254,7 +260,7 @@ __global__ void __launch_bounds__(256)
     const size_t plane = (size_t)OH * OW;
     float* o = out + (size_t)y * OW + x;
     for (int k = 0; k < K; k++)
-        o[k * plane] = bilerp(p11[k], p21[k], p12[k], p22[k], tx.d1, tx.d2, ty.d1, ty.d2);
+        o[k * plane] = up_post(bilerp(p11[k], p21[k], p12[k], p22[k], tx.d1, tx.d2, ty.d1, ty.d2), uq);
 }
 
 
@@ -392,7 +398,7 @@ __device__ __forceinline__ f32x2 bilerp2(f32x2 X11, f32x2 X21, f32x2 X12, f32x2 
 template <int NQ>
 __global__ void __launch_bounds__(256)
     upsample_argmax_shade_lds_kernel(const float* __restrict__ low, int LH, int LW, int K,
-                                     const uint32_t* __restrict__ lut, uint32_t* __restrict__ rgba, int OH, int OW) {
+                                     const uint32_t* __restrict__ lut, uint32_t* __restrict__ rgba, int OH, int OW, const UpQuant uq) {
     extern __shared__ __attribute__((aligned(16))) float up_smem[];
     const UpTile t = stage_lowres_tile(low, LH, LW, K, OH, OW, up_smem);
     const int xl = threadIdx.x & 63;
@@ -423,7 +429,7 @@ __global__ void __launch_bounds__(256)
                                      f32x2{v22[q].x, v22[q].y}, w11, w21, w12, w22);
             const f32x2 hi = bilerp2(f32x2{v11[q].z, v11[q].w}, f32x2{v21[q].z, v21[q].w}, f32x2{v12[q].z, v12[q].w},
                                      f32x2{v22[q].z, v22[q].w}, w11, w21, w12, w22);
-            const float c[4] = {lo.x, lo.y, hi.x, hi.y};
+            const float c[4] = {up_post(lo.x, uq), up_post(lo.y, uq), up_post(hi.x, uq), up_post(hi.y, uq)};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 if (c[e] > c_max) {
@@ -438,7 +444,7 @@ __global__ void __launch_bounds__(256)
 
 template <int NQ>
 __global__ void __launch_bounds__(256)
-    upsample_planar_lds_kernel(const float* __restrict__ low, int LH, int LW, int K, float* __restrict__ out, int OH, int OW) {
+    upsample_planar_lds_kernel(const float* __restrict__ low, int LH, int LW, int K, float* __restrict__ out, int OH, int OW, const UpQuant uq) {
     extern __shared__ __attribute__((aligned(16))) float up_smem[];
     const UpTile t = stage_lowres_tile(low, LH, LW, K, OH, OW, up_smem);
     const int xl = threadIdx.x & 63;
@@ -469,7 +475,7 @@ __global__ void __launch_bounds__(256)
                                      f32x2{v22[q].x, v22[q].y}, w11, w21, w12, w22);
             const f32x2 hi = bilerp2(f32x2{v11[q].z, v11[q].w}, f32x2{v21[q].z, v21[q].w}, f32x2{v12[q].z, v12[q].w},
                                      f32x2{v22[q].z, v22[q].w}, w11, w21, w12, w22);
-            const float c[4] = {lo.x, lo.y, hi.x, hi.y};
+            const float c[4] = {up_post(lo.x, uq), up_post(lo.y, uq), up_post(hi.x, uq), up_post(hi.y, uq)};
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 if (4 * q + e < K) o[(size_t)(4 * q + e) * plane] = c[e];
@@ -499,14 +505,14 @@ static size_t up_tile_lds_bytes(int LH, int LW, int K, int OH, int OW) {
 }
 
 hipError_t launch_upsample_planar(const float* low, int LH, int LW, int K, float* out, int OH,
-                                  int OW, hipStream_t s) {
+                                  int OW, hipStream_t s, const UpQuant uq) {
     const size_t lds = up_tile_lds_bytes(LH, LW, K, OH, OW);
     if (lds) {
         dim3 grid((OW + UP_TW - 1) / UP_TW, (OH + UP_TH - 1) / UP_TH);
-        UP_DISPATCH_NQ(upsample_planar_lds_kernel, K, grid, dim3(256), lds, s, low, LH, LW, K, out, OH, OW)
+        UP_DISPATCH_NQ(upsample_planar_lds_kernel, K, grid, dim3(256), lds, s, low, LH, LW, K, out, OH, OW, uq)
     } else {
         dim3 grid((OW + 63) / 64, (OH + 3) / 4);
-        hipLaunchKernelGGL(upsample_planar_kernel, grid, dim3(256), 0, s, low, LH, LW, K, out, OH, OW);
+        hipLaunchKernelGGL(upsample_planar_kernel, grid, dim3(256), 0, s, low, LH, LW, K, out, OH, OW, uq);
     }
     return hipGetLastError();
 }
@@ -514,7 +520,7 @@ hipError_t launch_upsample_planar(const float* low, int LH, int LW, int K, float
 // fused up-sample + argmax + shade, scalar form: same expression tree as upsample_planar -> colorcode
 __global__ void __launch_bounds__(256)
     upsample_argmax_shade_kernel(const float* __restrict__ low, int LH, int LW, int K,
-                                 const uint32_t* __restrict__ lut, uint32_t* __restrict__ rgba, int OH, int OW) {
+                                 const uint32_t* __restrict__ lut, uint32_t* __restrict__ rgba, int OH, int OW, const UpQuant uq) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= OW || y >= OH) return;
@@ -526,7 +532,7 @@ __global__ void __launch_bounds__(256)
     int k_max = 0;
     float c_max = 0.0f;
     for (int k = 0; k < K; k++) {
-        const float c = bilerp(p11[k], p21[k], p12[k], p22[k], tx.d1, tx.d2, ty.d1, ty.d2);
+        const float c = up_post(bilerp(p11[k], p21[k], p12[k], p22[k], tx.d1, tx.d2, ty.d1, ty.d2), uq);
         if (c > c_max) {
             k_max = k;
             c_max = c;
@@ -536,14 +542,14 @@ __global__ void __launch_bounds__(256)
 }
 
 hipError_t launch_upsample_argmax_shade(const float* low, int LH, int LW, int K, const uint32_t* lut,
-                                        uint32_t* rgba, int OH, int OW, hipStream_t s) {
+                                        uint32_t* rgba, int OH, int OW, hipStream_t s, const UpQuant uq) {
     const size_t lds = up_tile_lds_bytes(LH, LW, K, OH, OW);
     if (lds) {
         dim3 grid((OW + UP_TW - 1) / UP_TW, (OH + UP_TH - 1) / UP_TH);
-        UP_DISPATCH_NQ(upsample_argmax_shade_lds_kernel, K, grid, dim3(256), lds, s, low, LH, LW, K, lut, rgba, OH, OW)
+        UP_DISPATCH_NQ(upsample_argmax_shade_lds_kernel, K, grid, dim3(256), lds, s, low, LH, LW, K, lut, rgba, OH, OW, uq)
     } else {
         dim3 grid((OW + 63) / 64, (OH + 3) / 4);
-        hipLaunchKernelGGL(upsample_argmax_shade_kernel, grid, dim3(256), 0, s, low, LH, LW, K, lut, rgba, OH, OW);
+        hipLaunchKernelGGL(upsample_argmax_shade_kernel, grid, dim3(256), 0, s, low, LH, LW, K, lut, rgba, OH, OW, uq);
     }
     return hipGetLastError();
 }

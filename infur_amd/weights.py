@@ -278,7 +278,8 @@ def unpack_blob(blob: bytes):
 # carries exactly what those nodes carry (little endian):
 #
 #     0   char[8]  magic "INFURQ01"
-#     8   u32 depth, u32 num_classes, u32 has_aux, u32 n_convs, u32 n_adds, u32 reserved
+#     8   u32 depth, u32 num_classes, u32 has_aux, u32 n_convs, u32 n_adds, u32 flags (bit 0: the file's Resize runs on the u8
+#         logits and DequantizeLinear follows it -- QLinearConv -> Resize -> DequantizeLinear -- instead of the other way round)
 #     32  n_convs x 96-byte entries: char name[40]; u32 cout, cin, kh, kw; f32 x_scale; i32 x_zp; f32 y_scale; i32 y_zp;
 #                                    u64 w_off (s8 OIHW); u64 ws_off (f32 [cout] weight scales); u64 b_off (i32 [cout])
 #     ..  n_adds x 24-byte entries:  f32 a_scale; i32 a_zp; f32 b_scale; i32 b_zp; f32 c_scale; i32 c_zp
@@ -317,7 +318,7 @@ class QAdd:
     c_zp: int
 
 
-def pack_qblob(convs: List[QConv], adds: List[QAdd], depth: int, num_classes: int, aux: bool) -> bytes:
+def pack_qblob(convs: List[QConv], adds: List[QAdd], depth: int, num_classes: int, aux: bool, resize_u8: bool = False) -> bytes:
     n, na = len(convs), len(adds)
     off = (HDR + n * QENTRY + na * QADD + 63) & ~63
     table, chunks = bytearray(), []
@@ -338,7 +339,7 @@ def pack_qblob(convs: List[QConv], adds: List[QAdd], depth: int, num_classes: in
     for a in adds:
         table += struct.pack("<fififi", np.float32(a.a_scale), int(a.a_zp), np.float32(a.b_scale), int(a.b_zp), np.float32(a.c_scale), int(a.c_zp))
     buf = bytearray(off)
-    buf[0:HDR] = QMAGIC + struct.pack("<6I", depth, num_classes, 1 if aux else 0, n, na, 0)
+    buf[0:HDR] = QMAGIC + struct.pack("<6I", depth, num_classes, 1 if aux else 0, n, na, 1 if resize_u8 else 0)
     buf[HDR:HDR + len(table)] = table
     for o, arr in chunks:
         buf[o:o + arr.nbytes] = arr.tobytes()
@@ -348,7 +349,7 @@ def pack_qblob(convs: List[QConv], adds: List[QAdd], depth: int, num_classes: in
 def unpack_qblob(blob: bytes):
     if len(blob) < HDR or blob[:8] != QMAGIC:
         raise ValueError("not an INFURQ01 quantised weight blob")
-    depth, ncls, aux, n, na, _ = struct.unpack_from("<6I", blob, 8)
+    depth, ncls, aux, n, na, flags = struct.unpack_from("<6I", blob, 8)
     convs, adds = [], []
     for i in range(n):
         e = HDR + i * QENTRY
@@ -358,4 +359,7 @@ def unpack_qblob(blob: bytes):
                            np.frombuffer(blob, np.float32, cout, ws_off), np.frombuffer(blob, np.int32, cout, b_off), xs, xz, ys, yz))
     for i in range(na):
         adds.append(QAdd(*struct.unpack_from("<fififi", blob, HDR + n * QENTRY + i * QADD)))
-    return {"depth": depth, "num_classes": ncls, "aux": bool(aux), "n_convs": n, "n_adds": na}, convs, adds
+    meta = {"depth": depth, "num_classes": ncls, "aux": bool(aux), "n_convs": n, "n_adds": na}
+    if flags & 1:
+        meta["resize_u8"] = True
+    return meta, convs, adds

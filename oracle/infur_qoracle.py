@@ -10,7 +10,9 @@ com.microsoft definitions:
     QLinearConv       acc = sum (x - x_zp) * (w - w_zp) + bias  (int32, exact)          (onnx: QLinearConv-10)
                       y = sat_u8(round(float(acc) * (x_s * w_s[o] / y_s)) + y_zp)
     QLinearAdd        c = sat_u8(round((a - a_zp) * (a_s / c_s) + (b - b_zp) * (b_s / c_s)) + c_zp)   (com.microsoft)
-    MaxPool on u8, DequantizeLinear x = (q - zp) * s, Resize(linear, pytorch_half_pixel) on the dequantised logits
+    MaxPool on u8, DequantizeLinear x = (q - zp) * s, Resize(linear, pytorch_half_pixel) on the dequantised logits -- or, for files that
+    keep Resize on the u8 tensor (QLinearConv -> Resize -> DequantizeLinear): the float interpolation of the codes truncated to u8
+    (onnxruntime's UpsampleBilinear<uint8_t>: static_cast), then DequantizeLinear
 
 with round = round-half-to-even and every floating-point step ONE IEEE f32 operation in the order written (the order
 ONNX Runtime's MLAS requantisation uses: int32 -> f32, one multiply, nearbyint, + zero point, saturate).  The integer
@@ -124,6 +126,30 @@ def qforward(blob: bytes, chw: np.ndarray, taps: Optional[Dict[str, np.ndarray]]
     out = head(x)
     aux = head(l3) if meta["aux"] else None
     return out, aux
+
+
+def qforward_codes(blob: bytes, chw: np.ndarray):
+    """models whose file resizes the u8 logits before DequantizeLinear (INFURQ01 flag bit 0): the heads' u8 codes as f32
+    [K,lh,lw], and each head's (zero point, scale)"""
+    meta, convs, _ = W.unpack_qblob(blob)
+    lo, aux = qforward(blob, chw)
+    heads = [c for c in convs if c.name.endswith("classifier.4")]
+    out = []
+    for logits, c in zip((lo, aux), heads):
+        if logits is None:
+            out.append(None)
+            continue
+        codes = np.rint(logits.astype(np.float64) / np.float64(f32(c.y_scale))) + c.y_zp  # exact: logits = (q - zp) * scale in f32
+        assert ((codes >= 0) & (codes <= 255)).all() and (((codes - c.y_zp).astype(f32) * f32(c.y_scale)) == logits).all()
+        out.append(codes.astype(f32))
+    return out, [(int(c.y_zp), float(c.y_scale)) for c in heads]
+
+
+def resize_u8_then_dequantise(codes: np.ndarray, zp: int, scale: float, h: int, w: int, upsample) -> np.ndarray:
+    """ONNX Runtime's UpsampleBilinear<uint8_t> -- the float interpolation (`upsample`: the oracle's bilinear, the same expression
+    as for float tensors), static_cast to uint8_t = truncation -- followed by DequantizeLinear"""
+    up = np.trunc(upsample(codes, h, w)).astype(f32)
+    return ((up - f32(zp)) * f32(scale)).astype(f32)
 
 
 def synth_qblob(depth: int = 50) -> bytes:

@@ -279,3 +279,38 @@ def test_conv1x1_q8_forced_on_every_1x1_is_bit_exact():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
                         "every_layer or hostile or resnet101 or group_stream"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("size", [(96, 128), (135, 241)])
+def test_models_that_resize_before_they_dequantise(qblob, oracle, size, tmp_path):
+    """QLinearConv -> Resize (u8) -> DequantizeLinear (blob flag bit 0; the order onnxruntime's QOperator quantiser writes when Resize
+    is on its list): the heads' codes are interpolated in float, truncated to u8 as UpsampleBilinear<uint8_t> does, then dequantised --
+    full-resolution outputs, mask and the low-res read-back against the oracle's restatement, through the blob and the ONNX file"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import onnx_writer as OW
+    from oracle import infur_qoracle as Q
+
+    h, w = size
+    meta, convs, adds = W.unpack_qblob(qblob)
+    blob_r = W.pack_qblob(convs, adds, 50, 21, True, resize_u8=True)
+    p = tmp_path / "int8_resize_u8.onnx"
+    p.write_bytes(OW.fcn_qmodel(convs, adds, W.graph(50), resize_u8=True))
+    fr = W.synth_frame(h, w, index=3)
+    (codes, aux_codes), params = Q.qforward_codes(qblob, oracle.pack_normalize(fr))
+    ref = [Q.resize_u8_then_dequantise(cd, zp, sc, h, w, oracle.upsample_bilinear) for cd, (zp, sc) in zip((codes, aux_codes), params)]
+    plain = oracle.upsample_bilinear(Q.qforward(qblob, oracle.pack_normalize(fr))[0], h, w)
+    assert (ref[0] != plain).mean() > 0.2  # the two orders really are different functions
+    for cmd in (ModelCmd.LoadBlob(blob_r), ModelCmd.Load(str(p))):
+        with Context(device=0) as c:
+            m = Model(c).control(cmd)
+            out = []
+            m.advance(fr, out)
+            assert (out[0].view(np.uint32) == ref[0].view(np.uint32)).all() and (out[1].view(np.uint32) == ref[1].view(np.uint32)).all()
+            rgba, _ = FramePath(c).advance(fr, 1.0)
+            assert (rgba == oracle.colorcode(ref[0])).all()
+            lo, la = m.lowres()  # read back as logits: DequantizeLinear of the codes
+            want = Q.qforward(qblob, oracle.pack_normalize(fr))
+            assert (lo.view(np.uint32) == want[0].view(np.uint32)).all() and (la.view(np.uint32) == want[1].view(np.uint32)).all()

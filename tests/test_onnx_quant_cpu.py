@@ -214,3 +214,29 @@ def test_quantize_cli_on_an_onnx_file_with_a_raw_clip(lib, tmp_path, blob50):
     meta, convs, adds = W.unpack_qblob(out)
     assert meta["n_convs"] == 57 and meta["n_adds"] == 16 and all(c.w.dtype == np.int8 for c in convs)
     assert all(c.x_zp == 0 for s, c in zip(W.graph(50), convs) if s.pad and s.role != "stem")
+
+
+def test_resize_before_dequantize_sets_the_blob_flag(lib, q50):
+    """QLinearConv -> Resize (u8) -> DequantizeLinear, what onnxruntime's QOperator quantiser writes with Resize on its list: same
+    tensors, flag bit 0 of the blob; the two heads must agree on the order"""
+    specs, convs, adds = q50
+    rc, err, out = convert(lib, OW.fcn_qmodel(convs, adds, specs, resize_u8=True, per_tensor_scale=("backbone.layer2.1.conv2", "classifier.4")))
+    assert rc == 0, err
+    assert out == W.pack_qblob(convs, adds, 50, 21, True, resize_u8=True)
+    assert W.unpack_qblob(out)[0].get("resize_u8") is True
+    assert W.unpack_qblob(W.pack_qblob(convs, adds, 50, 21, True))[0].get("resize_u8") is None
+    rc, err, _ = convert(lib, OW.fcn_qmodel(convs, adds, specs, resize_u8=(True, False)))
+    assert rc != 0 and "order Resize and DequantizeLinear differently" in err, err
+
+
+def test_u8_resize_arithmetic_of_the_oracle():
+    """interpolate the codes in float, truncate (static_cast<uint8_t>), dequantise"""
+    from oracle import infur_qoracle as Q
+
+    codes = np.array([[[10.0, 20.0], [30.0, 41.0]]], np.float32)
+
+    def up(x, h, w):  # a stand-in interpolation: the four values averaged
+        return np.full((x.shape[0], h, w), x.mean(), np.float32)
+
+    got = Q.resize_u8_then_dequantise(codes, 5, 0.5, 2, 2, up)
+    assert got.shape == (1, 2, 2) and (got == np.float32((25 - 5) * 0.5)).all()  # 25.25 -> 25
