@@ -296,7 +296,7 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
 
 def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(), relu_after=(), w_zp=0, w_dtype=3, swap_add=None,
                input_type=1, coord_mode="pytorch_half_pixel", drop_last=0, stem_scale=None, dq_scale=None, no_bias=(), vector_wzp=False,
-               pad_zp_conv=None, extra_qconv=False, shift_weights=True, resize_u8=False):
+               pad_zp_conv=None, extra_qconv=False, shift_weights=True, resize_u8=False, resize_subgraph=False):
     """The QOperator int8 form of the same network, as ONNX Runtime's static quantisation writes it (the shape of
     `fcn-resnet50-12-int8.onnx`, the file the reference's tests load: predict_onnx.rs:357-381):
     QuantizeLinear -> QLinearConv (ReLU folded) -> MaxPool (u8) -> bottlenecks (QLinearConv x3 [+ downsample], com.microsoft
@@ -406,18 +406,45 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
             return
         c = by_name[prefix + ".4"][1]
         dq = fresh("dq")
-        inits.append(tensor(out_name + ".scales", np.array([1, 1, 8, 8], np.float32)))
         attrs = [attr_str("mode", "linear")]
         if coord_mode is not None:
             attrs.append(attr_str("coordinate_transformation_mode", coord_mode))
         dq_in = [scalar_f(prefix + ".dq.scale", dq_scale or c.y_scale), scalar_u8(prefix + ".dq.zp", c.y_zp)]
         rs = resize_u8 if isinstance(resize_u8, bool) else resize_u8[0 if prefix == "classifier" else 1]
+
+        def resize_inputs(x):
+            if not resize_subgraph:
+                inits.append(tensor(out_name + ".scales", np.array([1, 1, 8, 8], np.float32)))
+                return [x, "", out_name + ".scales"]
+            # the exporter's dynamic-size form, kept in float by the quantiser: sizes = concat(shape(x)[:2], shape(input)[2:])
+            shp, sl = fresh("shape"), fresh("slice")
+            emit("Shape", [x], [shp])
+            for nm, v in ((sl + "_s", [0]), (sl + "_e", [2]), (sl + "_a", [0])):
+                emit("Constant", [], [nm], [attr_tensor("value", tensor_i64(nm, v))])
+            emit("Slice", [shp, sl + "_s", sl + "_e", sl + "_a"], [sl])
+            dims = []
+            for ax in (2, 3):
+                ishp, gi, gg, u = fresh("ishape"), fresh("gidx"), fresh("gather"), fresh("unsq")
+                emit("Shape", ["input"], [ishp])
+                emit("Constant", [], [gi], [attr_tensor("value", tensor_i64(gi, ax))])
+                emit("Gather", [ishp, gi], [gg], [attr_int("axis", 0)])
+                emit("Unsqueeze", [gg], [u], [attr_ints("axes", [0])])
+                dims.append(u)
+            cc, cast, sizes = fresh("concat"), fresh("cast"), fresh("sizes")
+            emit("Concat", dims, [cc], [attr_int("axis", 0)])
+            emit("Cast", [cc], [cast], [attr_int("to", 7)])
+            emit("Concat", [sl, cast], [sizes], [attr_int("axis", 0)])
+            roi, scales = fresh("roi"), fresh("scales")
+            emit("Constant", [], [roi], [attr_tensor("value", tensor(roi, np.zeros((0,), np.float32)))])
+            emit("Constant", [], [scales], [attr_tensor("value", tensor(scales, np.zeros((0,), np.float32)))])
+            return [x, roi, scales, sizes]
+
         if rs:  # onnxruntime's QOperator quantiser: Resize stays on the u8 tensor, DequantizeLinear comes last
-            emit("Resize", [lo, "", out_name + ".scales"], [dq], attrs)
+            emit("Resize", resize_inputs(lo), [dq], attrs)
             emit("DequantizeLinear", [dq] + dq_in, [out_name])
         else:
             emit("DequantizeLinear", [lo] + dq_in, [dq])
-            emit("Resize", [dq, "", out_name + ".scales"], [out_name], attrs)
+            emit("Resize", resize_inputs(dq), [out_name], attrs)
 
     head("classifier", x, "out")
     head("aux_classifier", l3, "aux")

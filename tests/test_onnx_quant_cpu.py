@@ -240,3 +240,15 @@ def test_u8_resize_arithmetic_of_the_oracle():
 
     got = Q.resize_u8_then_dequantise(codes, 5, 0.5, 2, 2, up)
     assert got.shape == (1, 2, 2) and (got == np.float32((25 - 5) * 0.5)).all()  # 25.25 -> 25
+
+
+@pytest.mark.parametrize("resize_u8", [False, True])
+def test_dynamic_size_resize_subgraph_is_looked_through(lib, q50, resize_u8):
+    """the exporter's Shape -> Gather -> Unsqueeze -> Concat arithmetic around Resize stays in float in a quantised file: the
+    Shape readers of the image input and of the logits are not data consumers"""
+    specs, convs, adds = q50
+    model = OW.fcn_qmodel(convs, adds, specs, resize_subgraph=True, resize_u8=resize_u8, order="shuffled", rng=np.random.default_rng(4),
+                          per_tensor_scale=("backbone.layer2.1.conv2", "classifier.4"))
+    rc, err, out = convert(lib, model)
+    assert rc == 0, err
+    assert out == W.pack_qblob(convs, adds, 50, 21, True, resize_u8=resize_u8)
