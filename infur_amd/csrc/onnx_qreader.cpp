@@ -34,6 +34,7 @@ struct QGraph {
     std::vector<Node> nodes;
     std::map<std::string, std::vector<int>> consumers;
     std::map<std::string, int> producer;
+    std::map<std::string, int> graph_outputs;
 };
 
 bool scalar_f32(const QGraph& g, const std::string& name, float* v) {
@@ -160,9 +161,159 @@ bool read_qconv(const QGraph& g, int ni, QC* q, std::string* err) {
     return true;
 }
 
+// ---- QDQ format -> the QOperator node list the walker below understands ----
+// onnxruntime >= 1.11 writes statically quantised models in QDQ format by default: every tensor is DequantizeLinear(QuantizeLinear(.)),
+// the operators stay float -- and ONNX Runtime fuses each DQ -> op -> [Relu ->] Q group back into the QLinear operator when the
+// session is created (the reference asks for ORT_ENABLE_EXTENDED, predict_onnx.rs:291), so the arithmetic that runs is the QOperator
+// arithmetic.  This pass does the same fusion on the parsed graph, in place:
+//   DQ(x), DQ(w) [, DQ(b)] -> Conv -> [Relu ->] Q        =>  QLinearConv(x_q, ..., w_q, ..., y_scale, y_zp, b_q) -> y_q
+//   DQ(a), DQ(b) -> Add -> [Relu ->] Q                    =>  QLinearAdd(a_q, ..., b_q, ..., c_scale, c_zp) -> c_q
+//   DQ(x) -> MaxPool -> Q  (same parameters)              =>  MaxPool(x_q) -> y_q
+//   DQ(x) -> Resize -> Q (same parameters) -> DQ -> out   =>  Resize(x_q) -> DQ -> out          (else DQ -> Resize stays as it is)
+// A Relu between the operator and its Q is the clamp only when Q's zero point is 0: anything else is a format error.
+// DequantizeLinear nodes nobody reads afterwards are dropped.  Returns false with *err set on a graph it cannot fuse.
+bool qdq_to_qoperator(QGraph& g, std::string* err) {
+    struct DQ { std::string q, scale, zp; };
+    std::map<std::string, DQ> dq_of;  // float tensor -> what it dequantises
+    for (const Node& n : g.nodes)
+        if (n.op == "DequantizeLinear" && n.in.size() >= 2 && !n.out.empty()) dq_of[n.out[0]] = DQ{n.in[0], n.in[1], n.in.size() > 2 ? n.in[2] : std::string()};
+    std::map<std::string, std::vector<int>> cons;
+    for (size_t i = 0; i < g.nodes.size(); i++)
+        for (auto& in : g.nodes[i].in)
+            if (!in.empty()) cons[in].push_back((int)i);
+    std::vector<char> dead(g.nodes.size(), 0);
+    // the QuantizeLinear that ends an operator's group: op -> [Relu ->] Q, every link the only DATA consumer of the one before
+    // (Shape readers -- the Resize size arithmetic -- do not count)
+    auto data_cons = [&](const std::string& t) {
+        std::vector<int> u;
+        auto it = cons.find(t);
+        if (it != cons.end())
+            for (int k : it->second)
+                if (g.nodes[k].op != "Shape") u.push_back(k);
+        return u;
+    };
+    auto closing_q = [&](const Node& op, int* relu, int* qn) {
+        *relu = -1;
+        *qn = -1;
+        if (op.out.empty()) return false;
+        std::vector<int> u = data_cons(op.out[0]);
+        if (u.size() == 1 && g.nodes[u[0]].op == "Relu" && !g.nodes[u[0]].out.empty()) {
+            *relu = u[0];
+            u = data_cons(g.nodes[u[0]].out[0]);
+        }
+        if (u.size() != 1 || g.nodes[u[0]].op != "QuantizeLinear" || g.nodes[u[0]].in.size() < 3 || g.nodes[u[0]].out.empty()) return false;
+        *qn = u[0];
+        return true;
+    };
+    auto same_scalar = [&](const std::string& a, const std::string& b, bool is_float) {
+        if (a == b) return true;
+        if (is_float) {
+            float x, y;
+            return scalar_f32(g, a, &x) && scalar_f32(g, b, &y) && x == y;
+        }
+        int32_t x, y;
+        return scalar_u8(g, a, &x) && scalar_u8(g, b, &y) && x == y;
+    };
+    for (size_t i = 0; i < g.nodes.size(); i++) {
+        Node& n = g.nodes[i];
+        if (dead[i]) continue;
+        int relu, qn;
+        if (n.op == "Conv") {
+            if (n.in.size() < 2 || !dq_of.count(n.in[0]) || !dq_of.count(n.in[1])) { *err = "QDQ model: a Conv whose input or weight is not a DequantizeLinear output"; return false; }
+            if (!closing_q(n, &relu, &qn)) { *err = "QDQ model: a Conv (+ Relu) that does not end in exactly one QuantizeLinear"; return false; }
+            const DQ x = dq_of[n.in[0]], w = dq_of[n.in[1]];
+            if (!g.inits.count(w.q)) { *err = "QDQ model: a Conv weight that is not a quantised initializer"; return false; }
+            std::string bq;
+            if (n.in.size() > 2 && !n.in[2].empty()) {
+                if (!dq_of.count(n.in[2]) || !g.inits.count(dq_of[n.in[2]].q)) { *err = "QDQ model: a Conv bias that is not DequantizeLinear of an INT32 initializer"; return false; }
+                bq = dq_of[n.in[2]].q;
+            }
+            const Node& Q = g.nodes[qn];
+            if (relu >= 0) {
+                int32_t z;
+                if (!scalar_u8(g, Q.in[2], &z) || z != 0) { *err = "QDQ model: a Relu in front of a QuantizeLinear whose zero point is not 0"; return false; }
+                dead[relu] = 1;
+            }
+            if (w.zp.empty()) { *err = "QDQ model: a weight DequantizeLinear without a zero point input"; return false; }
+            Node f;
+            f.op = "QLinearConv";
+            f.in = {x.q, x.scale, x.zp, w.q, w.scale, w.zp, Q.in[1], Q.in[2]};
+            if (!bq.empty()) f.in.push_back(bq);
+            f.out = {Q.out[0]};
+            f.ints = n.ints;
+            f.strs = n.strs;
+            dead[qn] = 1;
+            n = std::move(f);
+        } else if (n.op == "Add") {
+            if (n.in.size() != 2 || !dq_of.count(n.in[0]) || !dq_of.count(n.in[1])) { *err = "QDQ model: an Add whose inputs are not DequantizeLinear outputs"; return false; }
+            if (!closing_q(n, &relu, &qn)) { *err = "QDQ model: an Add (+ Relu) that does not end in exactly one QuantizeLinear"; return false; }
+            const DQ a = dq_of[n.in[0]], b = dq_of[n.in[1]];
+            const Node& Q = g.nodes[qn];
+            if (relu >= 0) {
+                int32_t z;
+                if (!scalar_u8(g, Q.in[2], &z) || z != 0) { *err = "QDQ model: a Relu in front of a QuantizeLinear whose zero point is not 0"; return false; }
+                dead[relu] = 1;
+            }
+            Node f;
+            f.op = "QLinearAdd";
+            f.in = {a.q, a.scale, a.zp, b.q, b.scale, b.zp, Q.in[1], Q.in[2]};
+            f.out = {Q.out[0]};
+            dead[qn] = 1;
+            n = std::move(f);
+        } else if (n.op == "MaxPool") {
+            if (n.in.empty() || !dq_of.count(n.in[0])) continue;  // (a float MaxPool is a format error of the walker)
+            if (!closing_q(n, &relu, &qn) || relu >= 0) { *err = "QDQ model: a MaxPool that does not end in exactly one QuantizeLinear"; return false; }
+            const DQ x = dq_of[n.in[0]];
+            const Node& Q = g.nodes[qn];
+            if (!same_scalar(x.scale, Q.in[1], true) || !same_scalar(x.zp, Q.in[2], false)) { *err = "QDQ model: MaxPool is requantised with different parameters"; return false; }
+            n.in[0] = x.q;
+            n.out[0] = Q.out[0];
+            dead[qn] = 1;
+        } else if (n.op == "Resize") {
+            if (n.in.empty() || !dq_of.count(n.in[0]) || n.out.empty()) continue;
+            const std::vector<int> u = data_cons(n.out[0]);
+            if (u.size() == 1 && g.nodes[u[0]].op == "QuantizeLinear" && g.nodes[u[0]].in.size() >= 3 && !g.nodes[u[0]].out.empty()) {
+                const DQ x = dq_of[n.in[0]];
+                const Node& Q = g.nodes[u[0]];
+                if (!same_scalar(x.scale, Q.in[1], true) || !same_scalar(x.zp, Q.in[2], false)) { *err = "QDQ model: Resize is requantised with different parameters"; return false; }
+                n.in[0] = x.q;  // Resize on the u8 tensor; the DequantizeLinear behind Q stays and now follows the Resize
+                n.out[0] = Q.out[0];
+                dead[u[0]] = 1;
+            }
+        }
+    }
+    // drop the fused nodes, then every DequantizeLinear whose output nobody reads any more
+    std::vector<Node> kept;
+    for (size_t i = 0; i < g.nodes.size(); i++)
+        if (!dead[i]) kept.push_back(std::move(g.nodes[i]));
+    // (a DequantizeLinear that only Shape nodes still read -- the Resize size arithmetic -- goes too: the quantised tensor has the
+    //  same shape, the Shape nodes are re-pointed at it)
+    for (int pass = 0; pass < 2; pass++) {
+        std::map<std::string, int> uses;
+        for (const Node& n : kept)
+            if (n.op != "Shape")
+                for (auto& in : n.in) uses[in]++;
+        std::map<std::string, std::string> gone;  // float tensor -> the quantised tensor behind it
+        std::vector<Node> k2;
+        for (Node& n : kept) {
+            if (n.op == "DequantizeLinear" && !n.out.empty() && !n.in.empty() && !uses.count(n.out[0]) && !g.graph_outputs.count(n.out[0])) {
+                gone[n.out[0]] = n.in[0];
+                continue;
+            }
+            k2.push_back(std::move(n));
+        }
+        for (Node& n : k2)
+            if (n.op == "Shape" && !n.in.empty() && gone.count(n.in[0])) n.in[0] = gone[n.in[0]];
+        kept.swap(k2);
+    }
+    g.nodes.swap(kept);
+    return true;
+}
+
 }  // namespace
 
-// 0 ok; 1 malformed; 2 parsed but not a model this path can run.  `data` is a ModelProto whose graph contains QLinearConv.
+// 0 ok; 1 malformed; 2 parsed but not a model this path can run.  `data` is a ModelProto whose graph contains QLinearConv, or a
+// QDQ-format graph (float Conv nodes fed by DequantizeLinear).
 int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, OnnxInfo& info, std::string& err) {
     PB m(data, len);
     uint32_t f, wt; uint64_t v; const uint8_t* s; size_t l;
@@ -199,6 +350,16 @@ int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, 
     info.input_u8 = false;
     info.input_nhwc = false;
     for (auto& o : outputs) info.output_names.push_back(o.name);
+    for (auto& o : outputs) g.graph_outputs[o.name] = 1;
+    {
+        bool qdq = false, qop = false;
+        for (const Node& n : g.nodes) {
+            qop |= n.op == "QLinearConv";
+            qdq |= n.op == "Conv";
+        }
+        if (qdq && qop) { err = "the model mixes float Conv and QLinearConv nodes"; return 2; }
+        if (qdq && !qdq_to_qoperator(g, &err)) return 2;
+    }
 
     for (size_t i = 0; i < g.nodes.size(); i++) {
         for (auto& o : g.nodes[i].out) g.producer[o] = (int)i;

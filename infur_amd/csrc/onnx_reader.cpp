@@ -190,6 +190,13 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
         return true;
     };
 
+    {   // QDQ format: float Conv nodes whose input is a DequantizeLinear output (onnx_qreader.cpp fuses the groups)
+        std::map<std::string, char> dq_out;
+        for (auto& n : nodes)
+            if (n.op == "DequantizeLinear" && !n.out.empty()) dq_out[n.out[0]] = 1;
+        for (auto& n : nodes)
+            if (n.op == "Conv" && !n.in.empty() && dq_out.count(n.in[0])) return onnx_q_to_blob(data, len, blob, info = OnnxInfo(), err);
+    }
     for (auto& n : nodes) {
         // the QOperator int8 form (fcn-resnet50-12-int8.onnx, the file the reference's tests load) has its own reader and blob
         if (n.op == "QLinearConv") return onnx_q_to_blob(data, len, blob, info = OnnxInfo(), err);

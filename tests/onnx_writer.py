@@ -296,7 +296,7 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
 
 def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(), relu_after=(), w_zp=0, w_dtype=3, swap_add=None,
                input_type=1, coord_mode="pytorch_half_pixel", drop_last=0, stem_scale=None, dq_scale=None, no_bias=(), vector_wzp=False,
-               pad_zp_conv=None, extra_qconv=False, shift_weights=True, resize_u8=False, resize_subgraph=False):
+               pad_zp_conv=None, extra_qconv=False, shift_weights=True, resize_u8=False, resize_subgraph=False, qdq=False, qdq_share_dq=False):
     """The QOperator int8 form of the same network, as ONNX Runtime's static quantisation writes it (the shape of
     `fcn-resnet50-12-int8.onnx`, the file the reference's tests load: predict_onnx.rs:357-381):
     QuantizeLinear -> QLinearConv (ReLU folded) -> MaxPool (u8) -> bottlenecks (QLinearConv x3 [+ downsample], com.microsoft
@@ -332,6 +332,17 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
         inits.append(tensor(name, np.asarray(v, np.uint8).reshape(()), dtype=2))
         return name
 
+    qparams, shared_dq = {}, {}
+
+    def dequant(q, sc, zp):
+        """QDQ form: the float view of a quantised tensor -- one DequantizeLinear per consumer, or a shared one"""
+        if qdq_share_dq and q in shared_dq:
+            return shared_dq[q]
+        f = fresh("dq")
+        emit("DequantizeLinear", [q, sc, zp], [f])
+        shared_dq[q] = f
+        return f
+
     def qconv(name, x):
         if name not in by_name:
             return None
@@ -356,8 +367,28 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
             inits.append(tensor(name + ".bias", np.asarray(c.bias, np.int32), dtype=6))
             ins.append(name + ".bias")
         out = fresh("qconv")
-        emit("QLinearConv", ins, [out], [attr_ints("dilations", [s.dil, s.dil]), attr_int("group", 1), attr_ints("kernel_shape", [s.k, s.k]),
-                                          attr_ints("pads", [s.pad] * 4), attr_ints("strides", [s.stride, s.stride])])
+        cattrs = [attr_ints("dilations", [s.dil, s.dil]), attr_int("group", 1), attr_ints("kernel_shape", [s.k, s.k]),
+                  attr_ints("pads", [s.pad] * 4), attr_ints("strides", [s.stride, s.stride])]
+        if qdq:  # DQ(x), DQ(w), DQ(b) -> Conv -> [Relu ->] Q: what ONNX Runtime fuses back into QLinearConv at session creation
+            xf = dequant(x, xs, xz)
+            wf = fresh("w_dq")
+            emit("DequantizeLinear", [name + ".weight", name + ".w_scale", name + ".w_zp"], [wf], [attr_int("axis", 0)])
+            cin = [xf, wf]
+            if name not in no_bias:
+                inits.append(tensor(name + ".b_scale", (np.float32(c.x_scale) * np.asarray(c.w_scale, np.float32)).astype(np.float32)))
+                bf = fresh("b_dq")
+                emit("DequantizeLinear", [name + ".bias", name + ".b_scale"], [bf], [attr_int("axis", 0)])
+                cin.append(bf)
+            y = fresh("conv")
+            emit("Conv", cin, [y], cattrs)
+            if (c.y_zp == 0 and s.relu) or name in relu_after:
+                r = fresh("relu")
+                emit("Relu", [y], [r])
+                y = r
+            emit("QuantizeLinear", [y, ys, yz], [out])
+            qparams[out] = (ys, yz)
+            return out
+        emit("QLinearConv", ins, [out], cattrs)
         if name in relu_after:
             r = fresh("relu")
             emit("Relu", [out], [r])
@@ -369,7 +400,13 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
     emit("QuantizeLinear", ["input", scalar_f("input.scale", stem_c.x_scale), scalar_u8("input.zp", stem_c.x_zp)], [q])
     x = qconv("backbone.conv1", q)
     o = fresh("pool")
-    emit("MaxPool", [x], [o], [attr_ints("kernel_shape", [3, 3]), attr_ints("pads", [1, 1, 1, 1]), attr_ints("strides", [2, 2]), attr_int("ceil_mode", 0)])
+    pattrs = [attr_ints("kernel_shape", [3, 3]), attr_ints("pads", [1, 1, 1, 1]), attr_ints("strides", [2, 2]), attr_int("ceil_mode", 0)]
+    if qdq:  # DQ -> MaxPool -> Q with the same parameters
+        pf = fresh("poolf")
+        emit("MaxPool", [dequant(x, "backbone.conv1.y_scale", "backbone.conv1.y_zp")], [pf], pattrs)
+        emit("QuantizeLinear", [pf, "backbone.conv1.y_scale", "backbone.conv1.y_zp"], [o])
+    else:
+        emit("MaxPool", [x], [o], pattrs)
     x = o
     l3 = None
     blocks = sorted({s.name.rsplit(".", 1)[0] for s, _ in items if s.role == "conv1"}, key=lambda p: [int(v) if v.isdigit() else v for v in p.replace("layer", "layer.").split(".")])
@@ -394,7 +431,17 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
         B = [idt, scalar_f(p + ".add.b_scale", a.b_scale), scalar_u8(p + ".add.b_zp", a.b_zp)]
         sw = rng.random() < 0.5 if swap_add is None else swap_add
         o = fresh("qadd")
-        emit("QLinearAdd", (B + A if sw else A + B) + [scalar_f(p + ".add.c_scale", a.c_scale), scalar_u8(p + ".add.c_zp", a.c_zp)], [o], domain="com.microsoft")
+        if qdq:  # DQ(a), DQ(b) -> Add -> [Relu ->] Q
+            fa, fb = dequant(*A), dequant(*B)
+            y = fresh("add")
+            emit("Add", [fb, fa] if sw else [fa, fb], [y])
+            if a.c_zp == 0:
+                r = fresh("relu")
+                emit("Relu", [y], [r])
+                y = r
+            emit("QuantizeLinear", [y, scalar_f(p + ".add.c_scale", a.c_scale), scalar_u8(p + ".add.c_zp", a.c_zp)], [o])
+        else:
+            emit("QLinearAdd", (B + A if sw else A + B) + [scalar_f(p + ".add.c_scale", a.c_scale), scalar_u8(p + ".add.c_zp", a.c_zp)], [o], domain="com.microsoft")
         x = o
         if p.startswith("backbone.layer3."):
             l3 = x
@@ -439,7 +486,12 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
             emit("Constant", [], [scales], [attr_tensor("value", tensor(scales, np.zeros((0,), np.float32)))])
             return [x, roi, scales, sizes]
 
-        if rs:  # onnxruntime's QOperator quantiser: Resize stays on the u8 tensor, DequantizeLinear comes last
+        if rs and qdq:  # DQ -> Resize -> Q (same parameters) -> DQ -> output
+            rf, rq = fresh("resizef"), fresh("resizeq")
+            emit("Resize", resize_inputs(dequant(lo, *dq_in)), [rf], attrs)
+            emit("QuantizeLinear", [rf] + dq_in, [rq])
+            emit("DequantizeLinear", [rq] + dq_in, [out_name])
+        elif rs:  # onnxruntime's QOperator quantiser: Resize stays on the u8 tensor, DequantizeLinear comes last
             emit("Resize", resize_inputs(lo), [dq], attrs)
             emit("DequantizeLinear", [dq] + dq_in, [out_name])
         else:

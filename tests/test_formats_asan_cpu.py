@@ -73,7 +73,11 @@ def test_quantised_blob_and_qoperator_file_survive_mutation(harness, tmp_path):
     pb.write_bytes(W.pack_qblob(convs, adds, 50, 21, True))
     po = tmp_path / "r50_int8.onnx"
     po.write_bytes(OW.fcn_qmodel(convs, adds, specs))
-    procs = [subprocess.Popen([harness, "onnx", str(po), str(N_QONNX_PER_PROC), str(5000 + 31 * k)], stdout=subprocess.PIPE,
+    pq = tmp_path / "r50_int8_qdq.onnx"  # the QDQ form of the same model: the fusion pass in front of the walker
+    for c in convs[:12]:
+        c.y_zp = 0 if c.name.endswith(("conv1", "conv2")) else c.y_zp
+    pq.write_bytes(OW.fcn_qmodel(convs, adds, specs, qdq=True, resize_u8=True, resize_subgraph=True))
+    procs = [subprocess.Popen([harness, "onnx", str(po if k == 0 else pq), str(N_QONNX_PER_PROC), str(5000 + 31 * k)], stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for k in range(2)]
     r = subprocess.run([harness, "blob", str(pb), str(N_QBLOB), "0xC0FFEE"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]

@@ -314,3 +314,26 @@ def test_models_that_resize_before_they_dequantise(qblob, oracle, size, tmp_path
             lo, la = m.lowres()  # read back as logits: DequantizeLinear of the codes
             want = Q.qforward(qblob, oracle.pack_normalize(fr))
             assert (lo.view(np.uint32) == want[0].view(np.uint32)).all() and (la.view(np.uint32) == want[1].view(np.uint32)).all()
+
+
+def test_qdq_format_file_loads_and_runs_like_the_qoperator_file(qblob, oracle, tmp_path):
+    """a QDQ-format file (onnxruntime's default output since 1.11) of the same quantised model: fused by the reader into the same
+    blob, so ModelCmd::Load gives the same bits"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import onnx_writer as OW
+    from oracle import infur_qoracle as Q
+
+    meta, convs, adds = W.unpack_qblob(qblob)
+    p = tmp_path / "fcn-resnet50-int8-qdq.onnx"
+    p.write_bytes(OW.fcn_qmodel(convs, adds, W.graph(50), qdq=True, order="shuffled", rng=np.random.default_rng(8), resize_subgraph=True))
+    fr = W.synth_frame(104, 152, index=6)
+    ref_lo, ref_aux = Q.qforward(qblob, oracle.pack_normalize(fr))
+    with Context(device=0) as c:
+        m = Model(c).control(ModelCmd.Load(str(p)))
+        rgba, _ = FramePath(c).advance(fr, 1.0)
+        lo, la = m.lowres()
+        assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
+        assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 104, 152))).all()

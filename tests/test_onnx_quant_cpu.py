@@ -252,3 +252,38 @@ def test_dynamic_size_resize_subgraph_is_looked_through(lib, q50, resize_u8):
     rc, err, out = convert(lib, model)
     assert rc == 0, err
     assert out == W.pack_qblob(convs, adds, 50, 21, True, resize_u8=resize_u8)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(resize_u8=True, order="shuffled", qdq_share_dq=True), dict(resize_subgraph=True, swap_add=True),
+                                dict(resize_u8=True, resize_subgraph=True)])
+def test_qdq_format_is_fused_into_the_same_blob(lib, kw):
+    """QDQ format (onnxruntime's default since 1.11): DequantizeLinear -> Conv / Add / MaxPool / Resize -> [Relu ->] QuantizeLinear groups,
+    which ONNX Runtime fuses into the QLinear operators when the session is created -- the reader does the same fusion and must
+    arrive at the bytes the QOperator file gives"""
+    from hostile_q import hostile_qmodel
+
+    specs, convs, adds = hostile_qmodel(seed=4)  # (tensor parameters consistent along the edges: a shared DequantizeLinear is legal)
+    c = next(c for c in convs if c.name == "backbone.layer3.2.conv1")
+    c.w_scale = np.full_like(c.w_scale, c.w_scale[0])
+    model = OW.fcn_qmodel(convs, adds, specs, qdq=True, rng=np.random.default_rng(2), per_tensor_scale=("backbone.layer3.2.conv1",), **kw)
+    rc, err, out = convert(lib, model)
+    assert rc == 0, err
+    assert out == W.pack_qblob(convs, adds, 50, 21, True, resize_u8=bool(kw.get("resize_u8")))
+
+
+def test_qdq_graphs_that_cannot_be_fused_are_rejected(lib, q50):
+    specs, convs, adds = q50
+    model = OW.fcn_qmodel(convs, adds, specs, qdq=True)
+    assert convert(lib, model)[0] == 0
+    # a Relu in front of a QuantizeLinear whose zero point is not 0 is not the clamp
+    name = next(c.name for s_, c in zip(specs, convs) if c.y_zp != 0 and s_.role == "conv3")
+    rc, err, _ = convert(lib, OW.fcn_qmodel(convs, adds, specs, qdq=True, relu_after=(name,)))
+    assert rc != 0 and "Relu in front of a QuantizeLinear whose zero point is not 0" in err, err
+    # an operator group that is not closed by a QuantizeLinear / a float operator the fusion does not know
+    rc, err, _ = convert(lib, model.replace(b"MaxPool", b"MaxPooX"))
+    assert rc != 0 and err
+    rc, err, _ = convert(lib, model.replace(b"\x03Add", b"\x03Sub"))
+    assert rc != 0 and err
+    for cut in (len(model) // 2, len(model) - 64):
+        rc, err, out = convert(lib, model[:cut])
+        assert rc != 0 and out is None
