@@ -358,7 +358,9 @@ int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, 
             qdq |= n.op == "Conv";
         }
         if (qdq && qop) { err = "the model mixes float Conv and QLinearConv nodes"; return 2; }
-        if (qdq && !qdq_to_qoperator(g, &err)) return 2;
+        // (also for QOperator files: quantisers older than QLinearAdd leave the residual sums as DQ -> Add -> [Relu ->] Q between
+        //  QLinearConv nodes, which ONNX Runtime fuses the same way; without such groups the pass changes nothing)
+        if (!qdq_to_qoperator(g, &err)) return 2;
     }
 
     for (size_t i = 0; i < g.nodes.size(); i++) {

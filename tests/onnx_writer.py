@@ -296,7 +296,7 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
 
 def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(), relu_after=(), w_zp=0, w_dtype=3, swap_add=None,
                input_type=1, coord_mode="pytorch_half_pixel", drop_last=0, stem_scale=None, dq_scale=None, no_bias=(), vector_wzp=False,
-               pad_zp_conv=None, extra_qconv=False, shift_weights=True, resize_u8=False, resize_subgraph=False, qdq=False, qdq_share_dq=False):
+               pad_zp_conv=None, extra_qconv=False, shift_weights=True, resize_u8=False, resize_subgraph=False, qdq=False, qdq_share_dq=False, float_add=False):
     """The QOperator int8 form of the same network, as ONNX Runtime's static quantisation writes it (the shape of
     `fcn-resnet50-12-int8.onnx`, the file the reference's tests load: predict_onnx.rs:357-381):
     QuantizeLinear -> QLinearConv (ReLU folded) -> MaxPool (u8) -> bottlenecks (QLinearConv x3 [+ downsample], com.microsoft
@@ -431,7 +431,7 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
         B = [idt, scalar_f(p + ".add.b_scale", a.b_scale), scalar_u8(p + ".add.b_zp", a.b_zp)]
         sw = rng.random() < 0.5 if swap_add is None else swap_add
         o = fresh("qadd")
-        if qdq:  # DQ(a), DQ(b) -> Add -> [Relu ->] Q
+        if qdq or float_add:  # DQ(a), DQ(b) -> Add -> [Relu ->] Q  (float_add: between QLinearConv nodes, pre-QLinearAdd quantisers)
             fa, fb = dequant(*A), dequant(*B)
             y = fresh("add")
             emit("Add", [fb, fa] if sw else [fa, fb], [y])

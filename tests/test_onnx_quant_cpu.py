@@ -287,3 +287,14 @@ def test_qdq_graphs_that_cannot_be_fused_are_rejected(lib, q50):
     for cut in (len(model) // 2, len(model) - 64):
         rc, err, out = convert(lib, model[:cut])
         assert rc != 0 and out is None
+
+
+def test_qoperator_file_with_float_residual_sums(lib):
+    """QLinearConv everywhere but the residual sums left as DequantizeLinear -> Add -> [Relu ->] QuantizeLinear (quantisers older than
+    com.microsoft QLinearAdd): fused like ONNX Runtime fuses them, same blob"""
+    from hostile_q import hostile_qmodel
+
+    specs, convs, adds = hostile_qmodel(seed=6)
+    rc, err, out = convert(lib, OW.fcn_qmodel(convs, adds, specs, float_add=True, order="ds_first"))
+    assert rc == 0, err
+    assert out == W.pack_qblob(convs, adds, 50, 21, True)
