@@ -298,3 +298,17 @@ def test_qoperator_file_with_float_residual_sums(lib):
     rc, err, out = convert(lib, OW.fcn_qmodel(convs, adds, specs, float_add=True, order="ds_first"))
     assert rc == 0, err
     assert out == W.pack_qblob(convs, adds, 50, 21, True)
+
+
+def test_integer_oracle_against_its_committed_golden_vectors():
+    """tests/golden/int8_golden.json: hashes of the oracle's logits on two hostile models (pure numpy / exact integer arithmetic:
+    portable).  A change of the oracle's arithmetic, of the blob format or of the generator shows up here before any GPU run."""
+    import importlib.util
+    import json
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_int8_golden", os.path.join(here, "golden", "make_int8_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "golden", "int8_golden.json")))
+    assert mod.build() == want
