@@ -337,3 +337,31 @@ def test_qdq_format_file_loads_and_runs_like_the_qoperator_file(qblob, oracle, t
         lo, la = m.lowres()
         assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
         assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 104, 152))).all()
+
+
+def test_gpu_logits_hash_to_the_committed_golden_vectors():
+    """tests/golden/int8_golden.json (made by tests/golden/make_int8_golden.py from the integer oracle): the HIP path's dequantised
+    logits must hash to the committed values -- the fixture comparison that needs no oracle at run time"""
+    import hashlib
+    import json
+    import os
+    import re
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from hostile_q import hostile_qblob
+
+    for case in json.load(open(os.path.join(here, "golden", "int8_golden.json")))["cases"]:
+        seed = int(re.search(r"seed=(\d+)", case["model"]).group(1))
+        h, w, idx = map(int, re.search(r"synth_frame\((\d+), (\d+), index=(\d+)\)", case["frame"]).groups())
+        blob = hostile_qblob(seed=seed)
+        assert hashlib.sha1(blob).hexdigest() == case["blob_sha1"]
+        with Context(device=0) as c:
+            m = Model(c).control(ModelCmd.LoadBlob(blob))
+            FramePath(c).advance(W.synth_frame(h, w, index=idx), 1.0)
+            lo, la = m.lowres()
+        assert list(lo.shape) == case["out_low_shape"]
+        assert hashlib.sha1(np.ascontiguousarray(lo).tobytes()).hexdigest() == case["out_low_sha1"]
+        assert hashlib.sha1(np.ascontiguousarray(la).tobytes()).hexdigest() == case["aux_low_sha1"]
+        assert np.bincount(lo.argmax(0).ravel(), minlength=21).tolist() == case["argmax_histogram"]
