@@ -245,7 +245,8 @@ bool qdq_to_qoperator(QGraph& g, std::string* err) {
             dead[qn] = 1;
             n = std::move(f);
         } else if (n.op == "Add") {
-            if (n.in.size() != 2 || !dq_of.count(n.in[0]) || !dq_of.count(n.in[1])) { *err = "QDQ model: an Add whose inputs are not DequantizeLinear outputs"; return false; }
+            if (n.in.size() == 2 && !dq_of.count(n.in[0]) && !dq_of.count(n.in[1])) continue;  // (integer arithmetic of a Resize size subgraph)
+            if (n.in.size() != 2 || !dq_of.count(n.in[0]) || !dq_of.count(n.in[1])) { *err = "QDQ model: an Add with one DequantizeLinear input and one that is not"; return false; }
             if (!closing_q(n, &relu, &qn)) { *err = "QDQ model: an Add (+ Relu) that does not end in exactly one QuantizeLinear"; return false; }
             const DQ a = dq_of[n.in[0]], b = dq_of[n.in[1]];
             const Node& Q = g.nodes[qn];
