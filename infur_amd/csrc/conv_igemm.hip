@@ -66,6 +66,9 @@ static const CfgInfo kCfgs[] = {
     // LDS-DMA staging with the DMA instructions issued between the slices (NBUF == 5: the MFMA-bound layers)
     {256, 256, {"conv_igemm_f32<256,256,dmai>", "conv_igemm_f16<256,256,dmai>", "conv_igemm_f32s<256,256,dmai>"}},
     {256, 128, {"conv_igemm_f32<256,128,dmai>", "conv_igemm_f16<256,128,dmai>", "conv_igemm_f32s<256,128,dmai>"}},
+    // configuration 15 of the quantised mode with the N tiles of an M tile shared out over several workgroups (conv1x1_q8.hip):
+    // M = 32400 alone gives 254 workgroups for 256 CUs
+    {256, 128, {"conv1x1_f32<256,areg,nsplit>", "conv1x1_f16<256,areg,nsplit>", "conv1x1_f32s<256,areg,nsplit>"}},
     // (a RING OF THREE LDS images with a counted vmcnt -- two K steps of DMA in flight across the barrier -- was measured on
     // 256x128, 128x256 and 128x128 tiles for the HBM-bound 1x1 convs: better than the two-image form of the same tile
     // (layer3 conv1 at 4K: 0.123 -> 0.100 ms) but never better than 256x256 with two images (0.087) or the register form
@@ -128,6 +131,7 @@ bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32) 
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     if (mode == 3) mode = 2;  // the fp8 cross-term form stages like the split mode
     if (cfg >= 13 && mode != 1 && mode != 4) return false;  // LDS-DMA staging: byte operands that need no conversion (f16, i8)
+    if (cfg == 18) return mode == 4 && conv1x1_q8_valid(a, mode, out_f32) && conv1x1_q8_nsplit(a) > 1;
     if (cfg == 15) return mode == 4 ? conv1x1_q8_valid(a, mode, out_f32) : conv1x1_areg_valid(a, mode, out_f32);  // (never the f32 logits)
     const int bn = kCfgs[cfg].bn;
     if (a.Cout <= 32) return bn == 32;

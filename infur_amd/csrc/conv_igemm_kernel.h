@@ -734,7 +734,8 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                     qm[t] = a.q_mult[n + t];
                 }
         }
-        const float q_yzpf = (float)a.q_yzp, q_lo = -q_yzpf, q_hi = 255.f - q_yzpf, q_bzpf = (float)a.q_bzp, q_czpf = (float)a.q_czp;
+        const float q_yzpf = (float)a.q_yzp, q_lo = -q_yzpf, q_hi = 255.f - q_yzpf;
+        const QEpi qe = {q_yzpf, q_lo, q_hi, a.q_ra, a.q_rb, (float)a.q_bzp, (float)a.q_czp};
         float vmax = 0.f;  // SPLIT: largest |output| of this lane (range monitor)
 #pragma unroll
         for (int i = 0; i < TM; i++) {
@@ -790,15 +791,10 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                         }
                         u32x4 pk;
 #pragma unroll
-                        for (int t4 = 0; t4 < 4; t4++) {
-                            unsigned w = 0;
-#pragma unroll
-                            for (int t = 0; t < 4; t++) {
-                                const float d = q_requant_c(ai[t4][t] + qb[4 * t4 + t], qm[4 * t4 + t], q_lo, q_hi);  // y - y_zp
-                                const float y = has_res ? q_add_c(d, a.q_ra, q_byte(rv[t4], t), q_bzpf, a.q_rb, q_czpf) : d + q_yzpf;
-                                w = q_pack(y, t, w);
-                            }
-                            pk[t4] = w;
+                        for (int t4 = 0; t4 < 4; t4++) {  // (qepilogue.h: four outputs per call, packed multiplies / adds)
+                            const qi4 a4 = {ai[t4][0] + qb[4 * t4], ai[t4][1] + qb[4 * t4 + 1], ai[t4][2] + qb[4 * t4 + 2], ai[t4][3] + qb[4 * t4 + 3]};
+                            const qf4 m4 = {qm[4 * t4], qm[4 * t4 + 1], qm[4 * t4 + 2], qm[4 * t4 + 3]};
+                            pk[t4] = has_res ? q_word<true>(a4, m4, rv[t4], qe) : q_word<false>(a4, m4, 0u, qe);
                         }
                         *reinterpret_cast<u32x4*>(out + (size_t)m * a.Cout + n) = pk;
                     }
@@ -988,7 +984,12 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
                 if (conv1x1_areg_valid(a, 1, 0)) return launch_conv1x1_areg(a, s);
             }
             if constexpr (std::is_same<T, signed char>::value && std::is_same<OutT, unsigned char>::value) {
-                if (conv1x1_q8_valid(a, 4, 0)) return launch_conv1x1_q8(a, s);
+                if (conv1x1_q8_valid(a, 4, 0)) return launch_conv1x1_q8(a, 1, s);
+            }
+            return hipErrorInvalidValue;
+        case 18:
+            if constexpr (std::is_same<T, signed char>::value && std::is_same<OutT, unsigned char>::value) {
+                if (conv1x1_q8_valid(a, 4, 0) && conv1x1_q8_nsplit(a) > 1) return launch_conv1x1_q8(a, conv1x1_q8_nsplit(a), s);
             }
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;

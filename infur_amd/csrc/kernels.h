@@ -77,7 +77,8 @@ hipError_t launch_conv1x1_areg(const ConvArgs& a, hipStream_t s);
 // quantised models (mode 4, u8 output): activation tile in registers, 16 consecutive channels per lane straight from the
 // accumulators (conv1x1_q8.hip): configuration 15 in that mode
 bool conv1x1_q8_valid(const ConvArgs& a, int mode, int out_f32);
-hipError_t launch_conv1x1_q8(const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv1x1_q8(const ConvArgs& a, int nsplit, hipStream_t s);
+int conv1x1_q8_nsplit(const ConvArgs& a);  // configuration 18: N tiles shared out over this many workgroups per M tile (0: not a candidate)
 
 // Two 1x1 convolutions back to back on the same pixels, f16 (conv1x1_b2b.hip): y = ReLU(w3 * in + b3 + res) -- a
 // bottleneck's conv3 + residual -- is written once and immediately multiplied by the NEXT bottleneck's conv1 weights:

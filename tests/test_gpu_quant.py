@@ -267,15 +267,16 @@ def test_full_1080p_quantised_frame_is_bit_exact(qblob, oracle):
         assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, 1080, 1920))).all()
 
 
-def test_conv1x1_q8_forced_on_every_1x1_is_bit_exact():
-    """conv1x1_q8.hip (configuration 15 of the quantised mode) is picked by measurement per shape; here it is forced wherever it is a
-    candidate (INFUR_CONV_CFG is read once per process: a child process) and the layer-by-layer, hostile-parameter and ResNet-101
-    cases of this file run again"""
+@pytest.mark.parametrize("cfg", ["15", "18"])
+def test_conv1x1_q8_forced_on_every_1x1_is_bit_exact(cfg):
+    """conv1x1_q8.hip (configuration 15 of the quantised mode; 18 = the same walk with the N tiles of an M tile shared out over
+    several workgroups) is picked by measurement per shape; here it is forced wherever it is a candidate (INFUR_CONV_CFG is read
+    once per process: a child process) and the layer-by-layer, hostile-parameter and ResNet-101 cases of this file run again"""
     import os
     import subprocess
     import sys
 
-    env = dict(os.environ, INFUR_CONV_CFG="15")
+    env = dict(os.environ, INFUR_CONV_CFG=cfg)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
                         "every_layer or hostile or resnet101 or group_stream"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
