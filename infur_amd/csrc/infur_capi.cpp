@@ -791,6 +791,11 @@ int32_t run_b2b(infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1, const Te
 // signed operands, and the requantisation multipliers are computed as ONNX Runtime computes them (f32: x_s * w_s[o] / y_s).
 inline int q_cpad(int c, bool padded) { return padded && c < 128 ? 128 : c; }
 // bytes of a layer's repacked weights: s8 OHWI (padded); the stem: one dword (r, g, b, 0) per tap and channel
+// layer1's convs (64-channel tensors on one side or both) also get the pixel-pair arrangement of their weights
+inline bool q_pair_layer(const ConvLayer& L) {
+    return L.name.compare(0, 16, "backbone.layer1.") == 0 && L.stride == 1 && L.dil == 1 && (L.k == 1 || (L.k == 3 && L.pad == 1)) &&
+           (L.cin == 64 || L.cout == 64) && (L.cin % 64) == 0 && (L.cout % 64) == 0;
+}
 inline size_t q_wbytes(const ConvLayer& L) {
     return L.role == 's' ? (size_t)L.cout * L.k * L.k * 4 : (size_t)L.cout_p * L.k * L.k * L.cin_p + 64;
 }
@@ -832,6 +837,11 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
         L.cin_p = L.role == 's' ? L.cin : q_cpad(L.cin, true);
         L.cout_p = L.role == 's' ? L.cout : q_cpad(L.cout, !logits);
         total += align_up(q_wbytes(L), 256) + 2 * align_up((size_t)L.cout_p * 4, 256);
+        if (q_pair_layer(L)) {  // the pixel-pair form of layer1 (forward_q), beside the padded one (odd widths, kept activations)
+            L.cin2 = 2 * L.cin;
+            L.cout2 = 2 * L.cout;
+            total += align_up((size_t)L.cout2 * L.k * L.k * L.cin2 + 64, 256) + 2 * align_up((size_t)L.cout2 * 4, 256);
+        }
     }
     struct DevMem {
         void* p = nullptr;
@@ -930,6 +940,44 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
         HIPCHK(c, hipMemcpyAsync(L.d_qbias, qb.data(), (size_t)L.cout_p * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(L.d_qmult, h_mult.data(), (size_t)L.cout_p * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (L.cin2) {
+            // Pixel-pair weights, OHWI over pairs: output row p * cout + o (p = which pixel of the output pair), input column
+            // q * cin + i.  1x1: W where p == q.  3x3 (pad 1, in pair units too): pair-column kx' in {0, 1, 2} holds input pixel
+            // x_in = 2 (X + kx' - 1) + q for output pixel x_out = 2 X + p, i.e. the tap kx = 2 (kx' - 1) + q - p + 1 where that is
+            // a tap of the 3x3, zero elsewhere.  A structural zero multiplies whatever the other pixel holds by 0; the row sums,
+            // hence the folded bias, and the multipliers are the channel's own, once per pixel of the pair.
+            const int taps = L.k * L.k;
+            std::vector<int8_t> w((size_t)L.cout * L.cin * taps), w2((size_t)L.cout2 * taps * L.cin2, 0);
+            HIPCHK(c, hipMemcpyAsync(w.data(), src_w, w.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int pp = 0; pp < 2; pp++)
+                for (int o = 0; o < L.cout; o++)
+                    for (int ky = 0; ky < L.k; ky++)
+                        for (int kxp = 0; kxp < L.k; kxp++)
+                            for (int qq = 0; qq < 2; qq++) {
+                                const int kx = L.k == 1 ? (pp == qq ? 0 : -1) : 2 * (kxp - 1) + qq - pp + 1;
+                                if (kx < 0 || kx >= L.k) continue;
+                                int8_t* dst = &w2[(((size_t)(pp * L.cout + o) * L.k + ky) * L.k + kxp) * L.cin2 + (size_t)qq * L.cin];
+                                for (int i = 0; i < L.cin; i++) dst[i] = w[((size_t)o * L.cin + i) * taps + ky * L.k + kx];
+                            }
+            std::vector<int32_t> qb2(L.cout2);
+            std::vector<float> qm2(L.cout2);
+            for (int pp = 0; pp < 2; pp++)
+                for (int o = 0; o < L.cout; o++) {
+                    qb2[pp * L.cout + o] = qb[o];
+                    qm2[pp * L.cout + o] = h_mult[o];
+                }
+            L.d_w2 = base + off;
+            off += align_up(w2.size() + 64, 256);
+            L.d_qbias2 = (int32_t*)(base + off);
+            off += align_up((size_t)L.cout2 * 4, 256);
+            L.d_qmult2 = (float*)(base + off);
+            off += align_up((size_t)L.cout2 * 4, 256);
+            HIPCHK(c, hipMemcpyAsync(L.d_w2, w2.data(), w2.size(), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(L.d_qbias2, qb2.data(), (size_t)L.cout2 * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(L.d_qmult2, qm2.data(), (size_t)L.cout2 * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
     }
     model_free(c);  // the old model goes only now
     c->d_weights = arena.p;
@@ -970,27 +1018,30 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
 }
 
 // one QLinearConv (+ the block's QLinearAdd when `res` is given; f32 output = + DequantizeLinear) on the i8 MFMA
-int32_t run_qconv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, const QAddParams* add, Tensor* out) {
+// (pair: `in` / `res` / `out` are pixel-pair views -- (H, W/2, 2C) -- and the layer's pair weights are used: forward_q)
+int32_t run_qconv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, const QAddParams* add, Tensor* out, bool pair = false) {
     const int oh = conv_out(in.h, L.k, L.stride, L.pad, L.dil), ow = conv_out(in.w, L.k, L.stride, L.pad, L.dil);
     const int out_f32 = L.role == 'c' ? 1 : 0;
-    if (in.c != L.cin_p || in.es != 1) return fail(c, INFUR_E_SHAPE, "'%s' expects %d u8 channels, got %d", L.name.c_str(), L.cin_p, in.c);
-    RETIF(talloc(c, oh, ow, L.cout_p, out_f32 ? 4 : 1, out));
+    if (pair && !L.d_w2) return fail(c, INFUR_E_SHAPE, "'%s' has no pixel-pair weights", L.name.c_str());
+    const int cin_k = pair ? L.cin2 : L.cin_p, cout_k = pair ? L.cout2 : L.cout_p;
+    if (in.c != cin_k || in.es != 1) return fail(c, INFUR_E_SHAPE, "'%s' expects %d u8 channels, got %d", L.name.c_str(), cin_k, in.c);
+    RETIF(talloc(c, oh, ow, cout_k, out_f32 ? 4 : 1, out));
     ConvArgs a;
-    a.in = in.p; a.wt = L.d_w; a.bias = nullptr; a.res = res ? res->p : nullptr; a.out = out->p;
-    a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = L.cout_p;
+    a.in = in.p; a.wt = pair ? L.d_w2 : L.d_w; a.bias = nullptr; a.res = res ? res->p : nullptr; a.out = out->p;
+    a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = cout_k;
     a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = 0;
-    a.q_mult = L.d_qmult; a.q_bias = L.d_qbias; a.q_yzp = L.y_zp; a.q_dq = L.y_scale;
+    a.q_mult = pair ? L.d_qmult2 : L.d_qmult; a.q_bias = pair ? L.d_qbias2 : L.d_qbias; a.q_yzp = L.y_zp; a.q_dq = L.y_scale;
     if (out_f32 && c->q_resize_u8) {  // the file resizes the codes: leave them (as floats) for the post kernels to interpolate
         a.q_dq = 1.0f;
         a.q_dq_off = (float)L.y_zp;
     }
     if (res) {
-        if (!add || res->c != L.cout_p || res->h != oh || res->w != ow) return fail(c, INFUR_E_SHAPE, "residual of '%s' has the wrong shape", L.name.c_str());
+        if (!add || res->c != cout_k || res->h != oh || res->w != ow) return fail(c, INFUR_E_SHAPE, "residual of '%s' has the wrong shape", L.name.c_str());
         volatile float ra = add->a_scale / add->c_scale, rb = add->b_scale / add->c_scale;  // f32 divisions, as MLAS' QLinearAdd
         a.q_ra = ra; a.q_rb = rb; a.q_bzp = add->b_zp; a.q_czp = add->c_zp;
     }
     const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
-    const double bytes = (double)in.bytes() + (double)out->bytes() + (res ? (double)res->bytes() : 0.0) + (double)L.cout_p * L.cin_p * L.k * L.k;
+    const double bytes = (double)in.bytes() + (double)out->bytes() + (res ? (double)res->bytes() : 0.0) + (double)cout_k * cin_k * L.k * L.k;
     int cfg = -1;
     RETIF(pick_cfg(c, a, 4, out_f32, &cfg));
     {
@@ -1008,12 +1059,21 @@ int32_t forward_q(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     const int sh = conv_out(h, 7, 2, 3, 1), sw = conv_out(w, 7, 2, 3, 1);
     const int ph = conv_out(sh, 3, 2, 1, 1), pw = conv_out(sw, 3, 2, 1, 1);
     Tensor s, x;
+    // layer1 on PIXEL PAIRS (an even pooled width; not with kept activations, whose per-layer read-back is the padded layout): its
+    // 64-channel tensors are stored compact, two neighbouring pixels = one 128-byte GEMM row of a (H, W/2) image, and the convs use
+    // the pair arrangement of their weights (model_load_q_dev) -- no channel padding in HBM, half the rows (hence half the MFMA
+    // work) for conv2 and layer1.0.conv1; the 256-channel tensors are unchanged: (H, W/2, 512) IS (H, W, 256).  Same integer sums,
+    // same epilogue per channel: bit-identical to the padded form (INFUR_Q_NOPAIR=1 keeps that one: tests/test_gpu_quant.py).
+    static const bool no_pair_env = getenv("INFUR_Q_NOPAIR") && atoi(getenv("INFUR_Q_NOPAIR")) != 0;
+    bool pair = !no_pair_env && !c->opt.keep_activations && !c->opt.no_fuse_stem_pool && (pw % 2) == 0;
+    for (const ConvLayer& L : c->convs)
+        if (L.name.compare(0, 16, "backbone.layer1.") == 0 && !L.d_w2) pair = false;
     if (!c->opt.keep_activations && !c->opt.no_fuse_stem_pool) {
         // QuantizeLinear + QLinearConv + MaxPool in one launch, exact on the f16 MFMA; the 64-channel stem tensor is never written
-        RETIF(talloc(c, ph, pw, 128, 1, &x));
+        RETIF(talloc(c, ph, pw, pair ? 64 : 128, 1, &x));
         ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool_q", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes());
-        HIPCHK(c, launch_stem_pool_q(d_bgr, h, w, c->d_qstem_w, c->d_qstem_lut, c->d_qstem_bias, stem.d_qmult, stem.y_zp, (uint8_t*)x.p, sh, sw, ph, pw,
-                                     c->stream));
+        HIPCHK(c, launch_stem_pool_q(d_bgr, h, w, c->d_qstem_w, c->d_qstem_lut, c->d_qstem_bias, stem.d_qmult, stem.y_zp, (uint8_t*)x.p, pair ? 64 : 128,
+                                     sh, sw, ph, pw, c->stream));
     } else {
     {
         RETIF(talloc(c, sh, sw, 64, 1, &s));
@@ -1037,11 +1097,21 @@ int32_t forward_q(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
         const bool has_ds = c->convs[ci + 3].role == 'd';
         if (blk >= c->qadds.size()) return fail(c, INFUR_E_SHAPE, "quantised model has fewer residual sums than blocks");
         Tensor t1, t2, idt, y;
-        RETIF(run_qconv(c, c1, x, nullptr, nullptr, &t1));
-        RETIF(run_qconv(c, c2, t1, nullptr, nullptr, &t2));
+        const bool pv = pair && c1.name.compare(0, 16, "backbone.layer1.") == 0;
+        Tensor xv = x;  // the block's input as the convs see it
+        if (pv) {
+            xv.w = x.w / 2;
+            xv.c = x.c * 2;
+        }
+        RETIF(run_qconv(c, c1, xv, nullptr, nullptr, &t1, pv));
+        RETIF(run_qconv(c, c2, t1, nullptr, nullptr, &t2, pv));
         pool_release(c, t1);
-        if (has_ds) RETIF(run_qconv(c, c->convs[ci + 3], x, nullptr, nullptr, &idt));
-        RETIF(run_qconv(c, c3, t2, has_ds ? &idt : &x, &c->qadds[blk], &y));
+        if (has_ds) RETIF(run_qconv(c, c->convs[ci + 3], xv, nullptr, nullptr, &idt, pv));
+        RETIF(run_qconv(c, c3, t2, has_ds ? &idt : &xv, &c->qadds[blk], &y, pv));
+        if (pv) {  // (H, W/2, 512) is (H, W, 256)
+            y.w *= 2;
+            y.c /= 2;
+        }
         if (has_ds && c->opt.keep_activations) std::swap(c->kept[c->kept.size() - 1], c->kept[c->kept.size() - 2]);  // blob order: conv3, downsample
         pool_release(c, t2);
         if (has_ds) pool_release(c, idt);

@@ -57,6 +57,13 @@ struct ConvLayer {
     int x_zp = 0, y_zp = 0;
     int32_t* d_qbias = nullptr;
     float* d_qmult = nullptr;
+    // layer1 of a quantised model, PIXEL-PAIR view (forward_q): two horizontally adjacent pixels of a 64-channel tensor are one
+    // 128-byte row of a (H, W/2, 128) image -- no channel padding -- and the layer's weights are re-arranged to act on pairs:
+    // cin2 = 2 cin, cout2 = 2 cout, block structure [[W, 0], [0, W]] for the 1x1 convs, the three pair-columns of a 3x3
+    int cin2 = 0, cout2 = 0;
+    void* d_w2 = nullptr;
+    int32_t* d_qbias2 = nullptr;
+    float* d_qmult2 = nullptr;
 };
 
 struct QAddParams {  // com.microsoft QLinearAdd of one bottleneck: C = A (conv3) + B (identity / downsample)

@@ -123,7 +123,7 @@ hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt
 // quantised model: QuantizeLinear + QLinearConv 7x7/2 + u8 max-pool in one launch, exact on the f16 MFMA (stem_pool.hip).
 // wt: [147][64] f32 = the s8 weights, k = (ky * 7 + kx) * 3 + c; lut: [3][256] f32 = q - x_zp (RGB order); out: [PH][PW][128] u8
 hipError_t launch_stem_pool_q(const uint8_t* bgr, int H, int W, const float* wt, const float* lut, const int32_t* q_bias, const float* q_mult,
-                              int y_zp, uint8_t* out, int SH, int SW, int PH, int PW, hipStream_t s);
+                              int y_zp, uint8_t* out, int cstride, int SH, int SW, int PH, int PW, hipStream_t s);
 hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const float* bias, const float* lut, void* out,
                             int mode, int SH, int SW, int PH, int PW, float a_scale, float w_scale, unsigned* amax, hipStream_t s);
 

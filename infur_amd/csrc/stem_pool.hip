@@ -180,6 +180,7 @@ struct StemQuant {
     const int32_t* bias;  // the operator's own bias (the operand is q - x_zp: nothing to fold)
     const float* mult;    // (x_s * w_s[o]) / y_s
     int y_zp;
+    int cstride = 128;  // bytes per output pixel: 128 (64 values + 64 zeros, the K step of the i8 GEMMs) or 64 (compact: the pixel-pair view)
 };
 template <typename OutT, bool QUANT = false>
 __device__ __forceinline__ void stem_stage_and_pool(float* smem, const f32x16s (&acc)[2][2], const int (&pidx)[2], int half, float acc_scale,
@@ -241,9 +242,9 @@ __device__ __forceinline__ void stem_stage_and_pool(float* smem, const f32x16s (
             w = q_pack(q_requant_c((int)m.y + b4.y, m4.y, lo, hi) + yz, 1, w);
             w = q_pack(q_requant_c((int)m.z + b4.z, m4.z, lo, hi) + yz, 2, w);
             w = q_pack(q_requant_c((int)m.w + b4.w, m4.w, lo, hi) + yz, 3, w);
-            unsigned char* o = reinterpret_cast<unsigned char*>(out) + ((size_t)py * PW + pxo) * 128 + c4 * 4;
+            unsigned char* o = reinterpret_cast<unsigned char*>(out) + ((size_t)py * PW + pxo) * (size_t)q.cstride + c4 * 4;
             *reinterpret_cast<unsigned*>(o) = w;
-            *reinterpret_cast<unsigned*>(o + 64) = 0u;  // channel padding
+            if (q.cstride == 128) *reinterpret_cast<unsigned*>(o + 64) = 0u;  // channel padding
             continue;
         }
         OutT* o = out + ((size_t)py * PW + pxo) * 64 + c4 * 4;
@@ -517,10 +518,11 @@ __global__ void __launch_bounds__(256, 2)
 }
 
 hipError_t launch_stem_pool_q(const uint8_t* bgr, int H, int W, const float* wt, const float* lut, const int32_t* q_bias, const float* q_mult,
-                              int y_zp, uint8_t* out, int SH, int SW, int PH, int PW, hipStream_t s) {
+                              int y_zp, uint8_t* out, int cstride, int SH, int SW, int PH, int PW, hipStream_t s) {
+    if (cstride != 64 && cstride != 128) return hipErrorInvalidValue;
     dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
     hipLaunchKernelGGL((stem_pool16_kernel<unsigned char, false, true>), grid, dim3(256), 0, s, bgr, H, W, wt, (const float*)nullptr, lut, out, SH, SW,
-                       PH, PW, 1.0f, 1.0f, 1.0f, (unsigned*)nullptr, StemQuant{q_bias, q_mult, y_zp});
+                       PH, PW, 1.0f, 1.0f, 1.0f, (unsigned*)nullptr, StemQuant{q_bias, q_mult, y_zp, cstride});
     return hipGetLastError();
 }
 

@@ -282,6 +282,37 @@ def test_conv1x1_q8_forced_on_every_1x1_is_bit_exact(cfg):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+def test_layer1_padded_form_still_gives_the_oracles_bytes():
+    """forward_q runs layer1 of a quantised model on PIXEL PAIRS when the pooled width is even (no channel padding, pair-arranged
+    weights); INFUR_Q_NOPAIR=1 keeps the padded form (read once per process: a child process).  The whole-frame cases of this file
+    run again with the pair view off (the every-layer cases keep activations, which is the padded form in either process)"""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, INFUR_Q_NOPAIR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "640x480 or 1080p or hostile or group_stream or pixel_pair_sizes"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("size", [(64, 96), (97, 130), (48, 8), (61, 200)])
+def test_pixel_pair_sizes(qblob, oracle, size):
+    """pooled widths 24 (pairs), 33 (odd: the padded form), 2 (one pair), 50 (pairs, odd height): logits and mask against the integer oracle"""
+    from oracle import infur_qoracle as Q
+
+    h, w = size
+    fr = W.synth_frame(h, w, index=5)
+    c = Context(device=0)
+    m = Model(c).control(ModelCmd.LoadBlob(qblob))
+    rgba, _ = FramePath(c).advance(fr, 1.0)
+    lo, la = m.lowres()
+    c.close()
+    ref_lo, ref_aux = Q.qforward(qblob, oracle.pack_normalize(fr))
+    assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
+    assert (rgba == oracle.colorcode(oracle.upsample_bilinear(ref_lo, h, w))).all()
+
+
 @pytest.mark.parametrize("size", [(96, 128), (135, 241)])
 def test_models_that_resize_before_they_dequantise(qblob, oracle, size, tmp_path):
     """QLinearConv -> Resize (u8) -> DequantizeLinear (blob flag bit 0; the order onnxruntime's QOperator quantiser writes when Resize
