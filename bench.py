@@ -580,8 +580,13 @@ def resident_rate(a, dev, dtype, blob, d_frames, d_masks, Wd, H, scale, n_frames
     (weights loaded once, replicated to the other contexts through infur_group_weights_broadcast)."""
     from infur_amd.processors import Context, FramePath, Group, Model, ModelCmd
 
+    import torch
+
     K = max(1, a.contexts_per_gpu)
-    ctxs = [Context(device=dev, compute_aux=not a.no_aux, profile=False, dtype=dtype) for _ in range(K)]
+    # the contexts run on streams of torch's pool, as the headline's do (streams a context creates for itself one after the other
+    # can share a hardware queue, and two frames in flight then behave like one: the side measurements read 8-10 % low)
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    ctxs = [Context(device=dev, compute_aux=not a.no_aux, profile=False, dtype=dtype, stream=st.cuda_stream) for st in streams]
     Model(ctxs[0]).control(ModelCmd.LoadBlob(blob))
     if K > 1:
         with Group(ctxs) as g:
@@ -595,7 +600,13 @@ def resident_rate(a, dev, dtype, blob, d_frames, d_masks, Wd, H, scale, n_frames
         for c in ctxs:
             c.synchronize()
 
-    run(max(4 * K, 16) if n_frames >= 32 else 2 * K)  # arenas, tile configurations, and the clocks back up after the idle gap
+    # arenas, tile configurations, and the clocks back up after the idle gap: a side measurement starts after seconds of host work
+    # (blob synthesis) with the GPU idle, and 16 frames of a fast mode (27 ms of the quantised model) do not bring the package
+    # back to its steady clock -- warm up for at least 0.3 s of frames, like the headline's own warm-up steps do for it
+    tw = time.perf_counter()
+    run(max(4 * K, 16) if n_frames >= 32 else 2 * K)
+    while n_frames >= 32 and time.perf_counter() - tw < 0.3:
+        run(4 * K)
     t0 = time.perf_counter()
     run(n_frames)
     dt = time.perf_counter() - t0

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <climits>
 #include <cstring>
 #include <exception>
@@ -1313,7 +1314,19 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
         if (o.stream) {
             c->stream = (hipStream_t)o.stream;
         } else {
-            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            // The streams the library creates ALTERNATE between the normal and the high priority class.  Why: two contexts that work on
+            // different frames at the same time (bench.py, infur_stream_add_lane, infur_group_* on one device) only overlap if their
+            // streams sit on different hardware queues, and the runtime hands a new stream the least-used queue OF ITS PRIORITY CLASS
+            // -- after a process has created and destroyed streams unevenly, two streams created back to back can land on the same
+            // queue and the two frames in flight behave like one (scripts/ctx_streams.py: the quantised model 580 instead of 640
+            // frames/s, f32x 213 instead of 229, depending on nothing but the process's history).  Streams of different priority
+            // classes never share a queue.  Both classes run whenever work is ready; a host that wants something else passes its
+            // own stream in the options.
+            static std::atomic<unsigned> own_streams{0};
+            int prio_low = 0, prio_high = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: high < normal = 0 <= low)
+            const int prio = (own_streams.fetch_add(1) & 1u) ? prio_high : 0;
+            if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess) {
                 delete c;
                 return INFUR_E_HIP;
             }
