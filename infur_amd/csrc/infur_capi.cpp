@@ -25,6 +25,7 @@
 #include <cstring>
 #include <exception>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1294,6 +1295,26 @@ void infur_options_default(infur_options* o) {
     o->compute_aux = 1;
 }
 
+// the stream pool of infur_ctx_create (see there)
+static hipStream_t pool_stream(int device) {
+    constexpr int kPool = 8, kMaxDev = 64;
+    static std::mutex mu;
+    static hipStream_t pool[kMaxDev][kPool];
+    static bool made[kMaxDev];
+    static unsigned next[kMaxDev];
+    if (device < 0 || device >= kMaxDev) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!made[device]) {
+        for (int i = 0; i < kPool; i++)
+            if (hipStreamCreateWithFlags(&pool[device][i], hipStreamNonBlocking) != hipSuccess) {
+                for (int j = 0; j < i; j++) (void)hipStreamDestroy(pool[device][j]);
+                return nullptr;
+            }
+        made[device] = true;
+    }
+    return pool[device][next[device]++ % kPool];
+}
+
 int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
     try {
         if (!out) return INFUR_E_INVALID_ARG;
@@ -1314,23 +1335,22 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
         if (o.stream) {
             c->stream = (hipStream_t)o.stream;
         } else {
-            // The streams the library creates ALTERNATE between the normal and the high priority class.  Why: two contexts that work on
-            // different frames at the same time (bench.py, infur_stream_add_lane, infur_group_* on one device) only overlap if their
-            // streams sit on different hardware queues, and the runtime hands a new stream the least-used queue OF ITS PRIORITY CLASS
-            // -- after a process has created and destroyed streams unevenly, two streams created back to back can land on the same
-            // queue and the two frames in flight behave like one (scripts/ctx_streams.py: the quantised model 580 instead of 640
-            // frames/s, f32x 213 instead of 229, depending on nothing but the process's history).  Streams of different priority
-            // classes never share a queue.  Both classes run whenever work is ready; a host that wants something else passes its
-            // own stream in the options.
-            static std::atomic<unsigned> own_streams{0};
-            int prio_low = 0, prio_high = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);  // (numerically: high < normal = 0 <= low)
-            const int prio = (own_streams.fetch_add(1) & 1u) ? prio_high : 0;
-            if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess) {
+            // The streams the library hands out come from a per-device POOL of eight, created back to back the first time a context
+            // of the device asks, handed out round-robin and never destroyed.  Why: two contexts that work on different frames at the
+            // same time (bench.py, infur_stream_add_lane, infur_group_* on one device) only overlap if their streams sit on different
+            // hardware queues, and the runtime gives a NEW stream the least-used of its four queues -- in a process that has created and
+            // destroyed streams unevenly, two streams created back to back can land on the same queue and the two frames in flight
+            // behave like one (scripts/ctx_streams.py: the quantised model 580 instead of 640 frames/s, f32x 213 instead of 229,
+            // depending on nothing but the process's history).  Pool streams are created in one go (they spread over the queues) and
+            // contexts created one after the other get consecutive entries.  (Alternating the PRIORITY class also separates the queues,
+            // but the ring's copies, which run at normal priority, then starve behind the high-priority lane: configs[2]'s stream path
+            // fell from 341 to 286 frames/s.)  More than eight live contexts of a device share streams pairwise -- as they would share a
+            // hardware queue anyway; a host with its own stream policy passes its stream in the options.
+            c->stream = pool_stream(o.device);
+            if (!c->stream) {
                 delete c;
                 return INFUR_E_HIP;
             }
-            c->own_stream = true;
         }
         std::vector<float> pre(768);
         std::vector<uint32_t> col(20 * 256);
