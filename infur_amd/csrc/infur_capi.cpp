@@ -307,6 +307,8 @@ void model_free(infur_ctx* c) {
     c->convs.clear();
     c->qadds.clear();
     c->quant = false;
+    c->stem16_wt = nullptr;  // (the image is rebuilt for the next model even if its weights land at the same address)
+    c->stem16_split = -1;
     c->d_qlut = nullptr;
     c->d_qstem_w = nullptr;
     c->d_qstem_lut = nullptr;
@@ -786,6 +788,21 @@ int32_t run_b2b(infur_ctx* c, const ConvLayer& c3, const ConvLayer& n1, const Te
 }
 
 
+// the weight image of the f16-MFMA stems (stem_pool.hip), built on the context's stream the first time a model's stem runs in this
+// form and whenever the weights, their scale or the arithmetic change (model_free forgets it)
+int32_t stem16_image(infur_ctx* c, const float* wt, float w_scale, int split, const void** img) {
+    if (!c->d_stem16) HIPCHK(c, hipMalloc(&c->d_stem16, stem16_image_bytes()));
+    if (c->stem16_wt != wt || c->stem16_scale != w_scale || c->stem16_split != split) {
+        HIPCHK(c, launch_stem16_pack(wt, w_scale, split, c->d_stem16, c->stream));
+        c->stem16_wt = wt;
+        c->stem16_scale = w_scale;
+        c->stem16_split = split;
+        c->mem_gen++;  // (a frame captured as a graph before this must not be replayed without the pack launch)
+    }
+    *img = c->d_stem16;
+    return INFUR_OK;
+}
+
 // ---- quantised models (INFURQ01) ----
 // d_blob resident on the device.  Header and directory are checked by blob_dir.h (host-only); weights are repacked to
 // OHWI with the channel axes padded to the K step of the i8 GEMM (128 bytes: the 64-channel tensors of the stem and layer1
@@ -1073,8 +1090,10 @@ int32_t forward_q(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     if (!c->opt.keep_activations && !c->opt.no_fuse_stem_pool) {
         // QuantizeLinear + QLinearConv + MaxPool in one launch, exact on the f16 MFMA; the 64-channel stem tensor is never written
         RETIF(talloc(c, ph, pw, pair ? 64 : 128, 1, &x));
+        const void* wimg = nullptr;
+        RETIF(stem16_image(c, c->d_qstem_w, 1.0f, 0, &wimg));
         ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool_q", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes());
-        HIPCHK(c, launch_stem_pool_q(d_bgr, h, w, c->d_qstem_w, c->d_qstem_lut, c->d_qstem_bias, stem.d_qmult, stem.y_zp, (uint8_t*)x.p, pair ? 64 : 128,
+        HIPCHK(c, launch_stem_pool_q(d_bgr, h, w, wimg, c->d_qstem_lut, c->d_qstem_bias, stem.d_qmult, stem.y_zp, (uint8_t*)x.p, pair ? 64 : 128,
                                      sh, sw, ph, pw, c->stream));
     } else {
     {
@@ -1164,10 +1183,13 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     // the caller asked for the two-kernel form (options.no_fuse_stem_pool: a test / measurement knob)
     if (!c->opt.keep_activations && !c->opt.no_fuse_stem_pool) {
         RETIF(talloc(c, ph, pw, 64, act_es(c), &x));
+        const void* wimg = nullptr;
+        if (ctx_mode(c) == INFUR_DTYPE_F16) RETIF(stem16_image(c, (const float*)stem.d_w, 1.0f, 0, &wimg));
+        if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT) RETIF(stem16_image(c, (const float*)stem.d_w, stem.w_scale, 1, &wimg));
         ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes(),
                      2.0 * sh * sw * 64 * 147);
         // exact f32 MFMA in the f32 mode; in the f16-rate modes the stem runs on the f16 matrix cores as the conv stack does
-        HIPCHK(c, launch_stem_pool(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, stem_lut(c), x.p, ctx_mode(c), sh, sw, ph, pw,
+        HIPCHK(c, launch_stem_pool(d_bgr, h, w, (const float*)stem.d_w, wimg, stem.d_b, stem_lut(c), x.p, ctx_mode(c), sh, sw, ph, pw,
                                    kSplitActScale, stem.w_scale, c->d_range, c->stream));
     } else {
         {
@@ -1402,6 +1424,7 @@ void infur_ctx_destroy(infur_ctx* c) {
     if (c->d_u8_lut) (void)hipFree(c->d_u8_lut);
     if (c->d_color_lut) (void)hipFree(c->d_color_lut);
     if (c->d_range) (void)hipFree(c->d_range);
+    if (c->d_stem16) (void)hipFree(c->d_stem16);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -158,6 +158,11 @@ struct infur_ctx {
     // INFUR_DTYPE_F32_SPLIT range monitor: [0] max |activation| fed to a GEMM, [1] max |Winograd-domain input|
     // of the last forward (bit patterns of non-negative floats, atomicMax targets); infur_split_range
     unsigned* d_range = nullptr;
+    // the f16-rate / quantised stem's weight image (launch_stem16_pack) and what it was built from: rebuilt when any of it changes
+    void* d_stem16 = nullptr;
+    const void* stem16_wt = nullptr;
+    float stem16_scale = 0.f;
+    int stem16_split = -1;
 };
 
 

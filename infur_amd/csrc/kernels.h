@@ -122,9 +122,12 @@ hipError_t launch_stem_conv7x7(const uint8_t* bgr, int H, int W, const float* wt
 // of two), three MFMAs per product, f32-grade.
 // quantised model: QuantizeLinear + QLinearConv 7x7/2 + u8 max-pool in one launch, exact on the f16 MFMA (stem_pool.hip).
 // wt: [147][64] f32 = the s8 weights, k = (ky * 7 + kx) * 3 + c; lut: [3][256] f32 = q - x_zp (RGB order); out: [PH][PW][128] u8
-hipError_t launch_stem_pool_q(const uint8_t* bgr, int H, int W, const float* wt, const float* lut, const int32_t* q_bias, const float* q_mult,
+hipError_t launch_stem_pool_q(const uint8_t* bgr, int H, int W, const void* wimg, const float* lut, const int32_t* q_bias, const float* q_mult,
                               int y_zp, uint8_t* out, int cstride, int SH, int SW, int PH, int PW, hipStream_t s);
-hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const float* bias, const float* lut, void* out,
+// the f16-rate stems' weights as their finished LDS image (f16 hi (, lo) planes, pads zero), built once per model from wt[147][64] f32
+size_t stem16_image_bytes();
+hipError_t launch_stem16_pack(const float* wt, float w_scale, int split, void* img, hipStream_t s);
+hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const void* wimg, const float* bias, const float* lut, void* out,
                             int mode, int SH, int SW, int PH, int PW, float a_scale, float w_scale, unsigned* amax, hipStream_t s);
 
 // maxpool 3x3 stride 2 pad 1, NHWC f32 / f16 (C % 4 == 0)

@@ -400,7 +400,8 @@ template <typename OutT, bool SPLIT, bool QUANT = false>
 __global__ void __launch_bounds__(256, 2)
     stem_pool16_kernel(const uint8_t* __restrict__ bgr, int H, int W, const float* __restrict__ wt, const float* __restrict__ bias,
                        const float* __restrict__ lut, OutT* __restrict__ out, int SH, int SW, int PH, int PW,
-                       float a_scale, float w_scale, float acc_scale, unsigned* __restrict__ amax, const StemQuant sq = StemQuant{}) {
+                       float a_scale, float w_scale, float acc_scale, unsigned* __restrict__ amax, const u32x4s* __restrict__ wimg,
+                       const StemQuant sq = StemQuant{}) {
     constexpr int NP = SPLIT ? 2 : 1;  // operand planes: hi (, lo)
     __shared__ __attribute__((aligned(16))) float smem[SP_LDS_FLOATS];
     _Float16* patch = reinterpret_cast<_Float16*>(smem);  // [NP][SP_IH][S16_PSTR]
@@ -415,7 +416,19 @@ __global__ void __launch_bounds__(256, 2)
 
     // all global loads first (frame bytes, table, weights), then the LDS fills
     constexpr int NPX = (SP_IH * SP_IW + 255) / 256;
-    constexpr int NWT = (ST_K * 64 + 255) / 256;  // 37 weights per thread
+    // The weights arrive as the finished LDS image -- [NP][64][S16_WSTR] halfs, K pads zero, already f16 (hi, lo) -- built once per
+    // model by stem16_pack_kernel with the very conversions this kernel used to run per workgroup: 37 scattered f32 loads, 37
+    // conversions and 37 two-byte LDS writes per thread were 30 of the 79 us of the quantised 1080p stem (ablation, same box);
+    // now 6 (12: split) 16-byte loads and as many ds_write_b128.
+    constexpr int W_CHUNKS = NP * S16_W_H * 2 / 16;  // 16-byte chunks of the image
+    constexpr int NWC = (W_CHUNKS + 255) / 256;
+    static_assert((NP * S16_PATCH_H * 2) % 16 == 0 && (S16_W_H * 2) % 16 == 0, "the weight planes start on 16-byte boundaries");
+    u32x4s wv[NWC];
+#pragma unroll
+    for (int j = 0; j < NWC; j++) {
+        const int i = tid + 256 * j;
+        wv[j] = i < W_CHUNKS ? wimg[i] : u32x4s{0u, 0u, 0u, 0u};
+    }
     uint8_t pb[NPX][3];
     bool pin[NPX];
 #pragma unroll
@@ -430,8 +443,13 @@ __global__ void __launch_bounds__(256, 2)
         pb[j][2] = p[2];
     }
     const float l0 = lut[tid], l1 = lut[tid + 256], l2 = lut[tid + 512];
-    // zero the operand planes (row / K pads must be finite zeros), publish the table
-    for (int i = tid; i < NP * (S16_PATCH_H + S16_W_H) / 2; i += 256) reinterpret_cast<unsigned*>(patch)[i] = 0u;
+    // zero the patch planes (row pads must be finite zeros), copy the weight image, publish the table
+    for (int i = tid; i < NP * S16_PATCH_H / 2; i += 256) reinterpret_cast<unsigned*>(patch)[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < NWC; j++) {
+        const int i = tid + 256 * j;
+        if (i < W_CHUNKS) reinterpret_cast<u32x4s*>(wsm)[i] = wv[j];
+    }
     slut[tid] = l0;
     slut[tid + 256] = l1;
     slut[tid + 512] = l2;
@@ -441,15 +459,6 @@ __global__ void __launch_bounds__(256, 2)
         plane0[idx] = hi;
         if constexpr (SPLIT) plane0[plane_halfs + idx] = (_Float16)(x - (float)hi);
     };
-#pragma unroll 4
-    for (int j = 0; j < NWT; j++) {  // wt[k][n] f32, k = ky * 21 + (kx * 3 + c)  ->  wsm[n][ky * 24 + (kx * 3 + c)]
-        const int i = tid + 256 * j;
-        if (i < ST_K * 64) {
-            const int k = i >> 6, n = i & 63;
-            const int ky = k / 21, jj = k - ky * 21;
-            put(wsm, S16_W_H, n * S16_WSTR + ky * 24 + jj, wt[i] * w_scale);
-        }
-    }
 #pragma unroll
     for (int j = 0; j < NPX; j++) {
         const int i = tid + 256 * j;
@@ -517,26 +526,57 @@ __global__ void __launch_bounds__(256, 2)
     stem_stage_and_pool<OutT, QUANT>(smem, acc, pidx, half, acc_scale, bias, out, py0, px0, sy0, sx0, SH, SW, PH, PW, amax, sq);
 }
 
-hipError_t launch_stem_pool_q(const uint8_t* bgr, int H, int W, const float* wt, const float* lut, const int32_t* q_bias, const float* q_mult,
-                              int y_zp, uint8_t* out, int cstride, int SH, int SW, int PH, int PW, hipStream_t s) {
-    if (cstride != 64 && cstride != 128) return hipErrorInvalidValue;
-    dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
-    hipLaunchKernelGGL((stem_pool16_kernel<unsigned char, false, true>), grid, dim3(256), 0, s, bgr, H, W, wt, (const float*)nullptr, lut, out, SH, SW,
-                       PH, PW, 1.0f, 1.0f, 1.0f, (unsigned*)nullptr, StemQuant{q_bias, q_mult, y_zp, cstride});
+// The weight image of stem_pool16_kernel, built once per model: wt[k][n] f32 (k = ky * 21 + kx * 3 + c) -> img[plane][n][ky * 24 +
+// kx * 3 + c] halfs, hi = f16(w * w_scale) (, lo = f16(w * w_scale - hi)), pads zero.  Same operations, same rounding (FP16_OVFL
+// set as in the consumer) as the per-workgroup conversion it replaces: the consumer's results do not change by a bit.
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) stem16_pack_kernel(const float* __restrict__ wt, float w_scale, _Float16* __restrict__ img) {
+    constexpr int NP = SPLIT ? 2 : 1;
+    if constexpr (SPLIT) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < NP * S16_W_H; i += gridDim.x * 256) img[i] = (_Float16)0.f;
+    __syncthreads();  // (one block: launch_stem16_pack)
+    for (int i = threadIdx.x; i < ST_K * 64; i += 256) {
+        const int k = i >> 6, n = i & 63;
+        const int ky = k / 21, jj = k - ky * 21;
+        const float x = wt[i] * w_scale;
+        const _Float16 hi = (_Float16)x;
+        img[n * S16_WSTR + ky * 24 + jj] = hi;
+        if constexpr (SPLIT) img[S16_W_H + n * S16_WSTR + ky * 24 + jj] = (_Float16)(x - (float)hi);
+    }
+}
+
+size_t stem16_image_bytes() { return (size_t)2 * S16_W_H * 2; }
+
+hipError_t launch_stem16_pack(const float* wt, float w_scale, int split, void* img, hipStream_t s) {
+    if (split)
+        hipLaunchKernelGGL(stem16_pack_kernel<true>, dim3(1), dim3(256), 0, s, wt, w_scale, (_Float16*)img);
+    else
+        hipLaunchKernelGGL(stem16_pack_kernel<false>, dim3(1), dim3(256), 0, s, wt, w_scale, (_Float16*)img);
     return hipGetLastError();
 }
 
-hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const float* bias, const float* lut, void* out,
+hipError_t launch_stem_pool_q(const uint8_t* bgr, int H, int W, const void* wimg, const float* lut, const int32_t* q_bias, const float* q_mult,
+                              int y_zp, uint8_t* out, int cstride, int SH, int SW, int PH, int PW, hipStream_t s) {
+    if (cstride != 64 && cstride != 128) return hipErrorInvalidValue;
+    dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
+    hipLaunchKernelGGL((stem_pool16_kernel<unsigned char, false, true>), grid, dim3(256), 0, s, bgr, H, W, (const float*)nullptr, (const float*)nullptr, lut,
+                       out, SH, SW, PH, PW, 1.0f, 1.0f, 1.0f, (unsigned*)nullptr, (const u32x4s*)wimg, StemQuant{q_bias, q_mult, y_zp, cstride});
+    return hipGetLastError();
+}
+
+// (wimg: the f16-rate modes' weight image, launch_stem16_pack -- nullptr only where the f32 MFMA stem runs)
+hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, const void* wimg, const float* bias, const float* lut, void* out,
                             int mode, int SH, int SW, int PH, int PW, float a_scale, float w_scale, unsigned* amax, hipStream_t s) {
     dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
     static const int abl = getenv("INFUR_STEM_ABL") ? atoi(getenv("INFUR_STEM_ABL")) : 0;
     static const int exact = getenv("INFUR_STEM_F32") ? atoi(getenv("INFUR_STEM_F32")) : 0;  // measurement hook: f32 MFMA stem in every mode
+    if ((mode == 1 || mode == 2) && !exact && !wimg) return hipErrorInvalidValue;
     if (mode == 1 && !exact)
         hipLaunchKernelGGL((stem_pool16_kernel<_Float16, false>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (_Float16*)out, SH, SW, PH,
-                           PW, 1.0f, 1.0f, 1.0f, amax);
+                           PW, 1.0f, 1.0f, 1.0f, amax, (const u32x4s*)wimg);
     else if (mode == 2 && !exact)
         hipLaunchKernelGGL((stem_pool16_kernel<float, true>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW,
-                           a_scale, w_scale, 1.0f / (a_scale * w_scale), amax);
+                           a_scale, w_scale, 1.0f / (a_scale * w_scale), amax, (const u32x4s*)wimg);
     else if (mode == 1)
         hipLaunchKernelGGL(stem_pool_kernel<_Float16>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (_Float16*)out, SH, SW, PH, PW, amax);
     else if (abl == 1)
