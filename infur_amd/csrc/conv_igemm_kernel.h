@@ -726,7 +726,22 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
             qb[t] = 0;
             qm[t] = 0.f;
         }
-        if constexpr (I8) {
+        if constexpr (Q8) {
+            // (a u8 output has Cout % 16 == 0 and n is a multiple of 16: the lane's 16 channels exist together -- eight 16-byte loads
+            //  instead of 32 guarded dword loads at the head of every epilogue)
+            if (n_ok) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++) {
+                    const qi4 b4 = *reinterpret_cast<const qi4*>(a.q_bias + n + 4 * t4);
+                    const qf4 m4 = *reinterpret_cast<const qf4*>(a.q_mult + n + 4 * t4);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        qb[4 * t4 + t] = b4[t];
+                        qm[4 * t4 + t] = m4[t];
+                    }
+                }
+            }
+        } else if constexpr (I8) {
 #pragma unroll
             for (int t = 0; t < CPL; t++)
                 if (n + t < a.Cout) {
