@@ -22,8 +22,13 @@ from infur_amd import _lib  # noqa: E402
 from infur_amd import processors as P  # noqa: E402
 from infur_amd import weights as W  # noqa: E402
 
-c = P.Context(device=0, dtype=dtype)
-P.Model(c).control(P.ModelCmd.LoadBlob(W.synth_blob(depth=50)))
+c = P.Context(device=0, dtype="f32" if dtype == "i8" else dtype)
+if dtype == "i8":  # the quantised model (its own arithmetic: the context's dtype does not matter)
+    from infur_amd import quantize
+
+    P.Model(c).control(P.ModelCmd.LoadBlob(quantize.synth_qblob(depth=50)))
+else:
+    P.Model(c).control(P.ModelCmd.LoadBlob(W.synth_blob(depth=50)))
 fp = P.FramePath(c)
 fr = W.synth_frame(1080, 1920)
 for _ in range(3):
