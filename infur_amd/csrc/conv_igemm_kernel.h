@@ -578,14 +578,18 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     // 16 channels per lane: its 16-byte stores and residual loads are a quarter of the instructions of the 4-byte form
     // (which ran the quantised 1x1 expansions at 2 TB/s, instruction-bound in the epilogue)
     constexpr bool Q8 = I8 && std::is_same<OutT, unsigned char>::value;
-    constexpr int CPL = Q8 ? 16 : 4;
+    // f16 -> f16: 8 channels per lane (two float4 of the staging row, one 16-byte store / residual load): half the epilogue's
+    // iterations of the 4-channel form, whose 8-byte stores were 12 % of the 4K layer3 conv2's workgroup life (scripts/ktrace.py)
+    constexpr bool H8 = std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value;
+    constexpr int CPL = Q8 ? 16 : (H8 ? 8 : 4);
     constexpr int LPR = TN * 32 / CPL;
     constexpr int RPI = 64 / LPR;
     const int e_row = lane / LPR, e_col = lane % LPR;
     const int e_n = n0 + wn * TN * 32 + e_col * CPL;
     const T* res = static_cast<const T*>(a.res);
     using ResV = typename std::conditional<std::is_same<T, float>::value, float4,
-                                           typename std::conditional<Q8, u32x4, typename std::conditional<I8, unsigned, f16x4>::type>::type>::type;
+                                           typename std::conditional<Q8, u32x4, typename std::conditional<I8, unsigned,
+                                           typename std::conditional<H8, f16x8, f16x4>::type>::type>::type>::type;
     ResV rres[RESPF ? TM : 1][RESPF ? 32 / RPI : 1];
     if constexpr (RESPF) {
 #pragma unroll
@@ -697,7 +701,7 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     // split modes: one accumulator scale per launch, or one per batched problem (the Winograd planes carry their own weight scale)
     const float acc_scale = a.acc_scale_b ? a.acc_scale_b[bidx] : a.acc_scale;
     const bool has_bias = a.bias != nullptr;
-    const bool vec_ok = I8 || (a.Cout & 3) == 0;  // (the quantised epilogue guards its 4 channels one by one: 21-class logits too)
+    const bool vec_ok = I8 || (a.Cout & (CPL - 1)) == 0;  // (the quantised epilogue guards its 4 channels one by one: 21-class logits too)
 #ifdef KTRACE
     const unsigned long long kt_epi = __builtin_amdgcn_s_memtime();
     struct KtEnd {
@@ -717,8 +721,11 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
         const int rrow = e_row, rcol = e_col;
         const int n = e_n;
         const bool n_ok = n < a.Cout;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_bias && n_ok) bv = *reinterpret_cast<const float4*>(a.bias + n);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bv2 = bv;
+        if (has_bias && n_ok) {
+            bv = *reinterpret_cast<const float4*>(a.bias + n);
+            if constexpr (H8) bv2 = *reinterpret_cast<const float4*>(a.bias + n + 4);
+        }
         int qb[CPL];    // I8: folded bias and requantisation multiplier of this lane's channels
         float qm[CPL];
 #pragma unroll
@@ -836,6 +843,27 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                             }
                         }
                     }
+                } else if constexpr (H8) {
+                    if (m < M && n_ok) {  // the same steps per value as the 4-channel form below: + bias, + residual, ReLU, round to f16
+                        const float4 v2 = *reinterpret_cast<const float4*>(stage + row * ROWB + rcol * (CPL * 4) + 16);
+                        float x[8] = {v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w, v2.x + bv2.x, v2.y + bv2.y, v2.z + bv2.z, v2.w + bv2.w};
+                        if (RESPF || res) {
+                            ResV rv;
+                            if constexpr (RESPF)
+                                rv = rres[i][it];
+                            else
+                                rv = rlate[it];
+#pragma unroll
+                            for (int t = 0; t < 8; t++) x[t] += (float)rv[t];
+                        }
+                        if (a.relu) {
+#pragma unroll
+                            for (int t = 0; t < 8; t++) x[t] = fmaxf(x[t], 0.f);
+                        }
+                        const f16x8 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3],
+                                          (_Float16)x[4], (_Float16)x[5], (_Float16)x[6], (_Float16)x[7]};
+                        *reinterpret_cast<f16x8*>(out + (size_t)m * a.Cout + n) = hv;
+                    }
                 } else if (m < M && n_ok) {
                     const size_t o = (size_t)m * a.Cout + n;
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -948,7 +976,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
         // residual only ever enters a 1x1 conv, so this is a G1 form
         constexpr bool kCanPf = (BM / WM) * (BN / WN) <= 64 * 64;
         if constexpr (kCanPf) {
-            if (a.res && g1 && (a.Cout & 3) == 0) return launch_cfg_g<T, OutT, SPLIT, FP8X, true, true, false, BM, BN, WM, WN, NBUF>(a, s);
+            // (the prefetch reads a lane's whole channel group: 4 channels, 8 in the f16 -> f16 epilogue)
+            constexpr int kGroup = (std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value) ? 8 : 4;
+            if (a.res && g1 && (a.Cout & (kGroup - 1)) == 0) return launch_cfg_g<T, OutT, SPLIT, FP8X, true, true, false, BM, BN, WM, WN, NBUF>(a, s);
         }
     } else if (a.in2) {
         return hipErrorInvalidValue;
