@@ -69,6 +69,9 @@ static const CfgInfo kCfgs[] = {
     // configuration 15 of the quantised mode with the N tiles of an M tile shared out over several workgroups (conv1x1_q8.hip):
     // M = 32400 alone gives 254 workgroups for 256 CUs
     {256, 128, {"conv1x1_f32<256,areg,nsplit>", "conv1x1_f16<256,areg,nsplit>", "conv1x1_f32s<256,areg,nsplit>"}},
+    // (late round 3: a 128x32 tile of two waves for the logit convs -- M = 32400 gives only 127 workgroups of 256 rows for 256 CUs --
+    // is bit-identical and 2 us faster per launch (f32 28.8 -> 26.6 / 20.8 -> 18.6 us, i8 10.6 -> 9.5): the launch is latency-bound,
+    // not short of workgroups; not worth a configuration.)
     // (a RING OF THREE LDS images with a counted vmcnt -- two K steps of DMA in flight across the barrier -- was measured on
     // 256x128, 128x256 and 128x128 tiles for the HBM-bound 1x1 convs: better than the two-image form of the same tile
     // (layer3 conv1 at 4K: 0.123 -> 0.100 ms) but never better than 256x256 with two images (0.087) or the register form
