@@ -396,7 +396,10 @@ hipError_t launch_form(const B2bArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         if (known) attr_done[dev].store(true, std::memory_order_release);
     }
-    static const int dma_phase = getenv("INFUR_B2B_DMA") ? atoi(getenv("INFUR_B2B_DMA")) : 2;
+    // (0 / 1 / 2 only: any other value would leave the late waves' pieces un-issued -- which, as an ablation, runs the 4K layer3 pair in
+    //  157 instead of 188 us with HALF the weight / residual pieces missing: the step is bound by the DMA ingest, not by its MFMAs)
+    static const int dma_env = getenv("INFUR_B2B_DMA") ? atoi(getenv("INFUR_B2B_DMA")) : 2;
+    static const int dma_phase = dma_env < 0 || dma_env > 2 ? 2 : dma_env;
     hipLaunchKernelGGL(k, dim3(mtiles), dim3(NW * 64), B2bLds<KS>::TOTAL, s, a, mtiles, dma_phase);
     return hipGetLastError();
 }
