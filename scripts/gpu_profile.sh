@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --dtype $DT --no-split --no-side --no-cpu-baseline $EXTRA > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"
 kill $SMI 2>/dev/null
-# The default command keeps two frames in flight (two contexts): kernels of the two streams time-share the chip, so the
+# The default command keeps several frames in flight (--contexts-per-gpu, default 3): kernels of the streams time-share the chip, so the
 # trace above gives per-kernel wall time UNDER SHARING.  The solo trace (one context, strictly one kernel at a time) is
 # the one whose average durations must agree with the HIP events of bench.py's roofline frame, which also runs alone.
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_solo -- python $R/bench.py --dtype $DT --contexts-per-gpu 1 --no-split --no-side --no-cpu-baseline $EXTRA > $OUT/bench_trace_solo.json 2> $OUT/trace_solo.err
