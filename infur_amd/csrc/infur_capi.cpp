@@ -271,10 +271,13 @@ int conv_out(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1
 // 4x) and 1.9x instead of 2.27x the tensor in transform traffic.  Measured against the f32 CPU oracle (scripts/
 // f6_split_check.py): per-layer worst 1.07e-5 (F(4x4): 1.12e-5), whole-network logits 6-7e-6 in the exact-f32 mode
 // (F(4x4): 4-5e-6) and 4-6e-6 in the split mode (3e-6) -- north_star's budget is 1e-3.
+// INFUR_DTYPE_F32_SPLIT_FP8 (bf8 cross terms, products exact to ~2^-13) defaults to F(4x4): the F(6x6) output transform
+// amplifies the product error -- hostile parameters, 1080p, worst per-element error 1.03e-2 with F(6x6) against 6.95e-3 with
+// F(4x4) (max-abs 1.4e-4 / 1.1e-4; profiles/r04_hostile_probe.log) -- for 7 % of that mode's frame time.
 inline int wino_mt(const infur_ctx* c) {
     const uint32_t t = c->opt.winograd_tile;
     if (t == 2 || t == 4 || t == 6) return (int)t;
-    return 6;
+    return c->opt.compute_dtype == INFUR_DTYPE_F32_SPLIT_FP8 ? 4 : 6;
 }
 inline int wino_planes(const infur_ctx* c) { return (wino_mt(c) + 2) * (wino_mt(c) + 2); }
 

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/infur_hip.h"
@@ -64,6 +65,15 @@ struct ConvLayer {
     void* d_w2 = nullptr;
     int32_t* d_qbias2 = nullptr;
     float* d_qmult2 = nullptr;
+
+    // EVERY device pointer of the layer goes through `f` (void* -> void*): the one place a replica of the model re-bases its
+    // pointers into its own weight arena (infur_multi.cpp: adopt_model).  A new pointer field belongs in this list.
+    template <class F>
+    void map_device_pointers(F&& f) {
+        auto ap = [&](auto*& p) { p = static_cast<std::remove_reference_t<decltype(p)>>(f((void*)p)); };
+        ap(d_w); ap(d_b); ap(d_u); ap(d_uacc); ap(d_wcat); ap(d_bcat); ap(d_w3i);
+        ap(d_qbias); ap(d_qmult); ap(d_w2); ap(d_qbias2); ap(d_qmult2);
+    }
 };
 
 struct QAddParams {  // com.microsoft QLinearAdd of one bottleneck: C = A (conv3) + B (identity / downsample)

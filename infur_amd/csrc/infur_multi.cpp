@@ -277,17 +277,7 @@ void adopt_model(infur_ctx* dst, const infur_ctx* root, void* d_weights) {
     uint8_t* nb = (uint8_t*)d_weights;
     auto rebase = [&](const void* p) -> void* { return p ? nb + ((const uint8_t*)p - rb) : nullptr; };
     dst->convs = root->convs;
-    for (ConvLayer& L : dst->convs) {
-        L.d_w = rebase(L.d_w);
-        L.d_b = (float*)rebase(L.d_b);
-        L.d_u = (float*)rebase(L.d_u);
-        L.d_wcat = rebase(L.d_wcat);
-        L.d_bcat = (float*)rebase(L.d_bcat);
-        L.d_w3i = rebase(L.d_w3i);
-        L.d_uacc = (float*)rebase(L.d_uacc);
-        L.d_qbias = (int32_t*)rebase(L.d_qbias);
-        L.d_qmult = (float*)rebase(L.d_qmult);
-    }
+    for (ConvLayer& L : dst->convs) L.map_device_pointers(rebase);  // every pointer field, incl. the pixel-pair copies
     dst->d_weights = d_weights;
     dst->weight_bytes = root->weight_bytes;
     dst->depth = root->depth;

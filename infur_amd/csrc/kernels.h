@@ -58,8 +58,9 @@ struct ConvArgs {
 // mode 1: f16 operands, f32 accumulation (Cin % 64 == 0), output f16 or (out_f32) f32;
 // mode 2: f32 tensors, each value split into an f16 hi + lo pair while it is staged, three f16
 // MFMAs per product, f32 accumulation (Cin % 32 == 0) -- f32-grade results at f16 matrix rate / 3.
-// mode 3: as mode 2, but the two cross terms hi * lo run on the fp8 (e4m3) MX MFMA: 2 MFMA units per product instead of
-// 3, products exact to ~2^-14 (logits ~4e-5 from f32); weights prepared with launch_split_weights(fp8_cross = 1).
+// mode 3: as mode 2, but the two cross terms hi * lo run on the bf8 (OCP e5m2) MX MFMA: 2 MFMA units per product instead of
+// 3, products exact to ~2^-13 whatever the tensors' dynamic range (e5m2 has f16's exponent range: no scales; round 3 used
+// e4m3 under per-tensor scales, which heavy-tailed weights broke); weights prepared with launch_split_weights(fp8_cross = 1).
 // mode 4: quantised (ConvArgs::q_*): u8 NHWC activations, s8 OHWI weights (Cin % 128 == 0), output u8 or (out_f32) dequantised f32.
 // cfg: tile configuration index (conv_igemm_num_configs), -1 = built-in heuristic.  Every
 // configuration produces bit-identical results; only the speed differs.
@@ -141,7 +142,7 @@ hipError_t launch_repack_oihw_to_ohwi(const float* src, void* dst, int f16, int 
 // split: in place, every 32 consecutive f32 (one 128-byte K-step row chunk) become
 // [32 x f16 hi][32 x f16 lo] of w * scale, hi = rne(w*scale), lo = rne(w*scale - hi).
 hipError_t launch_absmax(const float* w, size_t n, float* out, hipStream_t s);
-// fp8_cross: the [f16 hi][e4m3 lo * 2^5][e4m3 hi * 2^-6] row form of conv_igemm mode 3 instead of [f16 hi][f16 lo]
+// fp8_cross: the [f16 hi][e5m2 lo * 2^11][e5m2 hi] row form of conv_igemm mode 3 instead of [f16 hi][f16 lo]
 hipError_t launch_split_weights(float* w, size_t n, float scale, int fp8_cross, hipStream_t s);
 // two-source GEMM weights (one-off at load): out[r] = a[r] ++ b[r] for `rows` rows of a_bytes / b_bytes
 // (multiples of 16); sum[i] = x[i] + y[i]

@@ -334,6 +334,12 @@ int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, 
         else if (f == 12) { ValueInfo vi; if (!parse_value_info(s, l, vi)) { err = "malformed graph output"; return 1; } outputs.push_back(std::move(vi)); }
     }
     if (!gr.ok) { err = "malformed GraphProto"; return 1; }
+    // every NodeProto names at least one output, every operator but Constant at least one input: the walkers index out[0] / in[0]
+    // of the nodes they reach (a MaxPool or QuantizeLinear without outputs used to be a SIGSEGV behind the C ABI -- ADVICE r3)
+    for (const Node& n : g.nodes) {
+        if (n.out.empty()) { err = "malformed graph: a " + (n.op.empty() ? std::string("node") : n.op) + " node has no outputs"; return 1; }
+        if (n.in.empty() && n.op != "Constant") { err = "malformed graph: a " + (n.op.empty() ? std::string("node") : n.op) + " node has no inputs"; return 1; }
+    }
     // input 0: the reference's infer_img_pre_proc (predict_onnx.rs:223-265); the int8 zoo file keeps a Float NCHW input
     const ValueInfo* in0 = nullptr;
     for (auto& vi : inputs)

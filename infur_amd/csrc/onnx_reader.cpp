@@ -137,6 +137,13 @@ int onnx_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, On
         }
     }
 
+    // ---- structure: every NodeProto names at least one output, every operator but Constant at least one input (the walkers
+    // below index out[0] / in[0] of the nodes they reach; a file that drops them is malformed, never a crash -- ADVICE r3) ----
+    for (auto& n : nodes) {
+        if (n.out.empty()) { err = "malformed graph: a " + (n.op.empty() ? std::string("node") : n.op) + " node has no outputs"; return 1; }
+        if (n.in.empty() && n.op != "Constant") { err = "malformed graph: a " + (n.op.empty() ? std::string("node") : n.op) + " node has no inputs"; return 1; }
+    }
+
     // ---- edges ----
     // Constant nodes are initializers in all but name (old exporters write weights that way)
     for (auto& n : nodes)

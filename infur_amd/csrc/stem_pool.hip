@@ -733,29 +733,29 @@ __global__ void split_weights_kernel(float* __restrict__ w, size_t groups, float
     for (int q = 0; q < 4; q++) o[4 + q] = lo[q];
 }
 
-// the fp8 cross-term form (conv_igemm SPLIT == 2): 32 f32 in, in place [32 x f16 hi][32 x e4m3 of lo * 2^5][32 x e4m3 of
-// hi * 2^-6].  With max |w * scale| in [2^13, 2^14) both fp8 planes stay below 256 (e4m3 max 448); clamped anyway, the
-// conversion gives NaN beyond the range.
+// the bf8 cross-term form (conv_igemm mode 3): 32 f32 in, in place [32 x f16 hi][32 x e5m2 of lo * 2^11][32 x e5m2 of hi].
+// With max |w * scale| in [2^13, 2^14) both planes stay below 2^14 (e5m2 max 57344); clamped anyway (a weight tensor holding
+// inf / NaN must not turn into a different kind of garbage here).
 __global__ void split_weights_fp8_kernel(float* __restrict__ w, size_t groups, float scale) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups) return;
     f32x8* p = reinterpret_cast<f32x8*>(w + g * 32);
     h16x8 hi[4];
     int lo8[8], hi8[8];
-    auto cl = [](float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); };
+    auto cl = [](float v) { return __builtin_amdgcn_fmed3f(v, -57344.0f, 57344.0f); };
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const f32x8 x = p[q] * scale;
         hi[q] = __builtin_convertvector(x, h16x8);
         const f32x8 hf = __builtin_convertvector(hi[q], f32x8);
-        const f32x8 l = (x - hf) * 32.0f, hs = hf * 0.015625f;
+        const f32x8 l = (x - hf) * 2048.0f, hs = hf;
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             int a = 0, b = 0;
-            a = __builtin_amdgcn_cvt_pk_fp8_f32(cl(l[4 * t]), cl(l[4 * t + 1]), a, false);
-            a = __builtin_amdgcn_cvt_pk_fp8_f32(cl(l[4 * t + 2]), cl(l[4 * t + 3]), a, true);
-            b = __builtin_amdgcn_cvt_pk_fp8_f32(cl(hs[4 * t]), cl(hs[4 * t + 1]), b, false);
-            b = __builtin_amdgcn_cvt_pk_fp8_f32(cl(hs[4 * t + 2]), cl(hs[4 * t + 3]), b, true);
+            a = __builtin_amdgcn_cvt_pk_bf8_f32(cl(l[4 * t]), cl(l[4 * t + 1]), a, false);
+            a = __builtin_amdgcn_cvt_pk_bf8_f32(cl(l[4 * t + 2]), cl(l[4 * t + 3]), a, true);
+            b = __builtin_amdgcn_cvt_pk_bf8_f32(cl(hs[4 * t]), cl(hs[4 * t + 1]), b, false);
+            b = __builtin_amdgcn_cvt_pk_bf8_f32(cl(hs[4 * t + 2]), cl(hs[4 * t + 3]), b, true);
             lo8[2 * q + t] = a;
             hi8[2 * q + t] = b;
         }

@@ -15,7 +15,8 @@ from infur_amd import weights as W  # noqa: E402
 h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2160, 3840)
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 101
 dtype = sys.argv[4] if len(sys.argv) > 4 else "f16"
-c = None if dtype == "i8" else P.Context(device=0, dtype=dtype, profile=True)
+tile = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # Winograd output tile (0 = default)
+c = None if dtype == "i8" else P.Context(device=0, dtype=dtype, profile=True, winograd_tile=tile)
 if dtype == "i8":
     from infur_amd import quantize
     c = P.Context(device=0, profile=True)
@@ -41,6 +42,6 @@ for it in range(7):
         blk = "first" if n.startswith("backbone.layer") and parts[2] == "0" else "rest"
         acc.setdefault(f"{grp} {role} {blk} {r['kernel']}", []).append(r["ms"])
 env = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("INFUR_"))
-print(f"[{env}] {w}x{h} r{depth} {dtype}: frame kernels {np.median(tot):.3f} ms")
+print(f"[{env}] {w}x{h} r{depth} {dtype} tile {tile}: frame kernels {np.median(tot):.3f} ms")
 for k in sorted(acc):
     print(f"   {k:90s} median {np.median(acc[k]) * 1e3:7.1f} us  (n={len(acc[k])})")

@@ -26,8 +26,10 @@ for (h, w) in sizes:
     ref, ref_aux = ref64.forward_lowres(co.pack_normalize(fr), taps=taps)
     ref = ref.numpy()
     print(f"== {w}x{h}: |logits| max {np.abs(ref).max():.3g}")
-    for dtype in ("f32", "f32s", "f32x"):
+    for dtype in ("f32", "f32s", "f32x", "f16"):
         for tile, name in ((6, "F(6x6)"), (4, "F(4x4)"), (2, "F(2x2)"), (-1, "direct")):
+            if dtype == "f16" and tile >= 0:
+                continue  # (the f16 mode runs every 3x3 directly)
             c = Context(device=0, dtype=dtype, keep_activations=True, winograd_tile=max(tile, 0),
                         winograd_min_cin=0xFFFFFFFF if tile < 0 else 0)
             m = Model(c).control(ModelCmd.LoadBlob(blob))
@@ -48,7 +50,7 @@ for (h, w) in sizes:
                     wrel, wrname = er, spec.name
             e, er = H.errors(lo, ref)
             extra = ""
-            if dtype != "f32":
+            if dtype in ("f32s", "f32x"):
                 a, wm, sat = c.split_range()
                 extra = f" | range act {a:.3g} wino {wm:.3g} sat {sat}"
             print(f"{dtype:5s} {name:7s} logits {e:.2e} / {er:.2e}   per-layer worst {worst:.2e} ({wname}) / {wrel:.2e} ({wrname}){extra}")

@@ -95,6 +95,10 @@ static bool parse(bool onnx, const uint8_t* d, size_t len, std::string* err) {
 
 // ---- where the structure of an ONNX file lives: everything except the interior of the big length-delimited payloads ----
 struct Range { size_t lo, hi; };
+// tag bytes of the `input` (field 1) / `output` (field 2) strings of every NodeProto: turning one into the tag of an unknown
+// length-delimited field (15) makes the node LOSE that input / output while the file stays well-formed protobuf -- the shape
+// behind ADVICE r3's two crashes (a MaxPool / QuantizeLinear without outputs), which random byte noise almost never produces
+static std::vector<size_t> node_io_tags;
 static bool rd_varint(const uint8_t* d, size_t len, size_t* p, uint64_t* v) {
     *v = 0;
     for (int sh = 0; sh < 64 && *p < len; sh += 7) {
@@ -106,10 +110,11 @@ static bool rd_varint(const uint8_t* d, size_t len, size_t* p, uint64_t* v) {
 }
 // walks one message; descends into length-delimited fields listed in `into` (field numbers per depth), records every byte
 // range that is NOT the interior of a payload longer than 256 bytes
-static void walk(const uint8_t* d, size_t lo, size_t hi, int depth, std::vector<Range>* out) {
+static void walk(const uint8_t* d, size_t lo, size_t hi, int depth, std::vector<Range>* out, bool in_node = false) {
     size_t p = lo, run = lo;
     while (p < hi) {
         uint64_t key, v;
+        const size_t tag_pos = p;
         if (!rd_varint(d, hi, &p, &key)) break;
         const int wt = (int)(key & 7), field = (int)(key >> 3);
         if (wt == 0) { if (!rd_varint(d, hi, &p, &v)) break; }
@@ -118,9 +123,10 @@ static void walk(const uint8_t* d, size_t lo, size_t hi, int depth, std::vector<
         else if (wt == 2) {
             if (!rd_varint(d, hi, &p, &v) || v > hi - p) break;
             const bool sub = (depth == 0 && field == 7) || (depth == 1 && (field == 1 || field == 5 || field == 11 || field == 12));  // graph; node, initializer, input, output
+            if (in_node && (field == 1 || field == 2) && p - tag_pos == 2) node_io_tags.push_back(tag_pos);  // (one-byte tag, one-byte length)
             if (sub) {
                 out->push_back({run, p});
-                walk(d, p, p + (size_t)v, depth + 1, out);
+                walk(d, p, p + (size_t)v, depth + 1, out, depth == 1 && field == 1);
                 run = p + (size_t)v;
             } else if (v > 256) {  // raw_data and friends: keep 4 bytes at either end, skip the interior
                 out->push_back({run, p + 4});
@@ -173,14 +179,26 @@ int main(int argc, char** argv) {
     const uint8_t extremes[] = {0x00, 0x01, 0x7f, 0x80, 0xff, 0xfe, 0x0a, 0x12};
     for (long it = 0; it < n_mut; it++) {
         const uint64_t r = rnd();
-        const int kind = (int)(r % 10);
+        int kind = (int)(r % 11);
+        if (kind == 10 && (!onnx || node_io_tags.empty())) kind = 3;
         const size_t span = (r >> 8) & 1 ? full.size() : (full.size() < 65536 ? full.size() : 65536);
         // ONNX: 15 of 16 mutations inside the structural byte ranges (node / tensor / value-info headers and the edges of the
         // payloads), the rest anywhere; blob: half in the first 64 KB (header + directory), half anywhere
         const size_t pos = onnx && hot_bytes && ((r >> 12) & 15) ? hot_pos(rnd()) : (size_t)(rnd() % span);
         err.clear();
         bool ok;
-        if (kind == 0) {  // truncation: the cut-off tail is poisoned, so a read past the new end is an ASan report
+        if (kind == 10) {  // structural: one or two nodes lose an input / output (tag -> unknown field 15, same length)
+            size_t at[2];
+            uint8_t sv[2];
+            const int n = 1 + (int)(rnd() & 1);
+            for (int k = 0; k < n; k++) {
+                at[k] = node_io_tags[(size_t)(rnd() % node_io_tags.size())];
+                sv[k] = full[at[k]];
+                full[at[k]] = 0x7a;
+            }
+            ok = parse(onnx, full.data(), full.size(), &err);
+            for (int k = n - 1; k >= 0; k--) full[at[k]] = sv[k];
+        } else if (kind == 0) {  // truncation: the cut-off tail is poisoned, so a read past the new end is an ASan report
             const size_t cut = (r >> 9) & 1 ? pos : full.size() - 1 - (size_t)(rnd() % (full.size() < 4096 ? full.size() : 4096));
             const size_t pl = (cut + 7) & ~(size_t)7;  // (poisoning is 8-byte granular: the first partial granule stays readable)
             if (pl < full.size()) ASAN_POISON_MEMORY_REGION(full.data() + pl, full.size() - pl);

@@ -3,7 +3,7 @@ distribution (uniform U(-a, a), BN gamma in [0.5, 1.5]); pretrained BN-folded we
 orders of magnitude apart, and the default f32 path runs 14 convs as Winograd F(6x6, 3x3), whose error grows with the dynamic
 range of weights and activations.  tests/hostile.py builds such a parameter set (1 % outliers at 30 sigma, per-channel scales
 over 3.2 decades as an exact reparametrisation, always-on channels) and a frame with saturated regions; the HIP modes f32
-(F(6x6) default), f32s and f32x are graded per layer at 320x240 and on the whole 1920x1080 frame against a FLOAT64 evaluation of
+(F(6x6) default), f32s, f32x (F(4x4) default) and -- for the record -- the reduced-precision f16 mode are graded per layer at 320x240 and on the whole 1920x1080 frame against a FLOAT64 evaluation of
 the network (torch CPU), with two metrics: max-abs error / max-abs reference (the reading tests/test_gpu_parity.py uses)
 and the worst per-element relative error over the elements with |ref| > 1e-2 max |ref|.  north_star's bar: logits within 1e-3."""
 import ctypes as C
@@ -21,17 +21,23 @@ from infur_amd.processors import Context, FramePath, Model, ModelCmd
 
 pytestmark = pytest.mark.gpu
 
-# Measured on an MI355X (scripts/hostile_probe.py prints every mode x Winograd tile; gpurun_out/hostile_probe2.log):
+# Measured on an MI355X (scripts/hostile_probe.py prints every mode x Winograd tile; profiles/r04_hostile_probe.log):
 #   mode   logits 1080p (max-abs/max-abs | per-element)   per-layer worst
-#   f32    3.8e-06 | 2.1e-04                               9.1e-06      exact f32 MFMA, F(6x6): as good as direct convs (4.1e-06)
-#   f32s   1.6e-05 | 1.0e-03                               3.1e-05      F(6x6); direct convs 9.4e-06.  BEFORE round 3's per-plane
+#   f32    3.8e-06 | 2.1e-04                               8.3e-06      exact f32 MFMA, F(6x6): as good as direct convs (4.1e-06)
+#   f32s   1.6e-05 | 1.0e-03                               2.6e-05      F(6x6); direct convs 9.4e-06.  BEFORE round 3's per-plane
 #                                                                      weight scales: 8.9e-03 .. 1.6e-02 -- outside the bar, found by this test
-#   f32x   7.1e-04 | 5.1e-02                               1.8e-03      the fp8 cross terms (products exact to ~2^-14) do not like
-#                                                                      heavy tails: direct convs give 5.7e-04 too; inside 1e-3, with little room
-# The logits bar is north_star's 1e-3 for every mode; the per-layer bars are the measured values with ~3x head-room.
-LOGIT_BAR = {"f32": 1e-3, "f32s": 1e-3, "f32x": 1e-3}
-LAYER_BAR = {"f32": 3e-5, "f32s": 1e-4, "f32x": 5e-3}
-ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 0.3}  # worst per-element relative error over |ref| > 1e-2 max |ref|
+#   f32x   1.1e-04 | 7.0e-03                               2.7e-04      round 4: bf8 (e5m2) cross terms, F(4x4) default (F(6x6): 1.4e-04 |
+#                                                                      1.0e-02; direct 1.0e-04 | 8.2e-03).  Round 3's e4m3 cross terms under
+#                                                                      static scales: 7.1e-04 | 5.1e-02 -- heavy tails clamp and flush e4m3
+#   f16    1.9e-03 | 1.3e-01                               4.5e-03      for the record: the reduced-precision mode (configs[4]'s arithmetic)
+#                                                                      is OUTSIDE north_star's 1e-3; its own stated bar is 5e-3
+# The logits bar is north_star's 1e-3 for every f32-grade mode, and VERDICT r3's 1e-2 per element for the mode meant to meet the
+# target sentence at f16-MFMA rate (f32x); the per-layer bars are the measured values with ~3x head-room.
+LOGIT_BAR = {"f32": 1e-3, "f32s": 1e-3, "f32x": 1e-3, "f16": 5e-3}
+LAYER_BAR = {"f32": 3e-5, "f32s": 1e-4, "f32x": 1e-3, "f16": 1.5e-2}
+ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 1e-2, "f16": 0.5}  # worst per-element relative error over |ref| > 1e-2 max |ref|
+# the per-layer read-back sees every conv output, incl. branch-internal tensors with few large elements: its per-element bar is wider
+LAYER_ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 3e-2, "f16": 0.6}
 
 
 @pytest.fixture(scope="module")
@@ -46,7 +52,7 @@ def ref64(hostile_blob):
     return TorchModel(hostile_blob, float64=True)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32s", "f32x"])
+@pytest.mark.parametrize("dtype", ["f32", "f32s", "f32x", "f16"])
 def test_per_layer_on_hostile_parameters(hostile_blob, ref64, oracle, dtype):
     fr = H.saturated_frame(240, 320)
     taps = {}
@@ -68,8 +74,8 @@ def test_per_layer_on_hostile_parameters(hostile_blob, ref64, oracle, dtype):
             worst = (worst[0], e_rel, worst[2], spec.name)
         assert e_max < LAYER_BAR[dtype], (dtype, spec.name, e_max, e_rel)
     print(f"{dtype} hostile per-layer 320x240: worst max-abs/max-abs {worst[0]:.2e} ({worst[2]}), worst per-element {worst[1]:.2e} ({worst[3]})")
-    assert worst[1] < ELEM_BAR[dtype]
-    if dtype != "f32":
+    assert worst[1] < LAYER_ELEM_BAR[dtype]
+    if dtype in ("f32s", "f32x"):
         amax, wmax, sat = c.split_range()
         print(f"   split range monitor: max |activation| {amax:.3g}, max |Winograd input| {wmax:.3g}, saturated {sat}")
         assert not sat
@@ -80,7 +86,7 @@ def test_whole_frame_1080p_on_hostile_parameters(hostile_blob, ref64, oracle):
     fr = H.saturated_frame(1080, 1920, index=2)
     ref, ref_aux = ref64.forward_lowres(oracle.pack_normalize(fr))
     ref, ref_aux = ref.numpy(), ref_aux.numpy()
-    for dtype in ("f32", "f32s", "f32x"):
+    for dtype in ("f32", "f32s", "f32x", "f16"):
         c = Context(device=0, dtype=dtype)
         m = Model(c).control(ModelCmd.LoadBlob(hostile_blob))
         rgba, _ = FramePath(c).advance(fr, 1.0)

@@ -170,6 +170,37 @@ def test_quantised_model_through_group_stream_and_batch(qblob, oracle):
             c.close()
 
 
+def test_replicas_of_a_quantised_model_do_not_point_into_the_roots_arena(qblob, oracle):
+    """a replica re-bases EVERY device pointer of the model into its own arena -- the pixel-pair copies of
+    layer1 (d_w2 / d_qbias2 / d_qmult2) used to keep pointing at the root's.  After the broadcast the root's arena is
+    freed and its memory overwritten (a float model of another depth is loaded over it, then a large allocation is
+    filled with 0xFF): the replicas must still produce the oracle's bytes.  An even pooled width takes the pair path."""
+    import torch
+
+    from infur_amd.processors import Group
+    from oracle import infur_qoracle as Q
+
+    fr = W.synth_frame(64, 96, index=7)  # pooled width 24: even -> layer1 on pixel pairs
+    lo, _ = Q.qforward(qblob, oracle.pack_normalize(fr))
+    want = oracle.colorcode(oracle.upsample_bilinear(lo, 64, 96))
+    ctxs = [Context(device=0) for _ in range(3)]
+    try:
+        root = Model(ctxs[0]).control(ModelCmd.LoadBlob(qblob))
+        with Group(ctxs) as g:
+            g.weights_broadcast(root=0)
+        root.control(ModelCmd.Load(""))  # unload: the root's arena goes back to the allocator
+        junk = torch.full((256 << 20,), 0xFF, dtype=torch.uint8, device="cuda")  # ... and is overwritten
+        torch.cuda.synchronize()
+        root.control(ModelCmd.LoadBlob(W.synth_blob(depth=50)))
+        for c in ctxs[1:]:
+            got, _ = FramePath(c).advance(fr, 1.0)
+            assert (got == want).all()
+        del junk
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_resnet101_quantised_is_bit_exact(oracle):
     from oracle import infur_qoracle as Q
 

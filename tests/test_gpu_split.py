@@ -14,10 +14,11 @@ from infur_amd.processors import Context, FramePath, Model, ModelCmd
 pytestmark = pytest.mark.gpu
 
 SPLIT_TOL = 3e-5  # relative to the largest logit; the native f32 MFMA mode measures ~4e-6, f16 ~2e-3
-# INFUR_DTYPE_F32_SPLIT_FP8 ("f32x"): hi*hi on the f16 MFMA, the cross terms hi*lo on the fp8 (e4m3) MX MFMA -- products exact
-# to ~2^-14.  Measured 1.2-1.5e-4 with Winograd F(6x6) (its output transform amplifies the product error), 4.5e-5 with
-# direct convs; north_star's bar is 1e-3.
-FP8X_TOL = 3e-4
+# INFUR_DTYPE_F32_SPLIT_FP8 ("f32x"): hi*hi on the f16 MFMA, the cross terms hi*lo on the bf8 (e5m2) MX MFMA -- products exact
+# to ~2^-13 WHATEVER the tensors' dynamic range (round 3 used e4m3 under static scales: 1.2-1.5e-4 on these friendly weights but
+# 7.1e-4 / 5.1e-2 per element on the hostile set; e5m2: 2-3e-4 here, 1.1e-4 / 7e-3 there -- tests/test_gpu_hostile.py).  The
+# mode's default Winograd tile is F(4x4); north_star's bar is 1e-3.
+FP8X_TOL = 5e-4
 
 
 def rel_err(a, b):
@@ -236,7 +237,7 @@ def test_fp8_cross_terms_without_winograd(oracle, blob50):
     fr = W.synth_frame(270, 480, index=3)
     tl, ta = tm.forward_lowres(oracle.pack_normalize(fr))
     errs = {}
-    for name, kw in (("F(6x6)", {}), ("direct", {"winograd_min_cin": 0xFFFFFFFF})):
+    for name, kw in (("F(4x4)", {}), ("F(6x6)", {"winograd_tile": 6}), ("direct", {"winograd_min_cin": 0xFFFFFFFF})):
         c = Context(device=0, dtype="f32x", **kw)
         m = Model(c).control(ModelCmd.LoadBlob(blob50))
         FramePath(c).advance(fr, 1.0)
@@ -244,4 +245,4 @@ def test_fp8_cross_terms_without_winograd(oracle, blob50):
         errs[name] = max(rel_err(lo, tl.numpy()), rel_err(la, ta.numpy()))
         c.close()
     print("f32x logits rel err:", {k: f"{v:.2e}" for k, v in errs.items()})
-    assert errs["direct"] < 1e-4 and errs["F(6x6)"] < FP8X_TOL
+    assert errs["direct"] < 3e-4 and errs["F(4x4)"] < FP8X_TOL and errs["F(6x6)"] < FP8X_TOL
