@@ -27,6 +27,8 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+CONV_KERNELS = ("conv_igemm_", "conv1x1_")  # tiled implicit GEMM; A-resident 1x1 and the fused conv3 -> next conv1 pair (f16 mode)
+COPY_CEILING_GBS = 5450.0  # measured: a streaming copy of 0.5-4 GB sustains 5.3-5.6 TB/s read + write on this pool (profiles/r03_copy_ceiling.md)
 
 
 def parse():
@@ -436,7 +438,6 @@ def main():
             peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "f32s": PEAK_F16_MFMA_TFLOPS / 3.0,
                     "f32x": PEAK_F16_MFMA_TFLOPS / 2.0,  # f32x: one f16 MFMA + one fp8 MX MFMA (half an f16 unit per term) per product
                     "i8": 2.0 * PEAK_F16_MFMA_TFLOPS}[a.dtype]  # dense i8 MFMA: twice the f16 rate (TOP/s; >= 3944 measured in the guide)
-            CONV_KERNELS = ("conv_igemm_", "conv1x1_")  # tiled implicit GEMM; A-resident 1x1 and the fused conv3 -> next conv1 pair (f16 mode)
             conv = [r for r in recs if r["kernel"].startswith(CONV_KERNELS)]
             # dominant kernel = the tile configuration of conv_igemm that takes the most time in a frame over the
             # launches that execute the convolution directly (algorithmic FLOPs == executed FLOPs); the
@@ -482,8 +483,9 @@ def main():
             for o in others.values():
                 o["GB/s"] = o["bytes"] / max(o["ms"], 1e-9) / 1e6
                 o["frac_hbm"] = o["GB/s"] / PEAK_HBM_GBS
+                o["frac_copy"] = o["GB/s"] / COPY_CEILING_GBS
             # what actually bounds each of them: only the Winograd transforms are HBM kernels
-            bound_of = {"wino_input": ("hbm", "a plain device-to-device copy of this size sustains 5.1-5.2 TB/s on this part (scripts/copy_ceiling.py)"),
+            bound_of = {"wino_input": ("hbm", "a hand-written 16 B / lane streaming copy of 0.5-4 GB sustains 5.3-5.6 TB/s read + write on this part (profiles/r03_copy_ceiling.md): frac_copy is GB/s over 5.45 TB/s"),
                         "wino_output": ("hbm", "see wino_input"),
                         "stem_pool": ("mfma", "7x7 stem as an implicit GEMM fused with the max-pool: 11.2 GFLOP executed per 1080p frame; its bytes are "
                                               "the 6.2 MB frame + the 33 MB pooled tensor, so GB/s says nothing about it"),
@@ -545,6 +547,10 @@ def main():
         if world == 1 and a.dtype == "f32" and not a.no_split:
             out["f32_split_mode"] = split_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H)
             out["f32_split_fp8_mode"] = split_fp8_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H)
+            try:
+                out["f16_mode_1080p"] = f16_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H)
+            except Exception as e:  # noqa: BLE001
+                out["f16_mode_1080p"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 out["int8_quantised_model"] = int8_mode_rate(a, dev, d_frames, d_masks, Wd, H)
             except Exception as e:  # noqa: BLE001
@@ -670,13 +676,17 @@ def split_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H):
 
 
 def split_fp8_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H):
-    """The same frames through INFUR_DTYPE_F32_SPLIT_FP8 ("f32x"): the split mode with its two cross terms hi*lo on the fp8
-    (e4m3) MX MFMA -- 2 MFMA units per product instead of 3.  A side measurement like f32_split_mode; its logits are within
-    3e-4 of the f32 oracle (tests/test_gpu_split.py; measured 1.2-1.5e-4), i.e. inside north_star's 1e-3, not f32-grade."""
+    """The same frames through INFUR_DTYPE_F32_SPLIT_FP8 ("f32x"): the split mode with its two cross terms hi*lo on the bf8
+    (OCP e5m2) MX MFMA -- 2 MFMA units per product instead of 3, no tensor-level scales (e5m2 has f16's exponent range).  The
+    cheapest arithmetic in the tree that stays inside north_star's 1e-3 on HOSTILE parameters too (tests/test_gpu_hostile.py:
+    1.1e-4 max-abs, 7e-3 per element at 1080p; the f16 mode: 1.9e-3 / 1.3e-1).  A side measurement like f32_split_mode."""
     fps, ms = resident_rate(a, dev, "f32x", blob, d_frames, d_masks, Wd, H, a.scale, len(d_frames) * a.steps)
     out = {"value": fps, "unit": "frames/s", "dtype": "f32x", "ms_per_frame": ms, "contexts_per_gpu": max(1, a.contexts_per_gpu),
-           "parity": "logits within 3e-4 of the f32 oracle enforced in tests/test_gpu_split.py (measured 1.2e-4 .. 1.5e-4 with "
-                     "Winograd F(6x6), 4.5e-5 with direct convs); f16 mode: 1.5e-3",
+           "parity": "logits within 5e-4 of the f32 oracle enforced in tests/test_gpu_split.py (synthetic weights: measured 2-3e-4); "
+                     "hostile parameters (heavy tails, per-channel scales over 3.2 decades) against a float64 reference, 1920x1080: "
+                     "1.1e-4 max-abs / 7.0e-3 worst per-element, bars 1e-3 / 1e-2 (tests/test_gpu_hostile.py, profiles/r04_hostile_probe.log); "
+                     "round 3's e4m3 cross terms: 7.1e-4 / 5.1e-2; f16 mode: 1.9e-3 / 1.3e-1",
+           "winograd_tile": "F(4x4) (this mode's default: F(6x6) is 7 % faster per frame and reads 1.4e-4 / 1.0e-2 on the hostile set)",
            "run": "python bench.py --dtype f32x"}
     try:
         from infur_amd import weights as W
@@ -686,10 +696,66 @@ def split_fp8_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H):
         out["roofline"] = with_executed(
             {"bound": "mfma", "achieved": flops * fps / 1e12, "peak": ceil, "unit": "TFLOP/s", "frac": flops * fps / 1e12 / ceil,
              "note": "whole-frame algorithmic (direct-conv) FLOPs x frames/s against half of the dense f16 MFMA peak (one f16 "
-                     "MFMA + one fp8 MX MFMA of twice the depth at twice the rate per product); 14 convs run as Winograd F(6x6)"},
+                     "MFMA + one bf8 MX MFMA of twice the depth at twice the rate per product); 14 convs run as Winograd F(4x4)"},
             executed_gflop_per_frame(a, dev, "f32x", blob, d_frames[0].cpu().numpy(), a.scale), fps)
     except Exception:
         pass
+    return out
+
+
+def f16_mode_rate(a, dev, blob, d_frames, d_masks, Wd, H):
+    """the headline's frames through INFUR_DTYPE_F16 (f16 tensors and operands, f32 accumulation -- configs[4]'s
+    arithmetic on configs[1]'s workload).  A REDUCED-PRECISION mode: its logits are outside north_star's 1e-3 (1.5-2e-3), so it is
+    reported for the record next to the compliant modes, never as `value`.  Every 3x3 runs directly (no Winograd in this mode), so
+    algorithmic FLOPs == executed FLOPs and `frac` is the matrix-pipe fraction of the whole frame."""
+    from infur_amd import weights as W
+    from infur_amd.processors import Context, FramePath, Model, ModelCmd
+
+    fps, ms = resident_rate(a, dev, "f16", blob, d_frames, d_masks, Wd, H, a.scale, len(d_frames) * a.steps)
+    flops = W.conv_flops(H, Wd, depth=a.depth, aux=not a.no_aux)["total"]
+    out = {"value": fps, "unit": "frames/s", "dtype": "f16", "ms_per_frame": ms, "contexts_per_gpu": max(1, a.contexts_per_gpu),
+           "workload": f"{Wd}x{H} frame, FCN-ResNet{a.depth}, f16 operands / f32 accumulation, scale {a.scale}, HBM resident",
+           "parity": "NOT inside north_star's 1e-3: logits 1.5-2.1e-3 from the f32 oracle on the synthetic weights (tests state 5e-3: "
+                     "tests/test_gpu_parity.py, tests/test_gpu_exporter.py), 1.9e-3 max-abs / 1.3e-1 worst per-element on hostile parameters "
+                     "(tests/test_gpu_hostile.py); scripts/sim_f16_attribution.py: weights, branch tensors, trunk and head each carry "
+                     "3e-4 .. 9e-4 of it, so no single tensor kept in f32 repairs it -- f32x is the compliant mode at this MFMA family",
+           "run": "python bench.py --dtype f16",
+           "roofline": {"bound": "mfma", "achieved": flops * fps / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops * fps / 1e12 / PEAK_F16_MFMA_TFLOPS, "executed_frac": flops * fps / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                        "note": "whole-frame direct-convolution FLOPs x frames/s against the dense f16 MFMA peak; every conv runs directly, "
+                                "so algorithmic == executed"}}
+    # one profiled frame on one context: which kernel ran each layer, the fused conv3 -> conv1 pairs and the dominant kernel's rate
+    try:
+        c = Context(device=dev, compute_aux=not a.no_aux, profile=True, dtype="f16")
+        try:
+            Model(c).control(ModelCmd.LoadBlob(blob))
+            fp = FramePath(c, a.scale_mode)
+            fr = d_frames[0].cpu().numpy()
+            for _ in range(3):
+                fp.advance(fr, a.scale)
+            recs = c.profile()
+        finally:
+            c.close()
+        by = {}
+        for r in recs:
+            o = by.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "gflop": 0.0, "mbytes": 0.0})
+            o["launches"] += 1
+            o["ms"] += r["ms"]
+            o["gflop"] += r["flops"] / 1e9
+            o["mbytes"] += r["bytes"] / 1e6
+        for o in by.values():
+            o["TFLOP/s"] = o["gflop"] / max(o["ms"], 1e-9)
+            o["GB/s"] = o["mbytes"] / max(o["ms"], 1e-9)
+        dom = max((k for k in by if k.startswith(CONV_KERNELS)), key=lambda k: by[k]["ms"])
+        out["roofline"]["dominant_kernel"] = {"kernel": dom, **by[dom], "frac": by[dom]["TFLOP/s"] / PEAK_F16_MFMA_TFLOPS}
+        out["roofline"]["frame_kernel_ms_one_context"] = sum(r["ms"] for r in recs)
+        out["kernels"] = by
+        out["fused_pairs"] = sum(1 for r in recs if r["kernel"].startswith("conv1x1_b2b"))
+        tj = os.path.join(ROOT, "profiles", "traffic_f16.json")
+        if os.path.exists(tj) and (Wd, H, a.scale, a.depth) == (1920, 1080, 1.0, 50):
+            out["roofline"]["traffic_file"] = "profiles/traffic_f16.json (HBM bytes per launch per kernel, separate --pmc passes)"
+    except Exception as e:  # noqa: BLE001
+        out["kernels"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
