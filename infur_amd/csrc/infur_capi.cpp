@@ -1320,24 +1320,46 @@ void infur_options_default(infur_options* o) {
     o->compute_aux = 1;
 }
 
-// the stream pool of infur_ctx_create (see there)
-static hipStream_t pool_stream(int device) {
-    constexpr int kPool = 8, kMaxDev = 64;
-    static std::mutex mu;
-    static hipStream_t pool[kMaxDev][kPool];
-    static bool made[kMaxDev];
-    static unsigned next[kMaxDev];
+// the stream pool of infur_ctx_create (see there).  Every pool stream knows how many live contexts hold it: a context that
+// wants to CAPTURE its stream (infur_ctx_set_graph_replay) must not share it -- another context's thread enqueueing to a
+// capturing stream would have its kernels recorded into this context's graph instead of executed.
+namespace {
+constexpr int kPool = 8, kMaxDev = 64;
+std::mutex g_pool_mu;
+hipStream_t g_pool[kMaxDev][kPool];
+bool g_pool_made[kMaxDev];
+unsigned g_pool_next[kMaxDev];
+int g_pool_users[kMaxDev][kPool];
+}  // namespace
+
+static hipStream_t pool_stream(int device, int* slot) {
+    *slot = -1;
     if (device < 0 || device >= kMaxDev) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!made[device]) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool_made[device]) {
         for (int i = 0; i < kPool; i++)
-            if (hipStreamCreateWithFlags(&pool[device][i], hipStreamNonBlocking) != hipSuccess) {
-                for (int j = 0; j < i; j++) (void)hipStreamDestroy(pool[device][j]);
+            if (hipStreamCreateWithFlags(&g_pool[device][i], hipStreamNonBlocking) != hipSuccess) {
+                for (int j = 0; j < i; j++) (void)hipStreamDestroy(g_pool[device][j]);
                 return nullptr;
             }
-        made[device] = true;
+        g_pool_made[device] = true;
     }
-    return pool[device][next[device]++ % kPool];
+    *slot = (int)(g_pool_next[device]++ % kPool);
+    g_pool_users[device][*slot]++;
+    return g_pool[device][*slot];
+}
+
+static void pool_stream_release(int device, int slot) {
+    if (device < 0 || device >= kMaxDev || slot < 0 || slot >= kPool) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool_users[device][slot] > 0) g_pool_users[device][slot]--;
+}
+
+// does another live context hold this context's (pool) stream?
+static bool stream_is_shared(const infur_ctx* c) {
+    if (c->pool_slot < 0) return false;  // the caller's own stream, or a private one
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    return g_pool_users[c->device][c->pool_slot] > 1;
 }
 
 int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
@@ -1371,7 +1393,7 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
             // but the ring's copies, which run at normal priority, then starve behind the high-priority lane: configs[2]'s stream path
             // fell from 341 to 286 frames/s.)  More than eight live contexts of a device share streams pairwise -- as they would share a
             // hardware queue anyway; a host with its own stream policy passes its stream in the options.
-            c->stream = pool_stream(o.device);
+            c->stream = pool_stream(o.device, &c->pool_slot);
             if (!c->stream) {
                 delete c;
                 return INFUR_E_HIP;
@@ -1429,6 +1451,7 @@ void infur_ctx_destroy(infur_ctx* c) {
     if (c->d_range) (void)hipFree(c->d_range);
     if (c->d_stem16) (void)hipFree(c->d_stem16);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    pool_stream_release(c->device, c->pool_slot);
     delete c;
 }
 
@@ -1996,7 +2019,8 @@ int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uin
             c->streak_gen = c->mem_gen;  // (a frame that allocated, trimmed or tuned restarts the count)
             return rc;
         }
-        // capture: the same enqueue code, recorded instead of executed
+        // capture: the same enqueue code, recorded instead of executed -- never on a stream another context enqueues to
+        if (stream_is_shared(c)) return frame_body(c, d_bgr, w, h, factor, mode, d_rgba, d_scaled, *ow, *oh);
         const uint64_t gen0 = c->mem_gen;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
@@ -2045,6 +2069,22 @@ int32_t infur_ctx_set_graph_replay(infur_ctx* c, uint32_t enable) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         graphs_drop(c);
+    } else if (c->pool_slot >= 0 && c->streams.empty() && !c->batch_ring) {
+        // A capturing context gets a stream of its OWN: pool streams are shared from the ninth context of a device on, and a
+        // kernel another context's thread enqueues between BeginCapture and EndCapture would be recorded into this context's
+        // graph, not executed (ThreadLocal capture mode only restricts the capturing thread).  With a ring already attached the
+        // stream stays (the ring's events are tied to it) and a shared stream simply never captures (frame_advance_dev).
+        hipStream_t own = nullptr;
+        (void)hipSetDevice(c->device);
+        if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess) {
+            (void)hipStreamSynchronize(c->stream);
+            pool_stream_release(c->device, c->pool_slot);
+            c->pool_slot = -1;
+            c->stream = own;
+            c->own_stream = true;
+        } else {
+            (void)hipGetLastError();
+        }
     }
     c->graph_streak = 0;
     return INFUR_OK;
@@ -2099,6 +2139,7 @@ struct infur_stream {
         void* d_in = nullptr;
         void* d_out = nullptr;  // [rgba | scaled bgr]
         size_t in_cap = 0, out_cap = 0;
+        uint32_t small_in = 0, small_out = 0;  // consecutive requests below a quarter of the capacity (slot_reserve's hysteresis)
         hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_done = nullptr;
         uint64_t id = 0;
         uint32_t ow = 0, oh = 0;
@@ -2115,24 +2156,32 @@ struct infur_stream {
 };
 
 namespace {
-// buffers grow on demand and are given back when a request needs less than a quarter of them (a ring that lives as
-// long as its context -- infur_batch_advance's -- would otherwise keep the largest frame it ever saw)
+// buffers grow on demand and are given back when requests have needed less than a quarter of them for a while (a ring that lives
+// as long as its context -- infur_batch_advance's -- would otherwise keep the largest frame it ever saw).  "For a while" = 8
+// consecutive small requests of that slot: a batch that ALTERNATES large and small frames (4K and 480p) would otherwise free and
+// reallocate pinned + device memory on every frame -- each a device-wide synchronisation, and new pointers that no cached
+// graph of the fused frame path can match.
+constexpr uint32_t kSlotShrinkAfter = 8;
 int32_t slot_reserve(infur_ctx* c, infur_stream::Slot& sl, size_t in_bytes, size_t out_bytes) {
-    if (sl.in_cap < in_bytes || sl.in_cap / 4 > in_bytes) {
+    sl.small_in = sl.in_cap / 4 > in_bytes ? sl.small_in + 1 : 0;
+    sl.small_out = sl.out_cap / 4 > out_bytes ? sl.small_out + 1 : 0;
+    if (sl.in_cap < in_bytes || sl.small_in >= kSlotShrinkAfter) {
         if (sl.h_in) HIPCHK(c, hipHostFree(sl.h_in));
         if (sl.d_in) HIPCHK(c, hipFree(sl.d_in));
         sl.h_in = nullptr; sl.d_in = nullptr; sl.in_cap = 0;
         HIPCHK(c, hipHostMalloc((void**)&sl.h_in, in_bytes, hipHostMallocDefault));
         HIPCHK(c, hipMalloc(&sl.d_in, in_bytes));
         sl.in_cap = in_bytes;
+        sl.small_in = 0;
     }
-    if (sl.out_cap < out_bytes || sl.out_cap / 4 > out_bytes) {
+    if (sl.out_cap < out_bytes || sl.small_out >= kSlotShrinkAfter) {
         if (sl.h_out) HIPCHK(c, hipHostFree(sl.h_out));
         if (sl.d_out) HIPCHK(c, hipFree(sl.d_out));
         sl.h_out = nullptr; sl.d_out = nullptr; sl.out_cap = 0;
         HIPCHK(c, hipHostMalloc((void**)&sl.h_out, out_bytes, hipHostMallocDefault));
         HIPCHK(c, hipMalloc(&sl.d_out, out_bytes));
         sl.out_cap = out_bytes;
+        sl.small_out = 0;
     }
     return INFUR_OK;
 }

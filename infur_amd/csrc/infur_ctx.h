@@ -95,6 +95,7 @@ struct infur_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    int pool_slot = -1;  // >= 0: `stream` is entry pool_slot of the device's stream pool (infur_capi.cpp), possibly shared
     std::string err;
 
     // lookup tables

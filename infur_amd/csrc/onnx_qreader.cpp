@@ -14,6 +14,7 @@
 // point (scalar or per output channel) fits 8 bits -- stored re-centred as s8 -- with one scale per tensor or per output channel, int32 bias, group 1, every shape / stride / pad / dilation as torchvision's fcn_resnet50/101.
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -227,6 +228,31 @@ bool qdq_to_qoperator(QGraph& g, std::string* err) {
             if (n.in.size() > 2 && !n.in[2].empty()) {
                 if (!dq_of.count(n.in[2]) || !g.inits.count(dq_of[n.in[2]].q)) { *err = "QDQ model: a Conv bias that is not DequantizeLinear of an INT32 initializer"; return false; }
                 bq = dq_of[n.in[2]].q;
+                // the int32 bias of QLinearConv is in units of x_scale * w_scale[o] with zero point 0 (ONNX QLinearConv-10): a bias
+                // DequantizeLinear that says anything else describes a different function than the fused operator computes --
+                // a format error here, not silently different logits
+                const DQ bd = dq_of[n.in[2]];
+                float xs;
+                std::vector<float> wsv, bsv;
+                auto wsi = g.inits.find(w.scale), bsi = g.inits.find(bd.scale);
+                if (!scalar_f32(g, x.scale, &xs) || wsi == g.inits.end() || bsi == g.inits.end() || wsi->second.dims.size() > 1 || bsi->second.dims.size() > 1 ||
+                    !wsi->second.floats(wsv) || !bsi->second.floats(bsv) || wsv.empty() || bsv.empty()) {
+                    *err = "QDQ model: a Conv's input / weight / bias scales must be float initializers"; return false;
+                }
+                const size_t nb = std::max(wsv.size(), bsv.size());
+                if ((wsv.size() != 1 && wsv.size() != nb) || (bsv.size() != 1 && bsv.size() != nb)) { *err = "QDQ model: a Conv's weight and bias scales have different lengths"; return false; }
+                for (size_t o = 0; o < nb; o++) {
+                    const float want = xs * wsv[wsv.size() == 1 ? 0 : o], have = bsv[bsv.size() == 1 ? 0 : o];
+                    if (!(std::fabs(have - want) <= 1e-6f * std::fabs(want))) { *err = "QDQ model: a Conv bias whose DequantizeLinear scale is not x_scale * w_scale"; return false; }
+                }
+                if (!bd.zp.empty()) {
+                    auto zi = g.inits.find(bd.zp);
+                    size_t zn;
+                    const uint8_t* zp;
+                    bool zero = zi != g.inits.end() && int_bytes(zi->second, 6, 4, &zn, &zp);
+                    for (size_t k = 0; zero && k < zn * 4; k++) zero = zp[k] == 0;
+                    if (!zero) { *err = "QDQ model: a Conv bias whose DequantizeLinear zero point is not an all-zero INT32 initializer"; return false; }
+                }
             }
             const Node& Q = g.nodes[qn];
             if (relu >= 0) {
@@ -506,6 +532,9 @@ int onnx_q_to_blob(const uint8_t* data, size_t len, std::vector<uint8_t>& blob, 
                 !qscale_ok(qa.b_scale) || !qscale_ok(qa.c_scale)) {
                 err = "QLinearAdd scales / zero points must be float / UINT8 scalar initializers"; return 2;
             }
+            // the sum's A input IS conv3's output tensor: its (scale, zero point) must be conv3's y parameters (the fused conv3 + add
+            // epilogue and the blob's directory check rely on it; said here, where the file is read -- ADVICE r3)
+            if (qa.a_scale != c3.y_scale || qa.a_zp != c3.y_zp) { err = "QLinearAdd: the parameters of its conv3 input differ from conv3's y_scale / y_zero_point"; return 2; }
             convs.push_back(c1); convs.push_back(c2); convs.push_back(c3);
             if (has_ds) convs.push_back(ds);
             adds.push_back(qa);

@@ -296,7 +296,8 @@ def fcn_model(tensors, specs, *, unfold_bn=False, raw=True, packed_dims=True, in
 
 def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(), relu_after=(), w_zp=0, w_dtype=3, swap_add=None,
                input_type=1, coord_mode="pytorch_half_pixel", drop_last=0, stem_scale=None, dq_scale=None, no_bias=(), vector_wzp=False,
-               pad_zp_conv=None, extra_qconv=False, shift_weights=True, resize_u8=False, resize_subgraph=False, qdq=False, qdq_share_dq=False, float_add=False):
+               pad_zp_conv=None, extra_qconv=False, shift_weights=True, resize_u8=False, resize_subgraph=False, qdq=False, qdq_share_dq=False, float_add=False,
+               qdq_bias_scale_factor=None, qdq_bias_zp=None):
     """The QOperator int8 form of the same network, as ONNX Runtime's static quantisation writes it (the shape of
     `fcn-resnet50-12-int8.onnx`, the file the reference's tests load: predict_onnx.rs:357-381):
     QuantizeLinear -> QLinearConv (ReLU folded) -> MaxPool (u8) -> bottlenecks (QLinearConv x3 [+ downsample], com.microsoft
@@ -375,9 +376,16 @@ def fcn_qmodel(convs, adds, specs, *, rng=None, order="topo", per_tensor_scale=(
             emit("DequantizeLinear", [name + ".weight", name + ".w_scale", name + ".w_zp"], [wf], [attr_int("axis", 0)])
             cin = [xf, wf]
             if name not in no_bias:
-                inits.append(tensor(name + ".b_scale", (np.float32(c.x_scale) * np.asarray(c.w_scale, np.float32)).astype(np.float32)))
+                bsc = (np.float32(c.x_scale) * np.asarray(c.w_scale, np.float32)).astype(np.float32)
+                if qdq_bias_scale_factor and name == qdq_bias_scale_factor[0]:  # a file the reader must reject
+                    bsc = (bsc * np.float32(qdq_bias_scale_factor[1])).astype(np.float32)
+                inits.append(tensor(name + ".b_scale", bsc))
                 bf = fresh("b_dq")
-                emit("DequantizeLinear", [name + ".bias", name + ".b_scale"], [bf], [attr_int("axis", 0)])
+                bins = [name + ".bias", name + ".b_scale"]
+                if qdq_bias_zp and name == qdq_bias_zp[0]:
+                    inits.append(tensor(name + ".b_zp", np.full(s.cout, qdq_bias_zp[1], np.int32), dtype=6))
+                    bins.append(name + ".b_zp")
+                emit("DequantizeLinear", bins, [bf], [attr_int("axis", 0)])
                 cin.append(bf)
             y = fresh("conv")
             emit("Conv", cin, [y], cattrs)

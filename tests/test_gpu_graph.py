@@ -73,3 +73,47 @@ def test_stream_ring_with_graph_replay_equals_direct():
         cap, rep, cached = cg.graph_stats()
         assert cached == 3 and rep >= 20, (cap, rep, cached)  # one graph per ring slot
         sp.close()
+
+
+def test_capture_never_runs_on_a_stream_another_context_uses():
+    """the library lends streams from a per-device pool of eight, so the ninth context of a device shares the first one's.
+    A context with graph replay must not capture such a stream (another context's kernels, enqueued from another thread during the
+    capture, would be recorded into ITS graph and not executed): it moves to a private stream when replay is switched on.  Nine
+    contexts, replay on the first, a thread hammering frames through the ninth while the first captures and replays."""
+    import threading
+
+    blob = W.synth_blob(depth=50)
+    frames = [W.synth_frame(96, 128, index=i) for i in range(3)]
+    ctxs = [Context(device=0, dtype="f16") for _ in range(9)]
+    try:
+        for c in (ctxs[0], ctxs[8]):
+            Model(c).control(ModelCmd.LoadBlob(blob))
+        ref = [FramePath(ctxs[8]).advance(f, 1.0)[0] for f in frames]
+        ctxs[0].check(ctxs[0].L.infur_ctx_set_graph_replay(ctxs[0].h, 1))
+        stop, bad = threading.Event(), []
+
+        def hammer():
+            fp = FramePath(ctxs[8])
+            k = 0
+            while not stop.is_set():
+                out, _ = fp.advance(frames[k % 3], 1.0)
+                if not (out == ref[k % 3]).all():
+                    bad.append(k)
+                k += 1
+
+        t = threading.Thread(target=hammer)
+        t.start()
+        fp0 = FramePath(ctxs[0])
+        try:
+            for it in range(30):
+                out, _ = fp0.advance(frames[it % 3], 1.0)
+                assert (out == ref[it % 3]).all(), it
+        finally:
+            stop.set()
+            t.join()
+        assert not bad
+        cap, rep, cached = ctxs[0].graph_stats()
+        assert cap >= 1 and rep >= 10, (cap, rep, cached)
+    finally:
+        for c in ctxs:
+            c.close()

@@ -429,6 +429,14 @@ def test_batch_ring_is_persistent_and_follows_the_frame_size(blob50):
         for _ in range(3):
             assert all((x == y).all() for x, y in zip(fp.advance_batch(big, 1.0), ref_big))
         assert torch.cuda.mem_get_info(0)[0] == free0, "a repeated batch of the same size allocated device memory"
+        # a batch that ALTERNATES large and small frames must not free / reallocate the ring's buffers frame by frame
+        mixed = [big[0], small[0], big[1], small[1], big[2], small[2]]
+        ref_mixed = [ref_big[0], ref_small[0], ref_big[1], ref_small[1], ref_big[2], ref_small[2]]
+        assert all((x == y).all() for x, y in zip(fp.advance_batch(mixed, 1.0), ref_mixed))
+        free1 = torch.cuda.mem_get_info(0)[0]
+        for _ in range(3):
+            assert all((x == y).all() for x, y in zip(fp.advance_batch(mixed, 1.0), ref_mixed))
+            assert torch.cuda.mem_get_info(0)[0] == free1, "alternating frame sizes made the ring reallocate"
         for _ in range(6):  # (the activation arena trims itself after a few frames of the new size as well)
             assert all((x == y).all() for x, y in zip(fp.advance_batch(small, 1.0), ref_small))
         assert torch.cuda.mem_get_info(0)[0] > free0, "the ring kept its 480x270 buffers for 48x32 frames"

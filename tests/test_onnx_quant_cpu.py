@@ -279,6 +279,12 @@ def test_qdq_graphs_that_cannot_be_fused_are_rejected(lib, q50):
     name = next(c.name for s_, c in zip(specs, convs) if c.y_zp != 0 and s_.role == "conv3")
     rc, err, _ = convert(lib, OW.fcn_qmodel(convs, adds, specs, qdq=True, relu_after=(name,)))
     assert rc != 0 and "Relu in front of a QuantizeLinear whose zero point is not 0" in err, err
+    # a bias DequantizeLinear that is not in units of x_scale * w_scale, or has a zero point: not the fused operator's function
+    rc, err, _ = convert(lib, OW.fcn_qmodel(convs, adds, specs, qdq=True, qdq_bias_scale_factor=("backbone.layer2.1.conv1", 1.5)))
+    assert rc != 0 and "scale is not x_scale * w_scale" in err, err
+    rc, err, _ = convert(lib, OW.fcn_qmodel(convs, adds, specs, qdq=True, qdq_bias_zp=("backbone.layer2.1.conv1", 3)))
+    assert rc != 0 and "zero point is not an all-zero INT32" in err, err
+    assert convert(lib, OW.fcn_qmodel(convs, adds, specs, qdq=True, qdq_bias_zp=("backbone.layer2.1.conv1", 0)))[0] == 0
     # an operator group that is not closed by a QuantizeLinear / a float operator the fusion does not know
     rc, err, _ = convert(lib, model.replace(b"MaxPool", b"MaxPooX"))
     assert rc != 0 and err
