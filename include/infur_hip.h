@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define INFUR_ABI_VERSION 3
+#define INFUR_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -68,9 +68,14 @@ enum {
                             accumulated in f32 from three f16 MFMAs (lo*hi + hi*lo + hi*hi).  f32-grade
                             logits (tests: <= 2e-5 of the f32 oracle) at a multiple of the f32 MFMA rate */
     INFUR_DTYPE_F32_SPLIT_FP8 = 3 /* as INFUR_DTYPE_F32_SPLIT, but only hi*hi runs on the f16 MFMA; the two cross terms
-                            hi*lo + lo*hi run on the fp8 (OCP e4m3) MX MFMA at twice the f16 rate: 2 MFMA units per
-                            product instead of 3.  Products are exact to ~2^-14: logits within 1e-4 of the f32 oracle
-                            (tests), i.e. inside north_star's 1e-3 with a 10x margin, 25x closer than INFUR_DTYPE_F16 */
+                            hi*lo + lo*hi run on the bf8 (OCP e5m2) MX MFMA at twice the f16 rate: 2 MFMA units per
+                            product instead of 3.  e5m2 has f16's exponent range, so no tensor-level scale is involved and
+                            the error does not depend on the tensors' dynamic range: products exact to ~2^-13, logits
+                            2-3e-4 (max-abs / max-abs) from the f32 oracle on the synthetic weights and 1.1e-4 max-abs /
+                            7e-3 worst per-element on heavy-tailed weights with per-channel scales over three decades
+                            (tests/test_gpu_hostile.py; bars 1e-3 / 1e-2) -- a side mode, ~15x closer than
+                            INFUR_DTYPE_F16, never the bench headline.  Default Winograd tile of this mode: F(4x4).
+                            (Round 3 used e4m3 under static scales: 7.1e-4 / 5.1e-2 on the same hostile set.) */
 };
 
 typedef struct infur_ctx infur_ctx;
@@ -108,6 +113,12 @@ typedef struct infur_model_info {
     uint32_t depth;         /* 50 | 101 */
     uint32_t n_convs;
     uint64_t weight_bytes;
+    /* ABI 4 (appended; infur_model_info_get_sized copies only as many bytes as the caller's struct has): */
+    uint32_t quantised;       /* 1: a QOperator / QDQ int8 model (INFURQ01): u8 activations x s8 weights on the i8 MFMA whatever
+                                 options.compute_dtype says; 0: a float model run in options.compute_dtype */
+    uint32_t resize_u8_heads; /* 1: the quantised file resizes the u8 logits BEFORE DequantizeLinear (onnxruntime's QOperator
+                                 quantiser keeps Resize on the u8 tensor): infur_model_read_lowres returns the dequantised codes,
+                                 the full-resolution outputs are interpolate -> truncate -> dequantise */
 } infur_model_info;
 
 /* one profiled kernel launch of the last advance */
@@ -150,14 +161,19 @@ int32_t infur_scale_dev(infur_ctx* ctx, const void* d_bgr, uint32_t w, uint32_t 
 
 /* ---- Model (predict_onnx.rs:283-345) ---- */
 /* ModelCmd::Load(path) (predict_onnx.rs:288-312): empty path unloads.  The file is an
- * INFURW01 weight blob (infur_amd/weights.py) or an ONNX model.  What the model is fed follows the
+ * INFURW01 weight blob (float FCN-ResNet50/101) or an INFURQ01 blob (the quantised form: u8 activations, s8 weights,
+ * QLinearConv / QLinearAdd arithmetic; both layouts in infur_amd/weights.py), or an ONNX model: float (Conv), QOperator
+ * (QLinearConv -- the shape of fcn-resnet50-12-int8.onnx, the file the reference's tests load, predict_onnx.rs:357-381) or
+ * QDQ (DequantizeLinear -> Conv -> QuantizeLinear groups, fused as ONNX Runtime fuses them).  A quantised model runs on the
+ * i8 MFMA whatever options.compute_dtype says; infur_model_info.quantised tells.  What the model is fed follows the
  * reference (predict_onnx.rs:103-139,296-301): a Float image input gets RGB planes normalised with
  * the torchvision constants; a Uint8 image input gets the frame's bytes themselves, BGR kept;
  * NCHW / NHWC is the file's own business (a Transpose in front of its stem). */
 int32_t infur_model_load(infur_ctx* ctx, const char* path);
 /* Host-only converter behind infur_model_load's .onnx support (no context, no GPU): parses an
- * ONNX ModelProto (float FCN-ResNet50/101 as exported by torchvision, BN folded or not) with the
- * reference's input checks (predict_onnx.rs:223-265) and returns a malloc'ed INFURW01 blob;
+ * ONNX ModelProto (FCN-ResNet50/101 as exported by torchvision, BN folded or not; float, or quantised in QOperator / QDQ
+ * form) with the reference's input checks (predict_onnx.rs:223-265) and returns a malloc'ed INFURW01 (float) or INFURQ01
+ * (quantised) blob;
  * release it with infur_buffer_free.  err (optional, errcap bytes) receives the message. */
 int32_t infur_onnx_to_blob(const void* onnx, size_t len, void** blob, size_t* blob_len, char* err,
                            size_t errcap);
@@ -168,6 +184,9 @@ int32_t infur_model_load_blob_dev(infur_ctx* ctx, const void* d_blob, size_t len
 int32_t infur_model_unload(infur_ctx* ctx);
 /* Model::get_info (predict_onnx.rs:341-345): INFUR_E_MODEL_NOT_LOADED when none */
 int32_t infur_model_info_get(const infur_ctx* ctx, infur_model_info* info);
+/* the same for a host compiled against an older (shorter) infur_model_info: at most info_size bytes are written, so the
+ * struct can grow at its end without an overrun; info_size == 0 is INFUR_E_INVALID_ARG */
+int32_t infur_model_info_get_sized(const infur_ctx* ctx, void* info, size_t info_size);
 /* Model::advance (predict_onnx.rs:317-334): pre-proc (:97-140) + forward (:138) + batch
  * strip (:326-330).  out / aux: [num_classes, h, w] f32 planar, either may be NULL.
  * With no model loaded this is a no-op returning INFUR_OK (predict_onnx.rs:318,333) and

@@ -118,6 +118,8 @@ struct ModelInfo {
     std::vector<std::string> input_names;
     std::string input0_dtype;
     std::vector<std::string> output_names;
+    bool quantised = false;        ///< a QOperator / QDQ int8 model: runs on the i8 MFMA whatever the context's dtype (ABI 4)
+    bool resize_u8_heads = false;  ///< ... whose file resizes the u8 logits before DequantizeLinear
 };
 
 /// predict_onnx.rs:146-345.  Command = ModelCmd::Load(path), Input = BgrImage, Output = Vec<ArrayD<f32>>.
@@ -137,6 +139,8 @@ public:
         r.input_names = {mi.input_name};
         r.input0_dtype = mi.input0_dtype;
         for (uint32_t i = 0; i < mi.n_outputs; i++) r.output_names.push_back(mi.output_names[i]);
+        r.quantised = mi.quantised != 0;
+        r.resize_u8_heads = mi.resize_u8_heads != 0;
         return r;
     }
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # INFUR_LIB_PATH: an instrumentation build of the same ABI (scripts/ktrace.py: `make ktrace` -> libinfur_hip_ktrace.so)
 LIB_PATH = os.environ.get("INFUR_LIB_PATH") or os.path.join(_HERE, "libinfur_hip.so")
 
-ABI_VERSION = 3  # INFUR_ABI_VERSION of include/infur_hip.h
+ABI_VERSION = 4  # INFUR_ABI_VERSION of include/infur_hip.h
 
 # status codes (include/infur_hip.h)
 OK = 0
@@ -63,6 +63,8 @@ class ModelInfoC(C.Structure):
         ("depth", C.c_uint32),
         ("n_convs", C.c_uint32),
         ("weight_bytes", C.c_uint64),
+        ("quantised", C.c_uint32),        # ABI 4
+        ("resize_u8_heads", C.c_uint32),  # ABI 4
     ]
 
 
@@ -105,6 +107,7 @@ SIGNATURES = {
     "infur_model_load_blob_dev": (C.c_int32, [_vp, _vp, _sz]),
     "infur_model_unload": (C.c_int32, [_vp]),
     "infur_model_info_get": (C.c_int32, [_vp, C.POINTER(ModelInfoC)]),
+    "infur_model_info_get_sized": (C.c_int32, [_vp, _vp, C.c_size_t]),
     "infur_model_advance": (C.c_int32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32p]),
     "infur_model_advance_dev": (C.c_int32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32p]),
     "infur_model_warmup": (C.c_int32, [_vp, _u32, _u32]),

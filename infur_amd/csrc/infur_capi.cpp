@@ -508,6 +508,8 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     mi.depth = (uint32_t)depth;
     mi.n_convs = n;
     mi.weight_bytes = total;
+    mi.quantised = 0;
+    mi.resize_u8_heads = 0;
     return INFUR_OK;
 }
 
@@ -1036,6 +1038,8 @@ int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
     mi.depth = (uint32_t)bh.depth;
     mi.n_convs = n;
     mi.weight_bytes = total;
+    mi.quantised = 1;
+    mi.resize_u8_heads = bh.resize_u8 ? 1 : 0;
     return INFUR_OK;
 }
 
@@ -1657,11 +1661,13 @@ int32_t infur_onnx_to_blob(const void* onnx, size_t len, void** blob, size_t* bl
 
 void infur_buffer_free(void* p) { free(p); }
 
-int32_t infur_model_info_get(const infur_ctx* c, infur_model_info* info) {
+int32_t infur_model_info_get(const infur_ctx* c, infur_model_info* info) { return infur_model_info_get_sized(c, info, sizeof *info); }
+
+int32_t infur_model_info_get_sized(const infur_ctx* c, void* info, size_t info_size) {
     enter(c);
-    if (!c || !info) return INFUR_E_INVALID_ARG;
+    if (!c || !info || info_size == 0) return INFUR_E_INVALID_ARG;
     if (!c->loaded) return INFUR_E_MODEL_NOT_LOADED;
-    *info = c->info;
+    memcpy(info, &c->info, info_size < sizeof c->info ? info_size : sizeof c->info);  // (an older, shorter struct gets its prefix)
     return INFUR_OK;
 }
 

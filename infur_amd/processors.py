@@ -296,6 +296,8 @@ class ModelInfo:
     num_classes: int = 0
     depth: int = 0
     weight_bytes: int = 0
+    quantised: bool = False        # a QOperator / QDQ int8 model: runs on the i8 MFMA whatever the context's dtype
+    resize_u8_heads: bool = False  # ... whose file resizes the u8 logits before DequantizeLinear
 
 
 class Model(Processor):
@@ -327,7 +329,7 @@ class Model(Processor):
         self.ctx.check(rc)
         outs = [bytes(mi.output_names[i]).split(b"\0", 1)[0].decode() for i in range(mi.n_outputs)]
         return ModelInfo([mi.input_name.decode()], mi.input0_dtype.decode(), outs, mi.num_classes, mi.depth,
-                         mi.weight_bytes)
+                         mi.weight_bytes, bool(mi.quantised), bool(mi.resize_u8_heads))
 
     def advance(self, img: np.ndarray, out: list) -> None:
         """Fills ``out`` with the model's outputs, each [num_classes, h, w] f32 -- [out, aux], or [out] alone for a

@@ -42,6 +42,8 @@ pub struct infur_model_info {
     pub depth: u32,
     pub n_convs: u32,
     pub weight_bytes: u64,
+    pub quantised: u32,
+    pub resize_u8_heads: u32,
 }
 
 pub const INFUR_OK: i32 = 0;
@@ -56,7 +58,7 @@ pub const INFUR_E_RCCL: i32 = 8;
 pub const INFUR_E_INVALID_ARG: i32 = 9;
 pub const INFUR_E_IO: i32 = 10;
 pub const INFUR_E_CAPACITY: i32 = 11;
-pub const INFUR_ABI_VERSION: u32 = 3;
+pub const INFUR_ABI_VERSION: u32 = 4;
 pub const INFUR_SCALE_NEAREST: u32 = 0;
 pub const INFUR_SCALE_BILINEAR: u32 = 1;
 pub const INFUR_DTYPE_F32: u32 = 0;
@@ -85,6 +87,7 @@ extern "C" {
     pub fn infur_model_load_blob(c: *mut infur_ctx, blob: *const c_void, len: usize) -> i32;
     pub fn infur_model_unload(c: *mut infur_ctx) -> i32;
     pub fn infur_model_info_get(c: *const infur_ctx, info: *mut infur_model_info) -> i32;
+    pub fn infur_model_info_get_sized(c: *const infur_ctx, info: *mut c_void, info_size: usize) -> i32;
     pub fn infur_model_advance(c: *mut infur_ctx, bgr: *const u8, w: u32, h: u32, out: *mut f32,
                                aux: *mut f32, n_outputs: *mut u32) -> i32;
 

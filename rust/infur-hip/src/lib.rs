@@ -147,7 +147,7 @@ impl Processor for HipScale {
 #[derive(Clone, Debug)]
 pub enum ModelCmd { Load(String) }
 #[derive(Debug, Clone)]
-pub struct ModelInfo { pub input_names: Vec<String>, pub input0_dtype: String, pub output_names: Vec<String> }
+pub struct ModelInfo { pub input_names: Vec<String>, pub input0_dtype: String, pub output_names: Vec<String>, pub quantised: bool, pub resize_u8_heads: bool }
 
 pub struct HipModel { ctx: Rc<Ctx> }
 impl HipModel {
@@ -164,6 +164,8 @@ impl HipModel {
             input_names: vec![s(mi.input_name.as_ptr())],
             input0_dtype: s(mi.input0_dtype.as_ptr()),
             output_names: (0..mi.n_outputs as usize).map(|i| s(mi.output_names[i].as_ptr())).collect(),
+            quantised: mi.quantised != 0,
+            resize_u8_heads: mi.resize_u8_heads != 0,
         })
     }
 }

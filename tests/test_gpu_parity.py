@@ -20,8 +20,20 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-3  # north_star: "logits within 1e-3 relative fp32"
 
 
+# max-abs / max-abs lets one large logit hide errors on the small ones, so the forward tests also grade the worst
+# PER-ELEMENT relative error over the elements with |ref| > 1e-2 max |ref| (the metric of tests/hostile.py::errors).  Measured in
+# the native f32 mode: 2e-4 (logits), 4e-4 (per layer), on friendly and hostile weights alike; the bar is 1e-3 like the other.
+ELEM_TOL = 1e-3
+
+
 def rel_err(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def elem_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    big = np.abs(b) > 1e-2 * np.abs(b).max()
+    return float((np.abs(a - b)[big] / np.abs(b[big])).max()) if big.any() else 0.0
 
 
 # --------------------------------------------------------------------------- #
@@ -261,17 +273,17 @@ def test_model_per_layer_against_torch_oracle(blob50):
     m.advance(fr, out)
     taps = {}
     tm.forward_lowres(co.pack_normalize(fr), taps=taps)
-    worst = 0.0
+    worst = worst_e = 0.0
     for i, spec in enumerate(W.graph(50)):
         ref = taps[spec.name].numpy()
         buf = np.empty(ref.shape, np.float32)
         c, h, w = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         c2.check(c2.L.infur_debug_read_activation(c2.h, i, buf.ctypes.data, buf.size, C.byref(c), C.byref(h), C.byref(w)))
         assert (c.value, h.value, w.value) == ref.shape, spec.name
-        e = rel_err(buf, ref)
-        worst = max(worst, e)
-        assert e < REL_TOL, (spec.name, e)
-    print("worst per-layer rel err", worst)
+        e, ee = rel_err(buf, ref), elem_err(buf, ref)
+        worst, worst_e = max(worst, e), max(worst_e, ee)
+        assert e < REL_TOL and ee < ELEM_TOL, (spec.name, e, ee)
+    print(f"worst per-layer error: max-abs / max-abs {worst:.2e}, per element {worst_e:.2e}")
     c2.close()
 
 
@@ -350,8 +362,10 @@ def test_full_size_properties(ctx, model, oracle, blob50, wh):
     assert (rgba1 == oracle.colorcode(oracle.upsample_bilinear(lo, h, w))).all()
     tl, ta = TorchModel(blob50).forward_lowres(oracle.pack_normalize(fr))
     e_out, e_aux = rel_err(lo, tl.numpy()), rel_err(la, ta.numpy())
-    print(f"{w}x{h}: low-res logits rel err out={e_out:.2e} aux={e_aux:.2e}")
+    p_out, p_aux = elem_err(lo, tl.numpy()), elem_err(la, ta.numpy())
+    print(f"{w}x{h}: low-res logits max-abs / max-abs out={e_out:.2e} aux={e_aux:.2e}; worst per-element out={p_out:.2e} aux={p_aux:.2e}")
     assert e_out < REL_TOL and e_aux < REL_TOL
+    assert p_out < ELEM_TOL and p_aux < ELEM_TOL
     ref_full = oracle.upsample_bilinear(tl.numpy(), h, w)
     nbad, unexplained = argmax_report(oracle, rgba1, ref_full, REL_TOL * np.abs(ref_full).max())
     print(f"{w}x{h}: {nbad} of {h*w} mask pixels differ from the CPU path; unexplained fraction {unexplained}")

@@ -94,8 +94,18 @@ def test_switching_between_float_and_quantised_models(qblob, blob50, oracle):
     fr = W.synth_frame(64, 96, index=1)
     with Context(device=0) as c:
         m = Model(c).control(ModelCmd.LoadBlob(blob50))
+        assert not m.get_info().quantised
         ref_f, _ = FramePath(c).advance(fr, 1.0)
         m.control(ModelCmd.LoadBlob(qblob))
+        assert m.get_info().quantised and not m.get_info().resize_u8_heads  # (ABI 4: the host can tell what it loaded)
+        # a host built against the ABI-3 struct (136 bytes) asks for its prefix only: nothing is written behind it
+        from infur_amd import _lib
+
+        buf = (C.c_uint8 * C.sizeof(_lib.ModelInfoC))()
+        C.memset(buf, 0xEE, len(buf))
+        assert c.L.infur_model_info_get_sized(c.h, buf, 136) == 0
+        assert bytes(buf[:5]) == b"input" and all(b == 0xEE for b in buf[136:])
+        assert c.L.infur_model_info_get_sized(c.h, buf, 0) == _lib.E_INVALID_ARG
         rq, _ = FramePath(c).advance(fr, 1.0)
         lo, _ = m.lowres()
         ref_lo, _ = Q.qforward(qblob, oracle.pack_normalize(fr))
@@ -123,7 +133,7 @@ def test_loading_the_qoperator_onnx_file_equals_the_blob(qblob, oracle, tmp_path
     with Context(device=0) as c:
         m = Model(c).control(ModelCmd.Load(str(p)))
         info = m.get_info()
-        assert info.input_names == ["input"] and info.output_names == ["out", "aux"] and info.depth == 50
+        assert info.input_names == ["input"] and info.output_names == ["out", "aux"] and info.depth == 50 and info.quantised
         rgba, _ = FramePath(c).advance(fr, 1.0)
         lo, la = m.lowres()
         assert (lo.view(np.uint32) == ref_lo.view(np.uint32)).all() and (la.view(np.uint32) == ref_aux.view(np.uint32)).all()
@@ -374,6 +384,7 @@ def test_models_that_resize_before_they_dequantise(qblob, oracle, size, tmp_path
             assert (out[0].view(np.uint32) == ref[0].view(np.uint32)).all() and (out[1].view(np.uint32) == ref[1].view(np.uint32)).all()
             rgba, _ = FramePath(c).advance(fr, 1.0)
             assert (rgba == oracle.colorcode(ref[0])).all()
+            assert m.get_info().quantised and m.get_info().resize_u8_heads
             lo, la = m.lowres()  # read back as logits: DequantizeLinear of the codes
             want = Q.qforward(qblob, oracle.pack_normalize(fr))
             assert (lo.view(np.uint32) == want[0].view(np.uint32)).all() and (la.view(np.uint32) == want[1].view(np.uint32)).all()
