@@ -1,0 +1,373 @@
+// conv3x3_halo.hip -- stride-1 3x3 convolution (pad = dilation), f16 operands, f32 accumulation: the INPUT PATCH of a ~16 x 16
+// output tile stays in LDS for all nine taps.  Replaces Conv nodes ONNX Runtime executes inside `session.run`
+// (infur/src/predict_onnx.rs:138): layer2 / layer3 conv2 and the heads of FCN-ResNet in the f16 mode.
+//
+// Why (round 4): the tiled implicit GEMM (conv_igemm_kernel.h) gathers the activation tile of every (tap, channel chunk) K step
+// from global memory -- nine shifted copies of nearly the same pixels per chunk.  At 1080p the stride-8 feature map has M =
+// 32,400 pixels, i.e. ONE 256-pixel tile per CU, and what bounds such a launch is not the MFMA but what a CU can take in from L2:
+// a 256 x 128 tile pulls 32 KB of activations + 16 KB of weights per K step for 1,024 cycles of MFMA work per SIMD -- 47 B/clk/CU
+// against the ~18-23 B/clk/CU the L2 -> LDS path sustains with all 256 CUs pulling (layer3 conv2: 53 us = 0.72 PFLOP/s).  Here a
+// workgroup owns a 16 x 16 block of output pixels; per 64-channel chunk it brings the (16 + 2d)^2 input pixels of the block's
+// halo into LDS ONCE (324 / 400 / 576 rows of 128 bytes for d = 1 / 2 / 4 instead of 9 x 256) and all nine taps read their
+// activation fragments from that patch at a per-tap row offset; only the weight tile (BN x 128 B) is new per tap.  Activation
+// ingest falls 5.8x (d = 2), the K step's L2 -> LDS traffic from 48 KB to ~22 KB, LDS write traffic with it.
+//
+// Shape: 8 waves, BN = 128 (waves 4 x 2, 64 pixels x 64 channels each) or BN = 256 (2 x 4, 128 x 64); everything arrives by
+// LDS-DMA (buffer_load ... lds, rows of 128 bytes, 16-byte chunk index XOR-swizzled by (row >> 1) & 7 on the SOURCE side, as in
+// conv_igemm_kernel.h); two weight images (tap t + 1 lands while tap t is multiplied), and two patch images when they fit the
+// 160 KB (the next chunk's patch lands piece by piece during this chunk's nine taps: one piece of 8 rows per wave and tap),
+// else one image and one extra barrier per chunk.  Out-of-image halo pixels are zeros through the descriptor's bounds check.
+//
+// Arithmetic: for every output element the k order is (channel chunk, tap, 16-wide slice) ascending with the weight fragment as
+// the MFMA's row operand -- the order conv_igemm_kernel.h uses for f16 KxK convolutions since round 4 (CMAJ) -- then + bias, ReLU,
+// round to f16: BIT-IDENTICAL to every tiled configuration (tests/test_gpu_conv_configs.py), so the tuner picks it by speed only.
+#include <atomic>
+
+#include "kernels.h"
+
+namespace infur {
+
+typedef float f32x16h __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8h __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_h;
+
+namespace {
+
+constexpr unsigned HOOB = 0x80000000u;
+constexpr int H_ROWB = 2 * 128 + 16;  // epilogue staging row of a wave: 64 f32 + pad
+
+__host__ __device__ constexpr int h_swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void h_dma16(const u32x4h rsrc, const unsigned lds, const unsigned voff, const unsigned soff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+
+__device__ __forceinline__ u32x4h h_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    u32x4h r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)v);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
+// A workgroup's output tile is th x tw pixels, th * tw <= 256 (the GEMM rows beyond th * tw are padding), chosen per launch so
+// that the number of workgroups fits the chip: 135 x 240 (1080p) cuts into 135 tiles of 16 x 16 but 128 of 17 x 15, and with
+// two N tiles that is 270 workgroups -- two rounds on 256 CUs, the second one 5 % full -- against 256: the first cut of this
+// kernel lost a factor of two right there.
+struct HaloGeom {
+    int th, tw;
+};
+__host__ __device__ constexpr int h_pieces(int th, int tw, int d) { return ((th + 2 * d) * (tw + 2 * d) + 7) / 8; }  // wave instructions of 8 rows
+__host__ __device__ constexpr int h_pimg(int th, int tw, int d) { return h_pieces(th, tw, d) * 1024; }
+// weight images: a ring of 3 for BN = 128 (the tap's 1,024 MFMA cycles per SIMD are shorter than the L2 latency: with one tap of
+// prefetch every step ended waiting for its successor's weights -- 2.6k cycles per tap), 2 for BN = 256 (2,048-cycle taps)
+__host__ __device__ constexpr int h_nb(int bn) { return bn == 128 ? 3 : 2; }
+__host__ __device__ constexpr int h_lds(int bn, int na, int th, int tw, int d) {
+    const int operands = na * h_pimg(th, tw, d) + h_nb(bn) * bn * 128;
+    const int staging = 8 * 32 * H_ROWB;
+    return operands > staging ? operands : staging;
+}
+
+template <int BN, int NA>
+__global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, const int th, const int tw, const int tiles_x, const int mtiles, const int ntiles) {
+    constexpr int WN = BN / 64, WM = 8 / WN;  // waves along N (64 channels each) / along M
+    constexpr int TM = 256 / WM / 32, TN = 2;
+    constexpr int B_IT = BN / 64;  // weight pieces (8 rows) per wave and tap
+    constexpr int NB = h_nb(BN);   // weight images (ring)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, hh = lane >> 5;
+    const int d = a.dil, PW = tw + 2 * d, P = PW * (th + 2 * d);
+    const int npiece = (P + 7) / 8, pimg = npiece * 1024;
+    const int npix = th * tw;              // GEMM rows that are pixels of the tile (the rest of the 256 is padding)
+    const float rtw = 1.0f / (float)tw;    // row -> (ty, tx): exact for these small integers
+    const int Kb = a.Cin * 2;      // bytes of a pixel's channels
+    const int cchunks = a.Cin / 64;
+
+    int tile;
+    {  // XCD-aware order (block b runs on XCD b % 8): every XCD gets a contiguous run of tiles, N fastest, so the N tiles
+       // that share a patch share one L2
+        const int nblk = mtiles * ntiles;
+        const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;
+        const int q = nblk >> 3, rem = nblk & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+    }
+    const int mt = tile / ntiles, nt = tile - mt * ntiles;
+    const int tyb = mt / tiles_x, txb = mt - tyb * tiles_x;
+    const int y0 = tyb * th, x0 = txb * tw, n0 = nt * BN;
+
+    char* const As = smem;              // [NA][npiece * 8 rows][128]
+    char* const Bs = smem + NA * pimg;  // [NB][BN][128]
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_h*)smem;
+    const u32x4h in_v = h_rsrc(a.in, (unsigned)((size_t)a.H * a.W * Kb));
+    const u32x4h wt_v = h_rsrc(a.wt, (unsigned)((size_t)a.Cout * 9 * Kb));
+
+    // ---- patch pieces: piece g = 8 t + wave is issued by this wave at tap t; lane l brings row p = 8 g + (l >> 3), LDS chunk
+    //      position l & 7 = data chunk (l & 7) ^ swz(p).  The per-lane byte offset holds for the whole K loop: the channel
+    //      chunk advances through the scalar offset. ----
+    unsigned a_voff[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int p = 8 * (8 * t + wave) + (lane >> 3);
+        const int py = p / PW, px = p - py * PW;
+        const int iy = y0 - d + py, ix = x0 - d + px;
+        const bool ok = p < P && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        a_voff[t] = ok ? (unsigned)(iy * a.W + ix) * (unsigned)Kb + (unsigned)(((lane & 7) ^ h_swz(p)) * 16) : HOOB;
+    }
+    unsigned b_voff[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; i++) {
+        const int row = 8 * (wave * B_IT + i) + (lane >> 3);
+        const int n = n0 + row;
+        b_voff[i] = n < a.Cout ? (unsigned)n * (unsigned)(9 * Kb) + (unsigned)(((lane & 7) ^ h_swz(row)) * 16) : HOOB;
+    }
+    auto dma_a = [&](const int t, const int cc, const int img) {  // this wave's patch piece of tap slot t, channel chunk cc
+        if (8 * t + wave < npiece)  // (wave-uniform)
+            h_dma16(in_v, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(img * pimg + (8 * t + wave) * 1024)), a_voff[t],
+                    __builtin_amdgcn_readfirstlane((unsigned)(cc * 128)));
+    };
+    auto dma_b = [&](const int cc, const int tap, const int img) {  // the weight tile of (chunk cc, tap): rows n0 .. n0 + BN - 1
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((tap * cchunks + cc) * 128));
+#pragma unroll
+        for (int i = 0; i < B_IT; i++)
+            h_dma16(wt_v, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(NA * pimg + img * (BN * 128) + (wave * B_IT + i) * 1024)), b_voff[i], soff);
+    };
+
+    // ---- lane-constant fragment addressing ----
+    int pbase[TM];  // patch row of this lane's pixel in block i at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int R = (wm * TM + i) * 32 + r;
+        const int ty = (int)(((float)R + 0.5f) * rtw), tx = R - ty * tw;
+        pbase[i] = R < npix ? ty * PW + tx : 0;  // (padding rows read a valid patch row; their results are never stored)
+    }
+    const int b_lds = (wn * 64 + r) * 128;
+    const int b_sw = h_swz(r);  // fragment rows are 32 apart: the swizzle does not change
+
+    f32x16h acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    // ---- prologue: the whole patch of chunk 0, the weights of the first NB - 1 taps ----
+#pragma unroll
+    for (int t = 0; t < 9; t++) dma_a(t, 0, 0);
+    dma_b(0, 0, 0);
+    if (NB == 3) dma_b(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto wait_vm = [](const int n) {  // s_waitcnt takes an immediate
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+        }
+    };
+
+    int bimg = 0;  // weight image of the current tap
+    for (int cc = 0; cc < cchunks; cc++) {
+        const int aimg = NA == 2 ? (cc & 1) : 0;
+        const bool more_chunks = cc + 1 < cchunks;
+        // (an opaque zero: without it the per-tap fragment addresses below are loop-invariant and the compiler keeps all 9 x TM of
+        //  them -- and their swizzles -- in registers across the chunk loop: 90 spilled VGPRs in the BN = 256 form)
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            // what this tap issues: its patch piece of the next chunk (two patch images), the weights NB - 1 taps ahead
+            const bool issue_a = NA == 2 && more_chunks && 8 * tap + wave < npiece;
+            const bool issue_b = more_chunks || tap + NB - 1 < 9;
+            const int bnext = bimg + NB - 1 >= NB ? bimg - 1 : bimg + NB - 1;  // (bimg + NB - 1) % NB
+            const int toff = (ky * PW + kx) * d + zero;  // (scalar) patch-row offset of this tap
+            // chunk (2 kk + hh) of row p sits at position (2 kk + hh) ^ swz(p) = (kk << 1) ^ (hh ^ swz(p)): one base address per
+            // block and tap, one XOR with a constant per slice (the swizzle of a patch row depends on the tap's row offset, so
+            // -- unlike the tiled kernel's -- it cannot be folded into the instruction's immediate)
+            unsigned abase[TM];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int p = pbase[i] + toff;
+                abase[i] = (unsigned)(aimg * pimg + p * 128) | (unsigned)((hh ^ h_swz(p)) << 4);
+            }
+            const char* Bb = Bs + bimg * (BN * 128) + b_lds;
+            auto read_slice = [&](const int kk, h16x8h (&fa)[TM], h16x8h (&fb)[TN]) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const h16x8h*>(As + (abase[i] ^ (unsigned)(kk << 5)));
+#pragma unroll
+                for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const h16x8h*>(Bb + j * 32 * 128 + (((2 * kk + hh) ^ b_sw) * 16));
+            };
+            // fragments run ONE slice ahead of the MFMAs (two register sets): with a fence per slice and no prefetch every slice paid
+            // its ds_read latency in full -- 3.8k cycles per tap for 1k of MFMA work (first cut: layer3 conv2 at 1080p 66 us against
+            // 45 for the tiled form)
+            h16x8h fa[2][TM], fb[2][TN];
+            read_slice(0, fa[0], fb[0]);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                if (kk < 3) read_slice(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+                // the DMA instructions go out behind a slice's fragment reads, in the shadow of MFMAs that already have their
+                // operands (the `dmai` placement of conv_igemm_kernel.h)
+                if (kk == 0 && issue_a) dma_a(tap, cc + 1, aimg ^ 1);
+                if (kk == 1 && issue_b) dma_b(tap + NB - 1 >= 9 ? cc + 1 : cc, tap + NB - 1 >= 9 ? tap + NB - 1 - 9 : tap + NB - 1, bnext);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
+            }
+            // The NEXT tap's weights must have landed (and, at a chunk's last tap, the next chunk's whole patch); loads retire in
+            // order, so what may stay in flight is exactly what was issued after them: with the ring of three, this tap's weight
+            // pieces (for tap + 2) and -- except at the chunk's end -- this tap's patch piece.  With two images nothing.
+            if (NB == 3)
+                wait_vm((issue_b ? B_IT : 0) + ((issue_a && tap < 8) ? 1 : 0));
+            else
+                wait_vm(0);
+            __builtin_amdgcn_s_barrier();
+            bimg = bimg + 1 == NB ? 0 : bimg + 1;
+        }
+        if (NA == 1 && more_chunks) {  // one patch image: it is free only now
+#pragma unroll
+            for (int t = 0; t < 9; t++) dma_a(t, cc + 1, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- epilogue: + bias, ReLU, f16; each wave passes its 32-pixel blocks through its own LDS slice so that 8 lanes store the
+    //      128 contiguous bytes of a pixel's 64 channels (the f16 -> f16 form of conv_igemm_kernel.h, same steps per value) ----
+    char* stage = smem + wave * 32 * H_ROWB;
+    const int e_row = lane >> 3, e_col = lane & 7;
+    const int n = n0 + wn * 64 + e_col * 8;
+    const bool n_ok = n < a.Cout;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bv2 = bv;
+    if (a.bias && n_ok) {
+        bv = *reinterpret_cast<const float4*>(a.bias + n);
+        bv2 = *reinterpret_cast<const float4*>(a.bias + n + 4);
+    }
+    _Float16* out = static_cast<_Float16*>(a.out);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int jj = 0; jj < TN; jj++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 v = make_float4(acc[i][jj][4 * g + 0], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
+                *reinterpret_cast<float4*>(stage + r * H_ROWB + (jj * 32 + 8 * g + 4 * hh) * 4) = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = it * 8 + e_row;
+            const int R = (wm * TM + i) * 32 + row;
+            const int ty = (int)(((float)R + 0.5f) * rtw), tx = R - ty * tw;
+            const int oy = y0 + ty, ox = x0 + tx;
+            if (R < npix && oy < a.OH && ox < a.OW && n_ok) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + row * H_ROWB + e_col * 32);
+                const float4 v2 = *reinterpret_cast<const float4*>(stage + row * H_ROWB + e_col * 32 + 16);
+                float x[8] = {v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w, v2.x + bv2.x, v2.y + bv2.y, v2.z + bv2.z, v2.w + bv2.w};
+                if (a.relu) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++) x[t] = fmaxf(x[t], 0.f);
+                }
+                const h16x8h hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3],
+                                   (_Float16)x[4], (_Float16)x[5], (_Float16)x[6], (_Float16)x[7]};
+                *reinterpret_cast<h16x8h*>(out + ((size_t)oy * a.OW + ox) * a.Cout + n) = hv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Tile shape and patch images for one launch: fewest rounds of workgroups on the chip first (a CU holds 160 KB / LDS footprint
+// of them), then the fewest padded GEMM rows, then the smallest patch; 16-wide tiles win ties (a 16-lane read group then covers
+// 16 consecutive patch rows: no bank conflict at all).
+constexpr HaloGeom kShapes[] = {{16, 16}, {17, 15}, {15, 17}, {14, 18}, {18, 14}, {13, 19}, {19, 13}, {12, 21}, {21, 12}, {11, 23}, {23, 11},
+                                {10, 25}, {25, 10}, {8, 32}, {32, 8}, {9, 28}, {28, 9}};
+struct HaloPlan {
+    int th = 0, tw = 0, na = 0, lds = 0;
+};
+HaloPlan halo_plan(const ConvArgs& a, int bn) {
+    HaloPlan best;
+    long best_cost[3] = {0, 0, 0};
+    const int ntiles = a.Cout / bn;
+    for (const HaloGeom& g : kShapes)
+        for (int na = 2; na >= 1; na--) {
+            const int lds = h_lds(bn, na, g.th, g.tw, a.dil);
+            if (lds > 160 * 1024 || h_pieces(g.th, g.tw, a.dil) > 72) continue;  // (72 = 9 tap slots x 8 waves of patch pieces)
+            const long tiles = (long)((a.OH + g.th - 1) / g.th) * ((a.OW + g.tw - 1) / g.tw);
+            // two workgroups share a CU only in the BN = 128 form with one patch image (<= 128 VGPRs) and <= 80 KB of LDS
+            const long per_cu = (bn == 128 && na == 1 && lds <= 80 * 1024) ? 2 : 1;
+            const long wgs = tiles * ntiles, slots = 256L * per_cu;
+            // one patch image costs a barrier + an exposed patch load per channel chunk: ~10 % of a round
+            const long cost[3] = {(wgs + slots - 1) / slots * (na == 1 ? 11 : 10), tiles, (long)(g.th + 2 * a.dil) * (g.tw + 2 * a.dil)};
+            bool better = best.th == 0;
+            for (int k = 0; k < 3 && !better; k++) {
+                if (cost[k] < best_cost[k]) better = true;
+                else if (cost[k] > best_cost[k]) break;
+            }
+            if (better) {
+                best.th = g.th; best.tw = g.tw; best.na = na; best.lds = lds;
+                for (int k = 0; k < 3; k++) best_cost[k] = cost[k];
+            }
+        }
+    return best;
+}
+
+template <int BN, int NA>
+hipError_t launch_halo(const ConvArgs& a, const HaloPlan& pl, hipStream_t s) {
+    const int tiles_x = (a.OW + pl.tw - 1) / pl.tw, tiles_y = (a.OH + pl.th - 1) / pl.th;
+    const int mtiles = tiles_x * tiles_y, ntiles = a.Cout / BN;
+    auto k = conv3x3_halo_kernel<BN, NA>;
+    // (the LDS size depends on the dilation and the tile shape: the attribute is raised to the largest footprint there is)
+    static std::atomic<bool> attr_done[64];
+    int dev = 0;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (!known || !attr_done[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (known) attr_done[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(k, dim3(mtiles * ntiles), dim3(512), pl.lds, s, a, pl.th, pl.tw, tiles_x, mtiles, ntiles);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn) {
+    if (mode != 1 || out_f32 || (bn != 128 && bn != 256)) return false;
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != a.dil || (a.dil != 1 && a.dil != 2 && a.dil != 4)) return false;
+    if (a.res || a.in2 || a.batch > 1 || a.OH != a.H || a.OW != a.W) return false;
+    if (a.Cin % 64 != 0 || a.Cout % bn != 0 || (a.Cout & 7)) return false;
+    if (halo_plan(a, bn).th == 0) return false;
+    // 32-bit buffer offsets with 0x80000000 (+ the channel chunk's scalar offset) as the out-of-range marker
+    return (size_t)a.H * a.W * a.Cin * 2 < 0x80000000ull && (size_t)a.Cout * 9 * a.Cin * 2 < 0x80000000ull;
+}
+
+hipError_t launch_conv3x3_halo(const ConvArgs& a, int bn, hipStream_t s) {
+    if (!conv3x3_halo_valid(a, 1, 0, bn)) return hipErrorInvalidValue;
+    const HaloPlan pl = halo_plan(a, bn);
+    if (bn == 128) return pl.na == 2 ? launch_halo<128, 2>(a, pl, s) : launch_halo<128, 1>(a, pl, s);
+    return pl.na == 2 ? launch_halo<256, 2>(a, pl, s) : launch_halo<256, 1>(a, pl, s);
+}
+
+}  // namespace infur

@@ -246,6 +246,10 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
     const int wm = wave / WN, wn = wave % WN;
 
     static_assert(!DUAL || (G1 && !RESPF), "DUAL is a form of the 1x1 GEMM addressing");
+    // f16 KxK convolutions walk K with the TAPS INSIDE each 128-byte channel chunk (chunk-major): the order in which
+    // conv3x3_halo.hip -- whose input patch stays in LDS for all nine taps of a chunk -- has to sum, so that it remains one more
+    // bit-identical configuration.  For this kernel the order is cost-neutral (round 3 measured it: 154.7 vs 155.6 us).
+    constexpr bool CMAJ = std::is_same<T, _Float16>::value && !G1 && !SPLIT;
     const int M = a.OH * a.OW;
     const int Ktot = DUAL ? a.Cin + a.Cin2 : a.KH * a.KW * a.Cin;
 
@@ -362,16 +366,30 @@ __global__ void __launch_bounds__(WM* WN * 64, min_waves_per_simd(BM, BN, WM, WN
                 ra[i] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off : OOB, 0, 0);
         }
         // advance (ky,kx,cc) to the next K step, branch-free (all wave-uniform scalars)
-        cc += 1;
-        const int w1 = cc == cchunks;
-        cc = w1 ? 0 : cc;
-        kx += w1;
-        const int w2 = kx == a.KW;
-        kx = w2 ? 0 : kx;
-        ky += w2;
+        if constexpr (CMAJ) {
+            kx += 1;
+            const int w1 = kx == a.KW;
+            kx = w1 ? 0 : kx;
+            ky += w1;
+            const int w2 = ky == a.KH;
+            ky = w2 ? 0 : ky;
+            cc += w2;
+        } else {
+            cc += 1;
+            const int w1 = cc == cchunks;
+            cc = w1 ? 0 : cc;
+            kx += w1;
+            const int w2 = kx == a.KW;
+            kx = w2 ? 0 : kx;
+            ky += w2;
+        }
     };
     auto load_b = [&](int ks) {
-        const unsigned koff = (unsigned)ks * (unsigned)ROW_BYTES;
+        unsigned koff = (unsigned)ks * (unsigned)ROW_BYTES;
+        if constexpr (CMAJ) {  // K step ks = (chunk, tap), the weight row is [tap][chunk]
+            const int taps = a.KH * a.KW, c_ = ks / taps, t_ = ks - c_ * taps;
+            koff = (unsigned)(t_ * cchunks + c_) * (unsigned)ROW_BYTES;
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; i++) {  // K step in the scalar offset
             if constexpr (GLDS)
@@ -1037,6 +1055,10 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
             if constexpr (std::is_same<T, signed char>::value && std::is_same<OutT, unsigned char>::value) {
                 if (conv1x1_q8_valid(a, 4, 0)) return launch_conv1x1_q8(a, 1, s);
             }
+            return hipErrorInvalidValue;
+        case 19:
+        case 20:
+            if constexpr (std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value && !SPLIT) return launch_conv3x3_halo(a, cfg == 19 ? 128 : 256, s);
             return hipErrorInvalidValue;
         case 18:
             if constexpr (std::is_same<T, signed char>::value && std::is_same<OutT, unsigned char>::value) {

@@ -271,13 +271,16 @@ int conv_out(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1
 // 4x) and 1.9x instead of 2.27x the tensor in transform traffic.  Measured against the f32 CPU oracle (scripts/
 // f6_split_check.py): per-layer worst 1.07e-5 (F(4x4): 1.12e-5), whole-network logits 6-7e-6 in the exact-f32 mode
 // (F(4x4): 4-5e-6) and 4-6e-6 in the split mode (3e-6) -- north_star's budget is 1e-3.
-// INFUR_DTYPE_F32_SPLIT_FP8 (bf8 cross terms, products exact to ~2^-13) defaults to F(4x4): the F(6x6) output transform
-// amplifies the product error -- hostile parameters, 1080p, worst per-element error 1.03e-2 with F(6x6) against 6.95e-3 with
-// F(4x4) (max-abs 1.4e-4 / 1.1e-4; profiles/r04_hostile_probe.log) -- for 7 % of that mode's frame time.
+// (INFUR_DTYPE_F32_SPLIT_FP8, bf8 cross terms: F(4x4) was tried as that mode's default because the F(6x6) output transform
+// amplifies the product error a little -- hostile parameters, 1080p: 1.4e-4 max-abs / 1.03e-2 worst per-element with F(6x6),
+// 1.1e-4 / 6.95e-3 with F(4x4), 1.0e-4 / 8.2e-3 with direct convolutions (profiles/r04_hostile_probe.log): all at the 1e-2 line
+// within the noise of a maximum over 680,000 elements -- but it costs 7.5 % of the frame (5.00 -> 5.38 ms) and puts the mode BELOW
+// the three-MFMA split mode it exists to beat (205 against 209 frames/s, bench.py on one box).  F(6x6) stays; options.winograd_tile
+// = 4 is the knob for a host that wants the margin.)
 inline int wino_mt(const infur_ctx* c) {
     const uint32_t t = c->opt.winograd_tile;
     if (t == 2 || t == 4 || t == 6) return (int)t;
-    return c->opt.compute_dtype == INFUR_DTYPE_F32_SPLIT_FP8 ? 4 : 6;
+    return 6;
 }
 inline int wino_planes(const infur_ctx* c) { return (wino_mt(c) + 2) * (wino_mt(c) + 2); }
 
@@ -555,8 +558,14 @@ int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cf
     }
     float best = 1e30f;
     std::vector<std::pair<int, float>> timed;
+    // (configuration 20 -- the BN = 256 form of conv3x3_halo.hip -- is not a tuning candidate: timed in isolation, with its operands
+    //  warm in the Infinity Cache, it beats the tiled `dmai` form on the long-K head convs by 2-4 %; inside a frame, where its
+    //  one-patch-image chunk boundaries meet HBM latency, it is 5-12 % slower (classifier.0 at 1080p 535 against 477 us).  It stays
+    //  selectable -- INFUR_CONV_CFG=20, INFUR_TUNE_HALO256=1 -- and bit-identical: tests/test_gpu_halo.py.)
+    static const bool tune_halo256 = getenv("INFUR_TUNE_HALO256") != nullptr;
     for (int k = 0; k < conv_igemm_num_configs(); k++) {
         if (!conv_igemm_config_valid(a, k, mode, out_f32)) continue;
+        if (k == 20 && !tune_halo256) continue;
         // a candidate that cannot launch on this shape after all (invalid value) is skipped, not fatal: the layer still
         // has the other configurations; anything else (a fault, a lost device) is an error of the frame
         const hipError_t le = launch_conv_igemm(a, mode, out_f32, k, c->stream);  // warm-up (attributes, caches)

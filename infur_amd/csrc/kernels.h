@@ -81,6 +81,11 @@ bool conv1x1_q8_valid(const ConvArgs& a, int mode, int out_f32);
 hipError_t launch_conv1x1_q8(const ConvArgs& a, int nsplit, hipStream_t s);
 int conv1x1_q8_nsplit(const ConvArgs& a);  // configuration 18: N tiles shared out over this many workgroups per M tile (0: not a candidate)
 
+// stride-1 3x3 convolutions (pad = dilation 1 / 2 / 4), f16 operands and output, no residual: the input patch of a 16 x 16 output
+// tile stays in LDS for all nine taps (conv3x3_halo.hip).  Configurations 19 (bn = 128) and 20 (bn = 256) of mode 1.
+bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn);
+hipError_t launch_conv3x3_halo(const ConvArgs& a, int bn, hipStream_t s);
+
 // Two 1x1 convolutions back to back on the same pixels, f16 (conv1x1_b2b.hip): y = ReLU(w3 * in + b3 + res) -- a
 // bottleneck's conv3 + residual -- is written once and immediately multiplied by the NEXT bottleneck's conv1 weights:
 // out2 = ReLU(w1 * y + b1).  C2 = channels of `in` = channels of out2 (128 or 256); y and res have 4 * C2 channels.
