@@ -53,22 +53,25 @@ namespace {
 constexpr int BB_BM = 256;   // pixels per workgroup
 constexpr int BB_NT = 32;    // channels of y per step
 constexpr int BB_NSLOT = 3;  // ring depth: step t computes while t + 1 and t + 2 are in flight
+#ifndef B2B_PF4
+#define B2B_PF4 8
+#endif
 
 // LDS: three rings, each contiguous (so that one lane-constant VGPR per operand plus an immediate reaches every slot),
 // then the two bias tables.
-template <int KS>
+template <int KS, int BM = BB_BM>
 struct B2bLds {
     static constexpr int C2 = 64 * KS, C4 = 4 * C2, N2 = C2;
     static constexpr int W3_SLICE = BB_NT * C2 * 2;  // 32 rows x C2 f16: KS sub-images [32 rows][128 B]
     static constexpr int W1_SLICE = N2 * BB_NT * 2;  // N2 rows x 64 B
-    static constexpr int RSLOT = BB_BM * 64;         // [256 px][64 B]: residual in, y out (in place); a wave owns its rows
+    static constexpr int RSLOT = BM * 64;            // [BM px][64 B]: residual in, y out (in place); a wave owns its rows
     static constexpr int OFF_W3 = 0;
     static constexpr int OFF_W1 = OFF_W3 + BB_NSLOT * W3_SLICE;
     static constexpr int OFF_R = OFF_W1 + BB_NSLOT * W1_SLICE;
     static constexpr int OFF_B3 = OFF_R + BB_NSLOT * RSLOT;
     static constexpr int OFF_B1 = OFF_B3 + C4 * 4;
     static constexpr int TOTAL = OFF_B1 + N2 * 4;
-    static constexpr int FINAL = BB_BM * N2 * 2;     // staging of t1' (over the idle rings)
+    static constexpr int FINAL = BM * N2 * 2;        // staging of t1' (over the idle rings)
     static_assert(FINAL <= OFF_B3, "the t1' staging must not reach the bias tables");
     static_assert(TOTAL <= 160 * 1024, "LDS");
     static_assert(BB_NSLOT * W3_SLICE <= 65536 && BB_NSLOT * W1_SLICE <= 65536 && BB_NSLOT * RSLOT <= 65536, "16-bit DS offsets");
@@ -119,22 +122,28 @@ __global__ void b2b_pack_w3_kernel(const _Float16* __restrict__ src, _Float16* _
     reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[(size_t)srow * chunks_per_row + ch];
 }
 
-// KS = C2 / 64 (2: layer2, 4: layer3 of a ResNet-50/101).  A wave owns RB blocks of 32 pixels; NW waves x RB x 32 = 256.
+// KS = C2 / 64 (2: layer2, 4: layer3 of a ResNet-50/101).  A wave owns RB blocks of 32 pixels; a workgroup NW x RB x 32 pixels.
 //   <KS, 1, 8>: two waves per SIMD, <= 256 registers each (A fragment 16 KS, GEMM-2 accumulators 32 KS, one weight fragment
 //               in flight: the two waves of a SIMD cover each other's LDS latency)
 //   <KS, 2, 4>: one wave per SIMD with the whole 512-register file: every weight fragment feeds two MFMAs (half the LDS
 //               reads) and there is room to keep several fragments in flight
+//   <KS, 1, 4>: 128 pixels per workgroup (round 4): at 1080p the stride-8 map has M = 32,400 pixels = 127 workgroups of 256 --
+//               half the chip idle for the whole launch; 254 workgroups of 128 put one on every CU.  One wave per SIMD and the
+//               full weight stream per 128 pixels make the workgroup less efficient (nothing covers a wave held at a DMA issue),
+//               but it does half the work: picked when the 256-pixel form would leave more than a third of the CUs empty
 template <int KS, int RB, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) conv1x1_b2b_kernel(const B2bArgs a, const int mtiles, const int dma_phase) {
-    using L = B2bLds<KS>;
+    constexpr int BM = NW * RB * 32;
+    using L = B2bLds<KS, BM>;
     constexpr int C2 = L::C2, C4 = L::C4, N2 = L::N2, NJ = N2 / 32, NSTEP = C4 / BB_NT, NSL = KS * 4;
     constexpr int NT = NW * 64;
     constexpr int NPW = KS * 4 / NW;       // DMA pieces (1 KB) per wave and step for each weight slice
     constexpr int NPR = 2 * RB;            // ... and residual pieces (16 pixels x 64 B each)
     constexpr int PP = 2 * NPW + NPR;
-    constexpr int PF = RB == 1 ? 2 : 6;    // weight fragments in flight per wave
+    // weight fragments in flight per wave (one wave per SIMD has the whole register file: nothing else covers its ds_read latency)
+    constexpr int PF = RB == 1 ? (NW == 4 ? B2B_PF4 : 2) : 6;
     static_assert(KS == 2 || KS == 4, "C2 = 128 or 256");
-    static_assert(NW * RB * 32 == BB_BM && NPW >= 1, "tile");
+    static_assert((BM == 256 || BM == 128) && NPW >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: every per-wave address below stays in SGPRs
@@ -146,7 +155,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) conv1x1_b2b_kernel(c
         const int q = mtiles >> 3, rem = mtiles & 7;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
     }
-    const int m0w = tile * BB_BM + wave * (32 * RB);  // first pixel of this wave
+    const int m0w = tile * BM + wave * (32 * RB);  // first pixel of this wave
 
     // ---- the wave's activation fragments, loaded once: pixel m0w + 32 ib + r, all C2 channels (rows >= M lie beyond
     //      num_records: zeros) ----
@@ -386,13 +395,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) conv1x1_b2b_kernel(c
 
 template <int KS, int RB, int NW>
 hipError_t launch_form(const B2bArgs& a, hipStream_t s) {
-    const int mtiles = (a.M + BB_BM - 1) / BB_BM;
+    constexpr int BM = NW * RB * 32;
+    constexpr int kLds = B2bLds<KS, BM>::TOTAL;
+    const int mtiles = (a.M + BM - 1) / BM;
     auto k = conv1x1_b2b_kernel<KS, RB, NW>;
     static std::atomic<bool> attr_done[64];
     int dev = 0;
     const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
     if (!known || !attr_done[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, B2bLds<KS>::TOTAL);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return e;
         if (known) attr_done[dev].store(true, std::memory_order_release);
     }
@@ -400,7 +411,7 @@ hipError_t launch_form(const B2bArgs& a, hipStream_t s) {
     //  157 instead of 188 us with HALF the weight / residual pieces missing: the step is bound by the DMA ingest, not by its MFMAs)
     static const int dma_env = getenv("INFUR_B2B_DMA") ? atoi(getenv("INFUR_B2B_DMA")) : 2;
     static const int dma_phase = dma_env < 0 || dma_env > 2 ? 2 : dma_env;
-    hipLaunchKernelGGL(k, dim3(mtiles), dim3(NW * 64), B2bLds<KS>::TOTAL, s, a, mtiles, dma_phase);
+    hipLaunchKernelGGL(k, dim3(mtiles), dim3(NW * 64), kLds, s, a, mtiles, dma_phase);
     return hipGetLastError();
 }
 
@@ -431,8 +442,13 @@ hipError_t launch_conv1x1_b2b(const B2bArgs& a, hipStream_t s) {
     // measurement hook: INFUR_B2B_FORM=1 (default) two waves per SIMD x 32 pixels; 2 one wave per SIMD x 64 pixels with the
     // whole register file -- half the LDS fragment reads, but nothing covers the wave while it is held at a DMA issue or in
     // its epilogue: 237 against 170 us on the 4K layer3 pair (same box)
-    static const int form = getenv("INFUR_B2B_FORM") ? atoi(getenv("INFUR_B2B_FORM")) : 1;
+    // INFUR_B2B_FORM (measurement hook): 1 two waves per SIMD x 32 pixels; 2 one wave per SIMD x 64 pixels; 3 the 128-pixel workgroup;
+    // default: 3 when 256-pixel workgroups would leave more than a third of the 256 CUs without one, else 1
+    static const int form_env = getenv("INFUR_B2B_FORM") ? atoi(getenv("INFUR_B2B_FORM")) : 0;
+    const int mt256 = (a.M + 255) / 256;
+    const int form = form_env >= 1 && form_env <= 3 ? form_env : (mt256 <= 170 ? 3 : 1);
     if (form == 1) return a.C2 == 256 ? launch_form<4, 1, 8>(a, s) : launch_form<2, 1, 8>(a, s);
+    if (form == 3) return a.C2 == 256 ? launch_form<4, 1, 4>(a, s) : launch_form<2, 1, 4>(a, s);
     return a.C2 == 256 ? launch_form<4, 2, 4>(a, s) : launch_form<2, 2, 4>(a, s);
 }
 

@@ -3,3 +3,4 @@ bash scripts/gpu_profile.sh f32s > gpurun_out/prof_f32s.log 2>&1; tail -2 gpurun
 bash scripts/gpu_profile.sh f32x > gpurun_out/prof_f32x.log 2>&1; tail -2 gpurun_out/prof_f32x.log
 bash scripts/gpu_profile.sh f16 > gpurun_out/prof_f16.log 2>&1; tail -2 gpurun_out/prof_f16.log
 bash scripts/gpu_profile.sh f16 4k --depth 101 --width 3840 --height 2160 --frames-per-step 2 > gpurun_out/prof_f16_4k.log 2>&1; tail -2 gpurun_out/prof_f16_4k.log
+bash scripts/gpu_profile.sh i8 > gpurun_out/prof_i8.log 2>&1; tail -2 gpurun_out/prof_i8.log

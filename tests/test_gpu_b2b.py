@@ -43,19 +43,23 @@ np.savez(sys.argv[2], **out)
 """
 
 
-def run(b2b, depth, path):
+def run(b2b, depth, path, form=None):
     env = dict(os.environ)
     env["INFUR_B2B"] = str(b2b)
+    env.pop("INFUR_B2B_FORM", None)
+    if form is not None:
+        env["INFUR_B2B_FORM"] = str(form)  # 1: 8 waves x 32 pixels, 2: 4 waves x 64 pixels, 3: the 128-pixel workgroup (4 waves x 32)
     subprocess.run([sys.executable, "-c", SCRIPT, ROOT, path, str(depth)], check=True, env=env, timeout=900)
     return np.load(path)
 
 
-@pytest.mark.parametrize("depth,pairs", [(50, 6), (101, 23)])
-def test_fused_pair_is_bit_identical_to_two_launches(tmp_path, depth, pairs):
+@pytest.mark.parametrize("depth,pairs,form", [(50, 6, 1), (50, 6, 3), (50, 6, 2), (101, 23, 1), (101, 23, 3), (50, 6, None)])
+def test_fused_pair_is_bit_identical_to_two_launches(tmp_path, depth, pairs, form):
     """layer2: blocks 1-2 of 4, layer3: blocks 1..n-2 (block 0's conv3 is the two-source GEMM with the downsample branch,
-    the last block's successor belongs to the next stage): 2 + 4 pairs in a ResNet-50, 2 + 21 in a ResNet-101"""
+    the last block's successor belongs to the next stage): 2 + 4 pairs in a ResNet-50, 2 + 21 in a ResNet-101.  Every
+    workgroup form (the 256-pixel forms and round 4's 128-pixel one; None = the launcher's own choice by M)"""
     ref = run(0, depth, str(tmp_path / "two.npz"))
-    got = run(1, depth, str(tmp_path / "fused.npz"))
+    got = run(1, depth, str(tmp_path / "fused.npz"), form)
     assert set(ref.files) == set(got.files)
     n_act = sum(1 for k in ref.files if k.startswith("act"))
     assert n_act > 100
