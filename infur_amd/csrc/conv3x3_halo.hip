@@ -1,4 +1,4 @@
-// conv3x3_halo.hip -- stride-1 3x3 convolution (pad = dilation), f16 operands, f32 accumulation: the INPUT PATCH of a ~16 x 16
+// conv3x3_halo.hip -- stride-1 3x3 convolution (pad = dilation), f16 operands, f32 accumulation: the INPUT PATCH of a 16 x 16
 // output tile stays in LDS for all nine taps.  Replaces Conv nodes ONNX Runtime executes inside `session.run`
 // (infur/src/predict_onnx.rs:138): layer2 / layer3 conv2 and the heads of FCN-ResNet in the f16 mode.
 //
@@ -62,12 +62,19 @@ __device__ __forceinline__ u32x4h h_rsrc(const void* p, unsigned bytes) {
     return r;
 }
 
-// A workgroup's output tile is th x tw pixels, th * tw <= 256 (the GEMM rows beyond th * tw are padding), chosen per launch so
-// that the number of workgroups fits the chip: 135 x 240 (1080p) cuts into 135 tiles of 16 x 16 but 128 of 17 x 15, and with
-// two N tiles that is 270 workgroups -- two rounds on 256 CUs, the second one 5 % full -- against 256: the first cut of this
-// kernel lost a factor of two right there.
+// A workgroup's output tile is th x tw pixels, th * tw <= 256 (GEMM rows beyond th * tw are padding).  tw is 16 or 32 ONLY: the
+// hardware serves a ds_read_b128 in groups of 16 lanes, a group is conflict-free iff its 16 patch rows differ mod 16, and with the
+// (row >> 1) & 7 swizzle that holds when the 16 lanes are 16 consecutive pixels of ONE tile row -- a 17 x 15 tile (which cuts
+// 1080p's 135 x 240 map into exactly 128 tiles) wraps inside every group: 4.9 M bank-conflict cycles per launch, every activation
+// fragment read served in two passes (profiles/r04_f16_summary.md, first collection).  The count of workgroups is made to fit the
+// chip with TWO REGIONS instead: 16 x 16 tiles over the first floor(H / 16) * 16 rows and, when no more than 8 rows remain, a
+// strip of (H mod 16) x 32 tiles -- 135 x 240: 120 + 8 = 128 tiles instead of 135 (270 workgroups with two N tiles: two rounds on
+// 256 CUs, the second 5 % full).
 struct HaloGeom {
-    int th, tw;
+    int th1, tw1, tiles_x1, n1;  // region 1: rows [0, ysplit)
+    int ysplit;
+    int th2, tw2, tiles_x2;      // region 2: rows [ysplit, H); th2 == 0: none
+    int mtiles;
 };
 __host__ __device__ constexpr int h_pieces(int th, int tw, int d) { return ((th + 2 * d) * (tw + 2 * d) + 7) / 8; }  // wave instructions of 8 rows
 __host__ __device__ constexpr int h_pimg(int th, int tw, int d) { return h_pieces(th, tw, d) * 1024; }
@@ -81,7 +88,7 @@ __host__ __device__ constexpr int h_lds(int bn, int na, int th, int tw, int d) {
 }
 
 template <int BN, int NA>
-__global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, const int th, const int tw, const int tiles_x, const int mtiles, const int ntiles) {
+__global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, const HaloGeom g, const int ntiles) {
     constexpr int WN = BN / 64, WM = 8 / WN;  // waves along N (64 channels each) / along M
     constexpr int TM = 256 / WM / 32, TN = 2;
     constexpr int B_IT = BN / 64;  // weight pieces (8 rows) per wave and tap
@@ -91,24 +98,26 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, hh = lane >> 5;
+    int tile;
+    {  // XCD-aware order (block b runs on XCD b % 8): every XCD gets a contiguous run of tiles, N fastest, so the N tiles
+       // that share a patch share one L2
+        const int nblk = g.mtiles * ntiles;
+        const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;
+        const int q = nblk >> 3, rem = nblk & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+    }
+    const int mt = tile / ntiles, nt = tile - mt * ntiles;
+    const bool r2 = mt >= g.n1;  // (workgroup-uniform) the strip region
+    const int th = r2 ? g.th2 : g.th1, tw = r2 ? g.tw2 : g.tw1, tiles_x = r2 ? g.tiles_x2 : g.tiles_x1;
+    const int mloc = r2 ? mt - g.n1 : mt;
+    const int tyb = mloc / tiles_x, txb = mloc - tyb * tiles_x;
+    const int y0 = (r2 ? g.ysplit : 0) + tyb * th, x0 = txb * tw, n0 = nt * BN;
     const int d = a.dil, PW = tw + 2 * d, P = PW * (th + 2 * d);
     const int npiece = (P + 7) / 8, pimg = npiece * 1024;
     const int npix = th * tw;              // GEMM rows that are pixels of the tile (the rest of the 256 is padding)
     const float rtw = 1.0f / (float)tw;    // row -> (ty, tx): exact for these small integers
     const int Kb = a.Cin * 2;      // bytes of a pixel's channels
     const int cchunks = a.Cin / 64;
-
-    int tile;
-    {  // XCD-aware order (block b runs on XCD b % 8): every XCD gets a contiguous run of tiles, N fastest, so the N tiles
-       // that share a patch share one L2
-        const int nblk = mtiles * ntiles;
-        const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;
-        const int q = nblk >> 3, rem = nblk & 7;
-        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
-    }
-    const int mt = tile / ntiles, nt = tile - mt * ntiles;
-    const int tyb = mt / tiles_x, txb = mt - tyb * tiles_x;
-    const int y0 = tyb * th, x0 = txb * tw, n0 = nt * BN;
 
     char* const As = smem;              // [NA][npiece * 8 rows][128]
     char* const Bs = smem + NA * pimg;  // [NB][BN][128]
@@ -298,35 +307,47 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
     }
 }
 
-// Tile shape and patch images for one launch: fewest rounds of workgroups on the chip first (a CU holds 160 KB / LDS footprint
-// of them), then the fewest padded GEMM rows, then the smallest patch; 16-wide tiles win ties (a 16-lane read group then covers
-// 16 consecutive patch rows: no bank conflict at all).
-constexpr HaloGeom kShapes[] = {{16, 16}, {17, 15}, {15, 17}, {14, 18}, {18, 14}, {13, 19}, {19, 13}, {12, 21}, {21, 12}, {11, 23}, {23, 11},
-                                {10, 25}, {25, 10}, {8, 32}, {32, 8}, {9, 28}, {28, 9}};
+// Tiling and patch images for one launch: fewest rounds of workgroups on the chip first, then the fewest tiles, then the smallest
+// patch.  Candidates: uniform 16 x 16, uniform 8 x 32, and 16 x 16 with an (H mod 16) x 32 strip when H mod 16 <= 8.
 struct HaloPlan {
-    int th = 0, tw = 0, na = 0, lds = 0;
+    HaloGeom g{};
+    int na = 0, lds = 0;
 };
 HaloPlan halo_plan(const ConvArgs& a, int bn) {
     HaloPlan best;
     long best_cost[3] = {0, 0, 0};
-    const int ntiles = a.Cout / bn;
-    for (const HaloGeom& g : kShapes)
+    const int ntiles = a.Cout / bn, d = a.dil, H = a.OH, W = a.OW;
+    auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    HaloGeom cands[3];
+    int nc = 0;
+    cands[nc++] = HaloGeom{16, 16, cdiv(W, 16), cdiv(H, 16) * cdiv(W, 16), H, 0, 0, 0, cdiv(H, 16) * cdiv(W, 16)};
+    cands[nc++] = HaloGeom{8, 32, cdiv(W, 32), cdiv(H, 8) * cdiv(W, 32), H, 0, 0, 0, cdiv(H, 8) * cdiv(W, 32)};
+    if (H >= 16 && H % 16 != 0 && H % 16 <= 8) {
+        const int n1 = (H / 16) * cdiv(W, 16), n2 = cdiv(W, 32);
+        cands[nc++] = HaloGeom{16, 16, cdiv(W, 16), n1, (H / 16) * 16, H % 16, 32, n2, n1 + n2};
+    }
+    for (int ci = 0; ci < nc; ci++)
         for (int na = 2; na >= 1; na--) {
-            const int lds = h_lds(bn, na, g.th, g.tw, a.dil);
-            if (lds > 160 * 1024 || h_pieces(g.th, g.tw, a.dil) > 72) continue;  // (72 = 9 tap slots x 8 waves of patch pieces)
-            const long tiles = (long)((a.OH + g.th - 1) / g.th) * ((a.OW + g.tw - 1) / g.tw);
+            const HaloGeom& g = cands[ci];
+            int lds = h_lds(bn, na, g.th1, g.tw1, d), pieces = h_pieces(g.th1, g.tw1, d);
+            long patch = (long)(g.th1 + 2 * d) * (g.tw1 + 2 * d);
+            if (g.th2) {
+                lds = lds > h_lds(bn, na, g.th2, g.tw2, d) ? lds : h_lds(bn, na, g.th2, g.tw2, d);
+                pieces = pieces > h_pieces(g.th2, g.tw2, d) ? pieces : h_pieces(g.th2, g.tw2, d);
+            }
+            if (lds > 160 * 1024 || pieces > 72) continue;  // (72 = 9 tap slots x 8 waves of patch pieces)
             // two workgroups share a CU only in the BN = 128 form with one patch image (<= 128 VGPRs) and <= 80 KB of LDS
             const long per_cu = (bn == 128 && na == 1 && lds <= 80 * 1024) ? 2 : 1;
-            const long wgs = tiles * ntiles, slots = 256L * per_cu;
+            const long wgs = (long)g.mtiles * ntiles, slots = 256L * per_cu;
             // one patch image costs a barrier + an exposed patch load per channel chunk: ~10 % of a round
-            const long cost[3] = {(wgs + slots - 1) / slots * (na == 1 ? 11 : 10), tiles, (long)(g.th + 2 * a.dil) * (g.tw + 2 * a.dil)};
-            bool better = best.th == 0;
+            const long cost[3] = {(wgs + slots - 1) / slots * (na == 1 ? 11 : 10), g.mtiles, patch};
+            bool better = best.na == 0;
             for (int k = 0; k < 3 && !better; k++) {
                 if (cost[k] < best_cost[k]) better = true;
                 else if (cost[k] > best_cost[k]) break;
             }
             if (better) {
-                best.th = g.th; best.tw = g.tw; best.na = na; best.lds = lds;
+                best.g = g; best.na = na; best.lds = lds;
                 for (int k = 0; k < 3; k++) best_cost[k] = cost[k];
             }
         }
@@ -335,8 +356,7 @@ HaloPlan halo_plan(const ConvArgs& a, int bn) {
 
 template <int BN, int NA>
 hipError_t launch_halo(const ConvArgs& a, const HaloPlan& pl, hipStream_t s) {
-    const int tiles_x = (a.OW + pl.tw - 1) / pl.tw, tiles_y = (a.OH + pl.th - 1) / pl.th;
-    const int mtiles = tiles_x * tiles_y, ntiles = a.Cout / BN;
+    const int ntiles = a.Cout / BN;
     auto k = conv3x3_halo_kernel<BN, NA>;
     // (the LDS size depends on the dilation and the tile shape: the attribute is raised to the largest footprint there is)
     static std::atomic<bool> attr_done[64];
@@ -347,7 +367,7 @@ hipError_t launch_halo(const ConvArgs& a, const HaloPlan& pl, hipStream_t s) {
         if (e != hipSuccess) return e;
         if (known) attr_done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k, dim3(mtiles * ntiles), dim3(512), pl.lds, s, a, pl.th, pl.tw, tiles_x, mtiles, ntiles);
+    hipLaunchKernelGGL(k, dim3(pl.g.mtiles * ntiles), dim3(512), pl.lds, s, a, pl.g, ntiles);
     return hipGetLastError();
 }
 
@@ -358,7 +378,7 @@ bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != a.dil || (a.dil != 1 && a.dil != 2 && a.dil != 4)) return false;
     if (a.res || a.in2 || a.batch > 1 || a.OH != a.H || a.OW != a.W) return false;
     if (a.Cin % 64 != 0 || a.Cout % bn != 0 || (a.Cout & 7)) return false;
-    if (halo_plan(a, bn).th == 0) return false;
+    if (halo_plan(a, bn).na == 0) return false;
     // 32-bit buffer offsets with 0x80000000 (+ the channel chunk's scalar offset) as the out-of-range marker
     return (size_t)a.H * a.W * a.Cin * 2 < 0x80000000ull && (size_t)a.Cout * 9 * a.Cin * 2 < 0x80000000ull;
 }

@@ -77,7 +77,7 @@ def main():
         shutil.copy(ks2, os.path.join(out, f"{tag}_solo_kernel_stats.csv"))
         md += ["## kernel trace, one context (`… bench.py --contexts-per-gpu 1`): one kernel at a time -- these average durations are the ones",
                "that must agree with the HIP-event durations of bench.py's roofline frame (which runs alone); the table above is the",
-               "default command with two frames in flight, where kernels of the two streams time-share the chip", "",
+               "default command with three frames in flight (--contexts-per-gpu 3), where kernels of the streams time-share the chip", "",
                "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
         for r in csv.DictReader(open(ks2)):
             md.append(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "

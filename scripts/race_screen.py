@@ -2,7 +2,8 @@
 """Race screen for the kernels whose LDS traffic is ordered by hand (LDS-DMA with counted vmcnt + raw barriers:
 conv_igemm `dma` / `dmai`, conv1x1_areg): the same frame N times on K contexts AT THE SAME TIME (so that timing varies),
 every run's stride-8 logits hashed -- one distinct hash per (dtype, size) or the schedule has a race.
-    python scripts/race_screen.py [runs]        (run on an MI355X)"""
+    python scripts/race_screen.py [runs [dtype]]        (run on an MI355X; dtype restricts the jobs, e.g. with INFUR_CONV_CFG=19 to
+                                                          force conv3x3_halo.hip onto every 3x3 of the f16 mode)"""
 import hashlib
 import os
 import sys
@@ -19,8 +20,11 @@ JOBS = [("f16", 101, 3840, 2160), ("f16", 50, 1920, 1080), ("f16", 50, 961, 541)
         # the quantised model: i8 `dma` / `dmai` tiles and conv1x1_q8 (hand-counted vmcnt over DMA pieces, residual loads and stores);
         # 2160p so that the tuner also takes conv1x1_q8 for the expansions, 1080p for the database's choices
         ("i8", 50, 1920, 1080), ("i8", 50, 3840, 2160)]
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None
 bad = 0
 for dtype, depth, w, h in JOBS:
+    if ONLY and dtype != ONLY:
+        continue
     if dtype == "i8":
         from infur_amd import quantize
 
