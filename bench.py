@@ -484,7 +484,7 @@ def main():
                 o["GB/s"] = o["bytes"] / max(o["ms"], 1e-9) / 1e6
                 o["frac_hbm"] = o["GB/s"] / PEAK_HBM_GBS
                 o["frac_copy"] = o["GB/s"] / COPY_CEILING_GBS
-            # what actually bounds each of them: only the Winograd transforms are HBM kernels
+            # what actually bounds each of them (LAB_NOTES.md 3.1b / 3.2): only the Winograd transforms are HBM kernels
             bound_of = {"wino_input": ("hbm", "a hand-written 16 B / lane streaming copy of 0.5-4 GB sustains 5.3-5.6 TB/s read + write on this part (profiles/r03_copy_ceiling.md): frac_copy is GB/s over 5.45 TB/s"),
                         "wino_output": ("hbm", "see wino_input"),
                         "stem_pool": ("mfma", "7x7 stem as an implicit GEMM fused with the max-pool: 11.2 GFLOP executed per 1080p frame; its bytes are "

@@ -340,7 +340,7 @@ int32_t infur_batch_advance_multi(infur_ctx* const* ctxs, uint32_t n_ctx, const 
                                   uint32_t* ows, uint32_t* ohs);
 
 /* ---- INFUR_DTYPE_F32_SPLIT range monitor ----
- * The split mode carries every GEMM operand as an f16 pair of x * 2^k with static k: exact to
+ * The split mode carries every GEMM operand as an f16 pair of x * 2^k with static k (LAB_NOTES.md 3.3a): exact to
  * 22 bits while |x * 2^k| <= 65504, saturating beyond.  Every forward records the largest |activation| fed to a
  * GEMM and the largest |Winograd-domain input|; this call returns them for the last forward and whether either
  * left the exact range (the logits of that frame are then not f32-grade: re-run it on an INFUR_DTYPE_F32 context).

@@ -4,7 +4,7 @@
 // Why: in the f16-rate modes the bottleneck expansions of FCN-ResNet (conv3: 256 -> 1024 channels + residual, 22 of them
 // in a ResNet-101) are not MFMA-bound but bound by the L2 -> L1 fill rate: the tiled implicit GEMM (conv_igemm.hip)
 // re-reads the activation tile once per N tile (8x) and the weight tile once per M tile; at 4K that is 1.33 GB of L1
-// fills per launch for 0.6 GB of compulsory traffic.  Here a workgroup owns 256 pixels: each of its 8
+// fills per launch for 0.6 GB of compulsory traffic (LAB_NOTES.md 3.3).  Here a workgroup owns 256 pixels: each of its 8
 // waves (4 along M x 2 along N) loads its 64 x Cin activation fragment ONCE, straight into the MFMA operand layout (<= 128
 // VGPRs), and then the workgroup streams the weight matrix through LDS in
 // 128-channel tiles by LDS-DMA (a ring of four 16 KB images: three K steps always in flight), accumulating and writing one

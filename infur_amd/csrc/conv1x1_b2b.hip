@@ -5,7 +5,7 @@
 // written once as the next block's residual and never read back by conv1'.  Replaces two of the Conv/Add/Relu node
 // groups ONNX Runtime executes inside `session.run` (infur/src/predict_onnx.rs:138).
 //
-// Why: in the f16-rate modes these 1x1 GEMMs are HBM-bound: conv3 reads t2 + x and writes y, conv1' reads
+// Why: in the f16-rate modes these 1x1 GEMMs are HBM-bound (LAB_NOTES.md 3.3): conv3 reads t2 + x and writes y, conv1' reads
 // y again and writes t1' -- 927 MB of traffic per pair at 4K for 662 MB of compulsory bytes once the re-read is gone.
 //
 // Shape of the kernel: a workgroup owns 256 pixels, each of its 8 waves 32 of them, privately: the wave keeps its 32 x C2

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM-resident frames/s for the workloads x arithmetic modes of DESIGN.md section 5 (two contexts per GPU, as bench.py).
+"""HBM-resident frames/s for the workloads x arithmetic modes of LAB_NOTES.md section 5 (two contexts per GPU, as bench.py).
    python scripts/rate_table.py            (on an MI355X; prints a markdown table)"""
 import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

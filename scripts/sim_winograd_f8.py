@@ -1,6 +1,6 @@
 """CPU simulation: would a Winograd F(8x8,3x3) tile (100 multiplies per 64 outputs: 12 % fewer MFMA FLOPs than F(6x6)) keep
 f32-grade results?  Cook-Toom matrices (wincnn construction, sympy rationals) for several point sets, one 256-channel
-3x3 convolution in f32 against a float64 direct convolution.  Result: no -- 6.7e-5 at best per layer,
+3x3 convolution in f32 against a float64 direct convolution.  Result (LAB_NOTES.md 3.1b): no -- 6.7e-5 at best per layer,
 ten times F(6x6)'s 6.8e-6, 2.5e-4 .. 1.9e-3 for the other point sets."""
 import numpy as np
 from fractions import Fraction as Fr

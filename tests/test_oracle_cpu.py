@@ -169,7 +169,7 @@ def test_blob_roundtrip():
 # ---- independent corroboration of two restated third-party rules (round 2) ----
 # Neither library below is the reference's; they are independent implementations of the same published conventions
 # that happen to be in the image.  They pin the RULE (which source pixel / which interpolation coordinates), not the
-# reference's bytes: DESIGN.md section 4 keeps those rows "unpinned".
+# reference's bytes: DESIGN.md section 5 keeps those rows "unpinned".
 @pytest.mark.parametrize("wh", [(640, 480), (1280, 720), (97, 61), (33, 17)])
 def test_nearest_rule_matches_pillow_outside_exact_ties(oracle, wh):
     """fast_image_resize's Nearest (processing.rs:189) samples the source pixel under the CENTRE of the destination
