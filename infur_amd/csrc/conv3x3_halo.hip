@@ -78,11 +78,16 @@ struct HaloGeom {
 };
 __host__ __device__ constexpr int h_pieces(int th, int tw, int d) { return ((th + 2 * d) * (tw + 2 * d) + 7) / 8; }  // wave instructions of 8 rows
 __host__ __device__ constexpr int h_pimg(int th, int tw, int d) { return h_pieces(th, tw, d) * 1024; }
-// weight images: a ring of 3 for BN = 128 (the tap's 1,024 MFMA cycles per SIMD are shorter than the L2 latency: with one tap of
-// prefetch every step ended waiting for its successor's weights -- 2.6k cycles per tap), 2 for BN = 256 (2,048-cycle taps)
-__host__ __device__ constexpr int h_nb(int bn) { return bn == 128 ? 3 : 2; }
+// Weight steps and images.  A tap's 64-channel weight tile is BN x 128 bytes: 16 KB for BN = 128, 32 KB for BN = 256.  BN = 128 takes
+// it whole (one step = one tap = 1,024 MFMA cycles per SIMD); BN = 256 takes it in two 32-channel HALVES (64-byte rows, one step =
+// half a tap = again 1,024 cycles), so that both forms stream 16 KB steps through a ring of THREE images (48 KB) -- steps this short
+// are shorter than the L2 latency, with one step of prefetch every step ended waiting for its successor's weights -- and two patch
+// images still fit beside them for d <= 2 (BN = 256 with whole-tap images needed 64 KB for two of them and one patch image: an
+// exposed patch load per channel chunk).
+__host__ __device__ constexpr int h_bkb(int bn) { return bn == 128 ? 128 : 64; }  // bytes of k per weight step and row
+__host__ __device__ constexpr int h_nb(int) { return 3; }
 __host__ __device__ constexpr int h_lds(int bn, int na, int th, int tw, int d) {
-    const int operands = na * h_pimg(th, tw, d) + h_nb(bn) * bn * 128;
+    const int operands = na * h_pimg(th, tw, d) + h_nb(bn) * bn * h_bkb(bn);
     const int staging = 8 * 32 * H_ROWB;
     return operands > staging ? operands : staging;
 }
@@ -91,8 +96,13 @@ template <int BN, int NA>
 __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, const HaloGeom g, const int ntiles) {
     constexpr int WN = BN / 64, WM = 8 / WN;  // waves along N (64 channels each) / along M
     constexpr int TM = 256 / WM / 32, TN = 2;
-    constexpr int B_IT = BN / 64;  // weight pieces (8 rows) per wave and tap
-    constexpr int NB = h_nb(BN);   // weight images (ring)
+    constexpr int BKB = h_bkb(BN);           // bytes of k per weight step: a whole tap's 128, or half a tap
+    constexpr int HS = 128 / BKB;            // weight steps per tap
+    constexpr int SL = 4 / HS;               // 16-wide MFMA slices per weight step
+    constexpr int BIMG = BN * BKB;           // one weight image
+    constexpr int B_IT = BIMG / 8192;        // weight pieces (1 KB) per wave and step
+    constexpr int NB = h_nb(BN);             // weight images (ring)
+    constexpr int SPC = 9 * HS;              // weight steps per channel chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,7 +130,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
     const int cchunks = a.Cin / 64;
 
     char* const As = smem;              // [NA][npiece * 8 rows][128]
-    char* const Bs = smem + NA * pimg;  // [NB][BN][128]
+    char* const Bs = smem + NA * pimg;  // [NB][BN][BKB]
     const unsigned lds0 = (unsigned)(size_t)(lds_void_h*)smem;
     const u32x4h in_v = h_rsrc(a.in, (unsigned)((size_t)a.H * a.W * Kb));
     const u32x4h wt_v = h_rsrc(a.wt, (unsigned)((size_t)a.Cout * 9 * Kb));
@@ -137,23 +147,27 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
         const bool ok = p < P && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         a_voff[t] = ok ? (unsigned)(iy * a.W + ix) * (unsigned)Kb + (unsigned)(((lane & 7) ^ h_swz(p)) * 16) : HOOB;
     }
+    // weight pieces: 1 KB = 8 rows of 128 bytes (chunk index XOR (row >> 1) & 7) or 16 rows of 64 bytes (XOR (row >> 2) & 3): either
+    // way a 16-lane fragment read group covers the 64 banks exactly once
     unsigned b_voff[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; i++) {
-        const int row = 8 * (wave * B_IT + i) + (lane >> 3);
+        const int row = (BKB == 128 ? 8 : 16) * (wave * B_IT + i) + (BKB == 128 ? (lane >> 3) : (lane >> 2));
+        const int chunk = BKB == 128 ? ((lane & 7) ^ h_swz(row)) : ((lane & 3) ^ ((row >> 2) & 3));
         const int n = n0 + row;
-        b_voff[i] = n < a.Cout ? (unsigned)n * (unsigned)(9 * Kb) + (unsigned)(((lane & 7) ^ h_swz(row)) * 16) : HOOB;
+        b_voff[i] = n < a.Cout ? (unsigned)n * (unsigned)(9 * Kb) + (unsigned)(chunk * 16) : HOOB;
     }
     auto dma_a = [&](const int t, const int cc, const int img) {  // this wave's patch piece of tap slot t, channel chunk cc
         if (8 * t + wave < npiece)  // (wave-uniform)
             h_dma16(in_v, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(img * pimg + (8 * t + wave) * 1024)), a_voff[t],
                     __builtin_amdgcn_readfirstlane((unsigned)(cc * 128)));
     };
-    auto dma_b = [&](const int cc, const int tap, const int img) {  // the weight tile of (chunk cc, tap): rows n0 .. n0 + BN - 1
-        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((tap * cchunks + cc) * 128));
+    auto dma_b = [&](const int cc, const int q, const int img) {  // weight step q = tap * HS + half of chunk cc: rows n0 .. n0 + BN - 1
+        const int tap = q / HS, half = q - tap * HS;
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((tap * cchunks + cc) * 128 + half * BKB));
 #pragma unroll
         for (int i = 0; i < B_IT; i++)
-            h_dma16(wt_v, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(NA * pimg + img * (BN * 128) + (wave * B_IT + i) * 1024)), b_voff[i], soff);
+            h_dma16(wt_v, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(NA * pimg + img * BIMG + (wave * B_IT + i) * 1024)), b_voff[i], soff);
     };
 
     // ---- lane-constant fragment addressing ----
@@ -164,8 +178,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
         const int ty = (int)(((float)R + 0.5f) * rtw), tx = R - ty * tw;
         pbase[i] = R < npix ? ty * PW + tx : 0;  // (padding rows read a valid patch row; their results are never stored)
     }
-    const int b_lds = (wn * 64 + r) * 128;
-    const int b_sw = h_swz(r);  // fragment rows are 32 apart: the swizzle does not change
+    const int b_lds = (wn * 64 + r) * BKB;
+    const int b_sw = BKB == 128 ? h_swz(r) : ((r >> 2) & 3);  // fragment rows are 32 apart: the swizzle does not change
 
     f32x16h acc[TM][TN];
 #pragma unroll
@@ -179,7 +193,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
 #pragma unroll
     for (int t = 0; t < 9; t++) dma_a(t, 0, 0);
     dma_b(0, 0, 0);
-    if (NB == 3) dma_b(0, 1, 1);
+    dma_b(0, 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     auto wait_vm = [](const int n) {  // s_waitcnt takes an immediate
@@ -204,10 +218,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int ky = tap / 3, kx = tap - 3 * ky;
-            // what this tap issues: its patch piece of the next chunk (two patch images), the weights NB - 1 taps ahead
-            const bool issue_a = NA == 2 && more_chunks && 8 * tap + wave < npiece;
-            const bool issue_b = more_chunks || tap + NB - 1 < 9;
-            const int bnext = bimg + NB - 1 >= NB ? bimg - 1 : bimg + NB - 1;  // (bimg + NB - 1) % NB
             const int toff = (ky * PW + kx) * d + zero;  // (scalar) patch-row offset of this tap
             // chunk (2 kk + hh) of row p sits at position (2 kk + hh) ^ swz(p) = (kk << 1) ^ (hh ^ swz(p)): one base address per
             // block and tap, one XOR with a constant per slice (the swizzle of a patch row depends on the tap's row offset, so
@@ -218,39 +228,43 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
                 const int p = pbase[i] + toff;
                 abase[i] = (unsigned)(aimg * pimg + p * 128) | (unsigned)((hh ^ h_swz(p)) << 4);
             }
-            const char* Bb = Bs + bimg * (BN * 128) + b_lds;
-            auto read_slice = [&](const int kk, h16x8h (&fa)[TM], h16x8h (&fb)[TN]) {
 #pragma unroll
-                for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const h16x8h*>(As + (abase[i] ^ (unsigned)(kk << 5)));
+            for (int half = 0; half < HS; half++) {
+                const int q = tap * HS + half;
+                // what this step issues: (first step of a tap) the tap's patch piece of the next chunk, and the weights NB - 1 steps ahead
+                const bool issue_a = half == 0 && NA == 2 && more_chunks && 8 * tap + wave < npiece;
+                const bool issue_b = more_chunks || q + NB - 1 < SPC;
+                const int bnext = bimg + NB - 1 >= NB ? bimg - 1 : bimg + NB - 1;  // (bimg + NB - 1) % NB
+                const char* Bb = Bs + bimg * BIMG + b_lds;
+                auto read_slice = [&](const int kl, h16x8h (&fa)[TM], h16x8h (&fb)[TN]) {  // slice kl of this step = slice half * SL + kl of the tap
 #pragma unroll
-                for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const h16x8h*>(Bb + j * 32 * 128 + (((2 * kk + hh) ^ b_sw) * 16));
-            };
-            // fragments run ONE slice ahead of the MFMAs (two register sets): with a fence per slice and no prefetch every slice paid
-            // its ds_read latency in full -- 3.8k cycles per tap for 1k of MFMA work (first cut: layer3 conv2 at 1080p 66 us against
-            // 45 for the tiled form)
-            h16x8h fa[2][TM], fb[2][TN];
-            read_slice(0, fa[0], fb[0]);
+                    for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const h16x8h*>(As + (abase[i] ^ (unsigned)((half * SL + kl) << 5)));
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                if (kk < 3) read_slice(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
-                // the DMA instructions go out behind a slice's fragment reads, in the shadow of MFMAs that already have their
-                // operands (the `dmai` placement of conv_igemm_kernel.h)
-                if (kk == 0 && issue_a) dma_a(tap, cc + 1, aimg ^ 1);
-                if (kk == 1 && issue_b) dma_b(tap + NB - 1 >= 9 ? cc + 1 : cc, tap + NB - 1 >= 9 ? tap + NB - 1 - 9 : tap + NB - 1, bnext);
+                    for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const h16x8h*>(Bb + j * 32 * BKB + (((2 * kl + hh) ^ b_sw) * 16));
+                };
+                // fragments run ONE slice ahead of the MFMAs (two register sets): with a fence per slice and no prefetch every slice
+                // paid its ds_read latency in full -- 3.8k cycles per tap for 1k of MFMA work in the first cut
+                h16x8h fa[2][TM], fb[2][TN];
+                read_slice(0, fa[0], fb[0]);
 #pragma unroll
-                for (int i = 0; i < TM; i++)
+                for (int kl = 0; kl < SL; kl++) {
+                    if (kl + 1 < SL) read_slice(kl + 1, fa[(kl + 1) & 1], fb[(kl + 1) & 1]);
+                    // the DMA instructions go out behind a slice's fragment reads, in the shadow of MFMAs that already have their
+                    // operands (the `dmai` placement of conv_igemm_kernel.h)
+                    if (kl == 0 && issue_a) dma_a(tap, cc + 1, aimg ^ 1);
+                    if (kl == (SL > 1 ? 1 : 0) && issue_b) dma_b(q + NB - 1 >= SPC ? cc + 1 : cc, q + NB - 1 >= SPC ? q + NB - 1 - SPC : q + NB - 1, bnext);
 #pragma unroll
-                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kl & 1][j], fa[kl & 1][i], acc[i][j], 0, 0, 0);
+                }
+                // The NEXT step's weights must have landed (and, at a chunk's last step, the next chunk's whole patch); loads retire in
+                // order, so what may stay in flight is exactly what was issued after them: this step's weight pieces (for two steps
+                // ahead) and this step's patch piece -- which is never issued in a chunk's last step.
+                wait_vm((issue_b ? B_IT : 0) + ((issue_a && q + 1 < SPC) ? 1 : 0));
+                __builtin_amdgcn_s_barrier();
+                bimg = bimg + 1 == NB ? 0 : bimg + 1;
             }
-            // The NEXT tap's weights must have landed (and, at a chunk's last tap, the next chunk's whole patch); loads retire in
-            // order, so what may stay in flight is exactly what was issued after them: with the ring of three, this tap's weight
-            // pieces (for tap + 2) and -- except at the chunk's end -- this tap's patch piece.  With two images nothing.
-            if (NB == 3)
-                wait_vm((issue_b ? B_IT : 0) + ((issue_a && tap < 8) ? 1 : 0));
-            else
-                wait_vm(0);
-            __builtin_amdgcn_s_barrier();
-            bimg = bimg + 1 == NB ? 0 : bimg + 1;
         }
         if (NA == 1 && more_chunks) {  // one patch image: it is free only now
 #pragma unroll
