@@ -18,7 +18,8 @@ from infur_amd import processors as P  # noqa: E402
 from infur_amd import weights as W  # noqa: E402
 
 JOBS = [("f32", 50, (1920, 1080), 1.0), ("f16", 50, (1920, 1080), 1.0), ("f16", 101, (3840, 2160), 1.0),
-        ("f32s", 50, (1920, 1080), 1.0), ("f32x", 50, (1920, 1080), 1.0), ("i8", 50, (1920, 1080), 1.0)]
+        ("f32s", 50, (1920, 1080), 1.0), ("f32x", 50, (1920, 1080), 1.0), ("i8", 50, (1920, 1080), 1.0),
+        ("f32@0.5", 50, (1920, 1080), 0.5), ("f32@480", 50, (640, 480), 1.0), ("f32s@0.5", 50, (1920, 1080), 0.5)]
 MODE = {"f32": "0", "f16": "1", "f32s": "2", "f32x": "3", "i8": "4"}
 FRAMES, MIN_GAIN = 7, 0.03  # a change must win 3 % on the layers it touches
 NCFG = 21
@@ -40,9 +41,10 @@ def main():
     db_lines = [ln for ln in open(P.TUNE_DB) if ln.strip() and not ln.startswith("#")]
     db = {" ".join(ln.split()[:13]): ln.split()[13] for ln in db_lines}
     changed = 0
-    for dtype, depth, (w, h), factor in JOBS:
-        if only and dtype not in only:
+    for job, depth, (w, h), factor in JOBS:
+        if only and job not in only:
             continue
+        dtype = job.split("@")[0]
         if dtype == "i8":
             from infur_amd import quantize
 
