@@ -12,7 +12,8 @@
 // activation fragments from that patch at a per-tap row offset; only the weight tile (BN x 128 B) is new per tap.  Activation
 // ingest falls 5.8x (d = 2), the K step's L2 -> LDS traffic from 48 KB to ~22 KB, LDS write traffic with it.
 //
-// Shape: 8 waves, BN = 128 (waves 4 x 2, 64 pixels x 64 channels each) or BN = 256 (2 x 4, 128 x 64); everything arrives by
+// Shape: 8 waves, BN = 64 (layer1: waves 8 x 1, 32 pixels x 64 channels each), BN = 128 (4 x 2, 64 x 64) or BN = 256 (2 x 4, 128 x 64);
+// everything arrives by
 // LDS-DMA (buffer_load ... lds, rows of 128 bytes, 16-byte chunk index XOR-swizzled by (row >> 1) & 7 on the SOURCE side, as in
 // conv_igemm_kernel.h); two weight images (tap t + 1 lands while tap t is multiplied), and two patch images when they fit the
 // 160 KB (the next chunk's patch lands piece by piece during this chunk's nine taps: one piece of 8 rows per wave and tap),
@@ -84,7 +85,7 @@ __host__ __device__ constexpr int h_pimg(int th, int tw, int d) { return h_piece
 // are shorter than the L2 latency, with one step of prefetch every step ended waiting for its successor's weights -- and two patch
 // images still fit beside them for d <= 2 (BN = 256 with whole-tap images needed 64 KB for two of them and one patch image: an
 // exposed patch load per channel chunk).
-__host__ __device__ constexpr int h_bkb(int bn) { return bn == 128 ? 128 : 64; }  // bytes of k per weight step and row
+__host__ __device__ constexpr int h_bkb(int bn) { return bn <= 128 ? 128 : 64; }  // bytes of k per weight step and row
 __host__ __device__ constexpr int h_nb(int) { return 3; }
 __host__ __device__ constexpr int h_lds(int bn, int na, int th, int tw, int d) {
     const int operands = na * h_pimg(th, tw, d) + h_nb(bn) * bn * h_bkb(bn);
@@ -341,7 +342,7 @@ HaloPlan halo_plan(const ConvArgs& a, int bn) {
         cands[nc++] = HaloGeom{16, 16, cdiv(W, 16), n1, (H / 16) * 16, H % 16, 32, n2, n1 + n2};
     }
     for (int ci = 0; ci < nc; ci++)
-        for (int na = 2; na >= 1; na--) {
+        for (int na = (a.Cin == 64 ? 1 : 2); na >= 1; na--) {  // (one channel chunk: there is no next patch to prefetch)
             const HaloGeom& g = cands[ci];
             int lds = h_lds(bn, na, g.th1, g.tw1, d), pieces = h_pieces(g.th1, g.tw1, d);
             long patch = (long)(g.th1 + 2 * d) * (g.tw1 + 2 * d);
@@ -351,10 +352,10 @@ HaloPlan halo_plan(const ConvArgs& a, int bn) {
             }
             if (lds > 160 * 1024 || pieces > 72) continue;  // (72 = 9 tap slots x 8 waves of patch pieces)
             // two workgroups share a CU only in the BN = 128 form with one patch image (<= 128 VGPRs) and <= 80 KB of LDS
-            const long per_cu = (bn == 128 && na == 1 && lds <= 80 * 1024) ? 2 : 1;
+            const long per_cu = (bn <= 128 && na == 1 && lds <= 80 * 1024) ? 2 : 1;
             const long wgs = (long)g.mtiles * ntiles, slots = 256L * per_cu;
             // one patch image costs a barrier + an exposed patch load per channel chunk: ~10 % of a round
-            const long cost[3] = {(wgs + slots - 1) / slots * (na == 1 ? 11 : 10), g.mtiles, patch};
+            const long cost[3] = {(wgs + slots - 1) / slots * ((na == 1 && a.Cin > 64) ? 11 : 10), g.mtiles, patch};
             bool better = best.na == 0;
             for (int k = 0; k < 3 && !better; k++) {
                 if (cost[k] < best_cost[k]) better = true;
@@ -388,7 +389,8 @@ hipError_t launch_halo(const ConvArgs& a, const HaloPlan& pl, hipStream_t s) {
 }  // namespace
 
 bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn) {
-    if (mode != 1 || out_f32 || (bn != 128 && bn != 256)) return false;
+    if (bn == 128 && a.Cout == 64) bn = 64;  // configuration 19 on the 64-channel convs of layer1: one N tile of 64 (8 waves x 32 pixels)
+    if (mode != 1 || out_f32 || (bn != 64 && bn != 128 && bn != 256)) return false;
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != a.dil || (a.dil != 1 && a.dil != 2 && a.dil != 4)) return false;
     if (a.res || a.in2 || a.batch > 1 || a.OH != a.H || a.OW != a.W) return false;
     if (a.Cin % 64 != 0 || a.Cout % bn != 0 || (a.Cout & 7)) return false;
@@ -399,7 +401,9 @@ bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn) {
 
 hipError_t launch_conv3x3_halo(const ConvArgs& a, int bn, hipStream_t s) {
     if (!conv3x3_halo_valid(a, 1, 0, bn)) return hipErrorInvalidValue;
+    if (bn == 128 && a.Cout == 64) bn = 64;
     const HaloPlan pl = halo_plan(a, bn);
+    if (bn == 64) return launch_halo<64, 1>(a, pl, s);
     if (bn == 128) return pl.na == 2 ? launch_halo<128, 2>(a, pl, s) : launch_halo<128, 1>(a, pl, s);
     return pl.na == 2 ? launch_halo<256, 2>(a, pl, s) : launch_halo<256, 1>(a, pl, s);
 }
