@@ -388,8 +388,18 @@ hipError_t launch_halo(const ConvArgs& a, const HaloPlan& pl, hipStream_t s) {
 
 }  // namespace
 
+// configuration 19 asks for BN = 128; it runs with N tiles of 64 (8 waves x 32 pixels, two workgroups per CU) on the 64-channel convs
+// of layer1 and wherever 128-wide tiles would leave more than a third of the CUs without a workgroup (layer2 conv2 at 1080p: 128
+// tiles x ONE N tile)
+static int halo_bn(const ConvArgs& a, int bn) {
+    if (bn != 128) return bn;
+    if (a.Cout == 64) return 64;
+    const long tiles = (long)((a.OH + 15) / 16) * ((a.OW + 15) / 16);
+    return (a.Cout % 128 == 0 && tiles * (a.Cout / 128) <= 170) ? 64 : 128;
+}
+
 bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn) {
-    if (bn == 128 && a.Cout == 64) bn = 64;  // configuration 19 on the 64-channel convs of layer1: one N tile of 64 (8 waves x 32 pixels)
+    bn = halo_bn(a, bn);
     if (mode != 1 || out_f32 || (bn != 64 && bn != 128 && bn != 256)) return false;
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != a.dil || (a.dil != 1 && a.dil != 2 && a.dil != 4)) return false;
     if (a.res || a.in2 || a.batch > 1 || a.OH != a.H || a.OW != a.W) return false;
@@ -401,7 +411,7 @@ bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn) {
 
 hipError_t launch_conv3x3_halo(const ConvArgs& a, int bn, hipStream_t s) {
     if (!conv3x3_halo_valid(a, 1, 0, bn)) return hipErrorInvalidValue;
-    if (bn == 128 && a.Cout == 64) bn = 64;
+    bn = halo_bn(a, bn);
     const HaloPlan pl = halo_plan(a, bn);
     if (bn == 64) return launch_halo<64, 1>(a, pl, s);
     if (bn == 128) return pl.na == 2 ? launch_halo<128, 2>(a, pl, s) : launch_halo<128, 1>(a, pl, s);
