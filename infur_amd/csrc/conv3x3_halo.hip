@@ -23,6 +23,7 @@
 // the MFMA's row operand -- the order conv_igemm_kernel.h uses for f16 KxK convolutions since round 4 (CMAJ) -- then + bias, ReLU,
 // round to f16: BIT-IDENTICAL to every tiled configuration (tests/test_gpu_conv_configs.py), so the tuner picks it by speed only.
 #include <atomic>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -394,6 +395,9 @@ hipError_t launch_halo(const ConvArgs& a, const HaloPlan& pl, hipStream_t s) {
 static int halo_bn(const ConvArgs& a, int bn) {
     if (bn != 128) return bn;
     if (a.Cout == 64) return 64;
+    static const int force = getenv("INFUR_HALO_BN") ? atoi(getenv("INFUR_HALO_BN")) : 0;  // measurement hook: 64 / 128
+    if (force == 64 && a.Cout % 64 == 0) return 64;
+    if (force == 128) return 128;
     const long tiles = (long)((a.OH + 15) / 16) * ((a.OW + 15) / 16);
     return (a.Cout % 128 == 0 && tiles * (a.Cout / 128) <= 170) ? 64 : 128;
 }
