@@ -13,6 +13,7 @@
 #include "../../include/infur_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -156,14 +157,59 @@ inline int ctx_mode(const infur_ctx* c) { return ctx_fp8x(c) ? (int)INFUR_DTYPE_
 inline int conv_mode(const infur_ctx* c) { return ctx_fp8x(c) ? 3 : ctx_mode(c); }
 inline int act_es(const infur_ctx* c) { return ctx_f16(c) ? 2 : 4; }
 
+// ---- roctx ranges ----
+// The reference wraps its stages in `tracing` spans / events (infur/src/main.rs:18-24, RUST_LOG); here INFUR_ROCTX=1 makes every
+// stage and layer launch a named roctx range ("<layer> [<kernel>]", inside "infur frame"), so that
+// `rocprofv3 --marker-trace --kernel-trace` shows which layer a kernel belongs to.  The library is taken by dlopen at the first
+// use (no link-time dependency; without it, or without the variable, a range costs one predictable branch).  Ranges are host
+// side: they bracket the ENQUEUE of a launch, so look at them with graph replay off (the default).
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+const Roctx* roctx() {
+    static Roctx r;
+    static std::once_flag once;
+    static bool ok = false;
+    std::call_once(once, [] {
+        const char* e = getenv("INFUR_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            r.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            r.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (r.push && r.pop) {
+                ok = true;
+                return;
+            }
+        }
+        fprintf(stderr, "infur: INFUR_ROCTX is set but no roctx library could be loaded\n");
+    });
+    return ok ? &r : nullptr;
+}
+struct RoctxRange {
+    const Roctx* rx;
+    explicit RoctxRange(const char* name) : rx(roctx()) {
+        if (rx) rx->push(name);
+    }
+    ~RoctxRange() {
+        if (rx) rx->pop();
+    }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 // ---- profiling ----
 struct ProfScope {
     infur_ctx* c;
     bool on;
+    const Roctx* rx;
     ProfRec r;
     ProfScope(infur_ctx* c_, const std::string& name, const char* kernel, double flops, double bytes,
               double algo_flops = -1.0)
-        : c(c_), on(c_->opt.profile != 0) {
+        : c(c_), on(c_->opt.profile != 0), rx(roctx()) {
+        if (rx) rx->push((name + " [" + kernel + "]").c_str());
         if (!on) return;
         r.name = name;
         r.kernel = kernel;
@@ -181,9 +227,11 @@ struct ProfScope {
         (void)hipEventRecord(r.e0, c->stream);
     }
     ~ProfScope() {
-        if (!on) return;
-        (void)hipEventRecord(r.e1, c->stream);
-        c->prof.push_back(r);
+        if (on) {
+            (void)hipEventRecord(r.e1, c->stream);
+            c->prof.push_back(r);
+        }
+        if (rx) rx->pop();
     }
 };
 
@@ -1183,6 +1231,7 @@ int32_t forward_q(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
 // Leaves the output-stride-8 logits in c->out_low / c->aux_low (NHWC).
 int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
     if (w <= 0 || h <= 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %dx%d", w, h);
+    RoctxRange rr("infur forward");
     pool_release_all(c);
     prof_reset(c);
     c->frame_no++;
@@ -1938,6 +1987,7 @@ static int32_t frame_body(infur_ctx* c, const void* d_bgr, uint32_t w, uint32_t 
                           uint32_t ow, uint32_t oh) {
     const size_t sbytes = (size_t)ow * oh * 3, need = (size_t)ow * oh * 4;
     const void* frame = d_bgr;
+    RoctxRange rr("infur frame");
     prof_reset(c);
     std::vector<ProfRec> pre;
     if (factor != 1.0f || d_scaled) {

@@ -21,8 +21,10 @@ JOBS = [("f32", 50, (1920, 1080), 1.0), ("f16", 50, (1920, 1080), 1.0), ("f16", 
         ("f32s", 50, (1920, 1080), 1.0), ("f32x", 50, (1920, 1080), 1.0), ("i8", 50, (1920, 1080), 1.0),
         ("f32@0.5", 50, (1920, 1080), 0.5), ("f32@480", 50, (640, 480), 1.0), ("f32s@0.5", 50, (1920, 1080), 0.5)]
 MODE = {"f32": "0", "f16": "1", "f32s": "2", "f32x": "3", "i8": "4"}
-FRAMES, MIN_GAIN = 7, 0.03  # a change must win 3 % on the layers it touches
+# a change must win 3 % on the layers it touches (INSITU_MIN_GAIN / INSITU_FRAMES / INSITU_CFGS="19,20": a closer look at few candidates)
+FRAMES, MIN_GAIN = int(os.environ.get("INSITU_FRAMES", 7)), float(os.environ.get("INSITU_MIN_GAIN", 0.03))
 NCFG = 21
+CANDS = [int(x) for x in os.environ["INSITU_CFGS"].split(",")] if os.environ.get("INSITU_CFGS") else list(range(NCFG))
 
 
 def frame_times(c, fp, fr, factor):
@@ -73,7 +75,7 @@ def main():
             if key.split()[10] == "3" or key not in cur:  # (the fused conv3 -> conv1 decision changes the record list: scripts/b2b_ab.py)
                 continue
             best, best_delta = cur[key], 0.0
-            for k in range(NCFG):
+            for k in CANDS:
                 if str(k) == cur[key]:
                     continue
                 txt = f"{key} {k}\n".encode()
