@@ -24,6 +24,7 @@
 // round to f16: BIT-IDENTICAL to every tiled configuration (tests/test_gpu_conv_configs.py), so the tuner picks it by speed only.
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -370,6 +371,352 @@ HaloPlan halo_plan(const ConvArgs& a, int bn) {
     return best;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The 4-wave form (round 4, configuration 21): BN = 256 with ONE wave per SIMD and a 128 x 128 wave tile.
+//
+// Why: with 128 x 64 wave tiles (every 8-wave form of this file and of conv_igemm_kernel.h) a 64-deep K step reads 192 KB of
+// fragments from LDS for 2,048 cycles of MFMA per SIMD -- with the DMA writes that is all the LDS can deliver, and the K loop sits
+// at 73 % of MFMA issue (LAB_NOTES).  A 128 x 128 wave tile reads 128 KB for the same MFMAs (16 per fragment octet instead of 8),
+// but its 256 accumulators leave room for only one wave per SIMD: nothing hides a wave's own latencies, so the schedule has to.
+// The resident patch is what makes that possible -- no activation gather in the K loop, a tap is an LDS address offset:
+//   * weight steps of half a tap (64-byte rows, 16 KB images) in a ring of THREE, the image of step s + 3 issued during step s
+//     (four slices of 16 MFMAs = 2,048 cycles of slack before it is waited for);
+//   * fragments run one 16-wide slice ahead of the MFMAs in two register sets, ACROSS steps: the barrier of a step sits between its
+//     two slices -- after it the next image is published (every wave waited for its own pieces with a counted vmcnt) and the current
+//     one is free (its last fragments are already in registers), so neither a DMA nor a ds_read latency is ever exposed;
+//   * the next channel chunk's patch arrives one piece per wave and step in the first steps of the current chunk (patch images are
+//     padded to a multiple of four pieces so that every wave issues the same count and the vmcnt immediates are uniform);
+//   * the last three steps re-issue the first steps' weights of a chunk that does not exist (wrapped to chunk 0: valid memory,
+//     never read back) instead of branching around the issue -- the counted waits stay the same to the end.
+// Same k order, same MFMA operand slots, same epilogue as every other configuration: bit-identical (tests/test_gpu_halo.py).
+constexpr int H4_BN = 256, H4_BKB = 64, H4_BIMG = H4_BN * H4_BKB, H4_NB = 3, H4_TMAX = 14;
+constexpr int H4_ROWB = 4 * 128 + 16;  // epilogue staging row of a wave: 128 f32 + pad
+__host__ __device__ constexpr int h4_slots(int th, int tw, int d) { return (h_pieces(th, tw, d) + 3) / 4; }  // patch pieces per wave
+__host__ __device__ constexpr int h4_pimg(int th, int tw, int d) { return h4_slots(th, tw, d) * 4096; }
+__host__ __device__ constexpr int h4_lds(int th, int tw, int d) {
+    const int operands = 2 * h4_pimg(th, tw, d) + H4_NB * H4_BIMG;
+    const int staging = 4 * 32 * H4_ROWB;
+    return operands > staging ? operands : staging;
+}
+
+template <int ABL>
+__global__ void __launch_bounds__(256, 1) conv3x3_halo4_kernel(const ConvArgs a, const HaloGeom g, const int ntiles) {
+    constexpr int TM = 4, TN = 4, B_IT = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    int tile;
+    {
+        const int nblk = g.mtiles * ntiles;
+        const int b = blockIdx.x, xcd = b & 7, loc = b >> 3;
+        const int q = nblk >> 3, rem = nblk & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+    }
+    const int mt = tile / ntiles, nt = tile - mt * ntiles;
+    const bool r2 = mt >= g.n1;
+    const int th = r2 ? g.th2 : g.th1, tw = r2 ? g.tw2 : g.tw1, tiles_x = r2 ? g.tiles_x2 : g.tiles_x1;
+    const int mloc = r2 ? mt - g.n1 : mt;
+    const int tyb = mloc / tiles_x, txb = mloc - tyb * tiles_x;
+    const int y0 = (r2 ? g.ysplit : 0) + tyb * th, x0 = txb * tw, n0 = nt * H4_BN;
+    const int d = a.dil, PW = tw + 2 * d, P = PW * (th + 2 * d);
+    const int T = ((P + 7) / 8 + 3) / 4;  // patch pieces per wave (workgroup-uniform)
+    const int pimg = T * 4096;
+    const int npix = th * tw;
+    const float rtw = 1.0f / (float)tw;
+    const int Kb = a.Cin * 2;
+    const int cchunks = a.Cin / 64;
+
+    char* const As = smem;             // [2][T * 32 rows][128]
+    char* const Bs = smem + 2 * pimg;  // [3][256][64]
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_h*)smem;
+    const u32x4h in_v = h_rsrc(a.in, (unsigned)((size_t)a.H * a.W * Kb));
+    const u32x4h wt_v = h_rsrc(a.wt, (unsigned)((size_t)a.Cout * 9 * Kb));
+
+    // patch piece of slot t: piece 4 t + wave, lane l brings row p = 8 (4 t + wave) + (l >> 3) (rows >= P: zeros into the padding)
+    unsigned a_voff[H4_TMAX];
+#pragma unroll
+    for (int t = 0; t < H4_TMAX; t++) {
+        const int p = 8 * (4 * t + wave) + (lane >> 3);
+        const int py = p / PW, px = p - py * PW;
+        const int iy = y0 - d + py, ix = x0 - d + px;
+        const bool ok = p < P && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        a_voff[t] = ok ? (unsigned)(iy * a.W + ix) * (unsigned)Kb + (unsigned)(((lane & 7) ^ h_swz(p)) * 16) : HOOB;
+    }
+    unsigned b_voff[B_IT];  // weight piece i of this wave: rows 16 (4 wave + i) .. + 15 of the 256 x 64 B image
+#pragma unroll
+    for (int i = 0; i < B_IT; i++) {
+        const int row = 16 * (wave * B_IT + i) + (lane >> 2);
+        const int n = n0 + row;
+        b_voff[i] = n < a.Cout ? (unsigned)n * (unsigned)(9 * Kb) + (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 16) : HOOB;
+    }
+    auto dma_a = [&](const int t, const int cc, const int img) {
+        h_dma16(in_v, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(img * pimg + (4 * t + wave) * 1024)), a_voff[t],
+                __builtin_amdgcn_readfirstlane((unsigned)(cc * 128)));
+    };
+    auto dma_b = [&](const int cc, const int q, const int img) {  // weight step q = 2 tap + half of channel chunk cc
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(((q >> 1) * cchunks + cc) * 128 + (q & 1) * H4_BKB));
+#pragma unroll
+        for (int i = 0; i < B_IT; i++)
+            h_dma16(wt_v, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * pimg + img * H4_BIMG + (wave * B_IT + i) * 1024)), b_voff[i], soff);
+    };
+
+    int pbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int R = (wm * TM + i) * 32 + r;
+        const int ty = (int)(((float)R + 0.5f) * rtw), tx = R - ty * tw;
+        pbase[i] = R < npix ? ty * PW + tx : 0;
+    }
+    const char* const b_lane = Bs + (wn * 128 + r) * H4_BKB;
+    const int b_sw = (r >> 2) & 3;
+
+    f32x16h acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    // ---- prologue: the patch of chunk 0 and the first three weight steps ----
+    for (int t = 0; t < T; t++) dma_a(t, 0, 0);
+    dma_b(0, 0, 0);
+    dma_b(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // In the K loop nothing travels by LDS-DMA: an LDS-DMA instruction holds its wave at issue for 50-60 cycles, an MFMA covers 32, and
+    // with one wave per SIMD nobody else feeds the pipe meanwhile (doubling the pieces of the first cut cost 24 %).  A plain 16-byte
+    // buffer load and, two steps later, a ds_write_b128 of the same registers each issue inside one MFMA's shadow: weight step s + 4 is
+    // loaded during step s into register set s & 1, written to the ring slot of step s + 2 during step s + 2 (free since that step's
+    // barrier), published by the barrier of step s + 3 and read from then on -- two whole steps of latency budget, no counted waits
+    // (the compiler tracks ordinary loads itself).
+    const auto wt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), 0, (unsigned)((size_t)a.Cout * 9 * Kb), 0x00020000);
+    const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (unsigned)((size_t)a.H * a.W * Kb), 0x00020000);
+    u32x4h wreg[2][B_IT], preg = {0u, 0u, 0u, 0u};
+    auto w_soff = [&](const int cc, const int q) { return (unsigned)(((q >> 1) * cchunks + cc) * 128 + (q & 1) * H4_BKB); };
+#pragma unroll
+    for (int i = 0; i < B_IT; i++) {
+        wreg[0][i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rs, b_voff[i], w_soff(0, 2), 0);
+        wreg[1][i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rs, b_voff[i], w_soff(0, 3), 0);
+    }
+    char* const w_dst = smem + 2 * pimg + wave * B_IT * 1024 + lane * 16;  // a piece lands lane-linear, as the DMA's did
+    char* const p_dst = smem + wave * 1024 + lane * 16;
+
+    // fragment addresses of all nine taps, kept for the whole kernel (36 VGPRs: with one wave per SIMD there is room, and the K loop
+    // loses the ~20 VALU instructions per tap that sat in ONE MFMA gap): chunk (2 sl + hh) of patch row p sits at position
+    // (2 sl + hh) ^ swz(p) = (sl << 1) ^ (hh ^ swz(p)); the patch image's offset is added by the same v_xad_u32 that applies the slice
+    unsigned abase9[9][TM];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int p = pbase[i] + ((t / 3) * PW + (t % 3)) * d;
+            abase9[t][i] = (unsigned)(p * 128) | (unsigned)((hh ^ h_swz(p)) << 4);
+        }
+    // MFMAs k0 .. k1 - 1 of a slice's sixteen (k = 4 i + j: consecutive MFMAs write different accumulators)
+    auto mma = [&](const h16x8h (&fa)[TM], const h16x8h (&fb)[TN], const int k0, const int k1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = k0; k < k1; k++)
+            acc[k >> 2][k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[k & 3], fa[k >> 2], acc[k >> 2][k & 3], 0, 0, 0);
+    };
+    // (the image offset is added FIRST and the slice XORed in after it -- the two touch disjoint bits, so the order is free, but
+    //  `(abase9 ^ slice)` alone is loop-invariant and the compiler would keep all 144 of them in registers: 30 spills)
+    unsigned acur[TM];  // abase9[current tap] + offset of the current patch image
+    auto read_a = [&](const int sl, h16x8h (&fa)[TM]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const h16x8h*>(As + (acur[i] ^ (unsigned)(sl << 5)));
+    };
+    auto read_b = [&](const int bs, const int kl, h16x8h (&fb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const h16x8h*>(b_lane + bs * H4_BIMG + j * 32 * H4_BKB + (((2 * kl + hh) ^ b_sw) * 16));
+    };
+// (with one wave per SIMD the ORDER is the schedule: an LDS-DMA holds its wave at issue for tens of cycles, a clump of five of them
+//  right after the barrier left the matrix pipe idle for most of that time -- every piece now sits alone between two MFMA pairs, the
+//  fragment reads likewise, and sched_barrier pins it)
+#define H4_PIN __builtin_amdgcn_sched_barrier(0)
+
+    h16x8h fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) acur[i] = abase9[0][i];
+    read_a(0, fa0);
+    read_b(0, 0, fb0);
+    for (int cc = 0; cc < cchunks; cc++) {
+        const int aimg = cc & 1;
+        const bool more_chunks = cc + 1 < cchunks;
+        const int ccn = more_chunks ? cc + 1 : 0;
+        const unsigned aoff = (unsigned)(aimg * pimg), aoff_n = (unsigned)((aimg ^ 1) * pimg);
+        // (the eighteen steps are instantiated one by one: `#pragma unroll` gives up on a body with pinned scheduling regions, and a
+        //  run-time q turns the slot / tap arithmetic and a_voff[q] into indexed register accesses -- 111 spilled VGPRs)
+        auto step = [&](auto QC) __attribute__((always_inline)) {
+            constexpr int q = decltype(QC)::value;
+            constexpr int half = q & 1;
+            // ---- slice 0 of step q: the fragments of slice 1 (same tap, same weight image) are read while set 0 is multiplied: ONE
+            //      ds_read_b128 behind each of the first eight MFMAs (a read holds the wave ~16 cycles at issue, an MFMA covers 32; four
+            //      reads in a row behind a pair of MFMAs left the pipe idle for half of them: 15 % of the kernel, INFUR_H4_ABL) ----
+#define H4_RA(fa, sl, i) if (!(ABL & 4)) fa[i] = *reinterpret_cast<const h16x8h*>(As + (acur[i] ^ (unsigned)((sl) << 5)))
+#define H4_RB(fb, bs, kl, j) if (!(ABL & 4)) fb[j] = *reinterpret_cast<const h16x8h*>(b_lane + (bs) * H4_BIMG + (j) * 32 * H4_BKB + (((2 * (kl) + hh) ^ b_sw) * 16))
+#define H4_M(fa, fb, k) acc[(k) >> 2][(k) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[(k) & 3], fa[(k) >> 2], acc[(k) >> 2][(k) & 3], 0, 0, 0)
+            H4_M(fa0, fb0, 0); H4_PIN; H4_RA(fa1, 2 * half + 1, 0); H4_PIN;
+            H4_M(fa0, fb0, 1); H4_PIN; H4_RA(fa1, 2 * half + 1, 1); H4_PIN;
+            H4_M(fa0, fb0, 2); H4_PIN; H4_RA(fa1, 2 * half + 1, 2); H4_PIN;
+            H4_M(fa0, fb0, 3); H4_PIN; H4_RA(fa1, 2 * half + 1, 3); H4_PIN;
+            H4_M(fa0, fb0, 4); H4_PIN; H4_RB(fb1, q % 3, 1, 0); H4_PIN;
+            H4_M(fa0, fb0, 5); H4_PIN; H4_RB(fb1, q % 3, 1, 1); H4_PIN;
+            H4_M(fa0, fb0, 6); H4_PIN; H4_RB(fb1, q % 3, 1, 2); H4_PIN;
+            H4_M(fa0, fb0, 7); H4_PIN; H4_RB(fb1, q % 3, 1, 3); H4_PIN;
+            // the next chunk's patch, one piece per wave and step: written here one step after it was asked for
+            H4_M(fa0, fb0, 8); H4_PIN;
+            if (!(ABL & 1) && q >= 1 && q - 1 < T && more_chunks) *reinterpret_cast<u32x4h*>(p_dst + (aimg ^ 1) * pimg + (q - 1) * 4096) = preg;
+            H4_PIN;
+            H4_M(fa0, fb0, 9); H4_PIN;
+            if (!(ABL & 1) && q < T && more_chunks) preg = __builtin_amdgcn_raw_buffer_load_b128(in_rs, a_voff[q], (unsigned)((cc + 1) * 128), 0);
+            H4_PIN;
+            mma(fa0, fb0, 10, 16);
+            // ---- image q + 1 is published (written during step q - 1, before this barrier), image q is free ----
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+            // ---- slice 1: the next step's first fragments; weight step q + 2 from its registers into the ring; weight step q + 4 into them ----
+            constexpr int qb = q + 4 >= 18 ? q + 4 - 18 : q + 4;
+            const int cb = q + 4 >= 18 ? ccn : cc;
+            constexpr int tn = q == 17 ? 0 : (q + 1) >> 1;  // the next step's tap (of the next chunk after the ninth)
+            const unsigned ao_n = q == 17 ? aoff_n : aoff;
+#define H4_AC(i) if (half == 1) acur[i] = abase9[tn][i] + ao_n
+            H4_M(fa1, fb1, 0); H4_PIN; H4_AC(0); H4_RA(fa0, half == 1 ? 0 : 2, 0); H4_PIN;
+            H4_M(fa1, fb1, 1); H4_PIN; H4_AC(1); H4_RA(fa0, half == 1 ? 0 : 2, 1); H4_PIN;
+            H4_M(fa1, fb1, 2); H4_PIN; H4_AC(2); H4_RA(fa0, half == 1 ? 0 : 2, 2); H4_PIN;
+            H4_M(fa1, fb1, 3); H4_PIN; H4_AC(3); H4_RA(fa0, half == 1 ? 0 : 2, 3); H4_PIN;
+#undef H4_AC
+            H4_M(fa1, fb1, 4); H4_PIN; H4_RB(fb0, (q + 1) % 3, 0, 0); H4_PIN;
+            H4_M(fa1, fb1, 5); H4_PIN; H4_RB(fb0, (q + 1) % 3, 0, 1); H4_PIN;
+            H4_M(fa1, fb1, 6); H4_PIN; H4_RB(fb0, (q + 1) % 3, 0, 2); H4_PIN;
+            H4_M(fa1, fb1, 7); H4_PIN; H4_RB(fb0, (q + 1) % 3, 0, 3); H4_PIN;
+#define H4_W(i) if (!(ABL & 1)) *reinterpret_cast<u32x4h*>(w_dst + ((q + 2) % 3) * H4_BIMG + (i) * 1024) = wreg[q & 1][i]
+#define H4_L(i) if (!(ABL & 1)) wreg[q & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rs, b_voff[i], w_soff(cb, qb), 0)
+            H4_M(fa1, fb1, 8); H4_PIN; H4_W(0); H4_PIN;
+            H4_M(fa1, fb1, 9); H4_PIN; H4_W(1); H4_PIN;
+            H4_M(fa1, fb1, 10); H4_PIN; H4_W(2); H4_PIN;
+            H4_M(fa1, fb1, 11); H4_PIN; H4_W(3); H4_PIN;
+            H4_M(fa1, fb1, 12); H4_PIN; H4_L(0); H4_PIN;
+            H4_M(fa1, fb1, 13); H4_PIN; H4_L(1); H4_PIN;
+            H4_M(fa1, fb1, 14); H4_PIN; H4_L(2); H4_PIN;
+            H4_M(fa1, fb1, 15); H4_PIN; H4_L(3); H4_PIN;
+#undef H4_W
+#undef H4_L
+#undef H4_RA
+#undef H4_RB
+#undef H4_M
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+        step(std::integral_constant<int, 9>{});
+        step(std::integral_constant<int, 10>{});
+        step(std::integral_constant<int, 11>{});
+        step(std::integral_constant<int, 12>{});
+        step(std::integral_constant<int, 13>{});
+        step(std::integral_constant<int, 14>{});
+        step(std::integral_constant<int, 15>{});
+        step(std::integral_constant<int, 16>{});
+        step(std::integral_constant<int, 17>{});
+    }
+#undef H4_PIN
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: + bias, ReLU, f16 (the steps per value of every other configuration); 16 lanes store the 256 contiguous bytes
+    //      of a pixel's 128 channels ----
+    char* stage = smem + wave * 32 * H4_ROWB;
+    const int e_row = lane >> 4, e_col = lane & 15;
+    const int n = n0 + wn * 128 + e_col * 8;
+    const bool n_ok = n < a.Cout;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bv2 = bv;
+    if (a.bias && n_ok) {
+        bv = *reinterpret_cast<const float4*>(a.bias + n);
+        bv2 = *reinterpret_cast<const float4*>(a.bias + n + 4);
+    }
+    _Float16* out = static_cast<_Float16*>(a.out);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int jj = 0; jj < TN; jj++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const float4 v = make_float4(acc[i][jj][4 * gq + 0], acc[i][jj][4 * gq + 1], acc[i][jj][4 * gq + 2], acc[i][jj][4 * gq + 3]);
+                *reinterpret_cast<float4*>(stage + r * H4_ROWB + (jj * 32 + 8 * gq + 4 * hh) * 4) = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + e_row;
+            const int R = (wm * TM + i) * 32 + row;
+            const int ty = (int)(((float)R + 0.5f) * rtw), tx = R - ty * tw;
+            const int oy = y0 + ty, ox = x0 + tx;
+            if (R < npix && oy < a.OH && ox < a.OW && n_ok) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + row * H4_ROWB + e_col * 32);
+                const float4 v2 = *reinterpret_cast<const float4*>(stage + row * H4_ROWB + e_col * 32 + 16);
+                float x[8] = {v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w, v2.x + bv2.x, v2.y + bv2.y, v2.z + bv2.z, v2.w + bv2.w};
+                if (a.relu) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++) x[t] = fmaxf(x[t], 0.f);
+                }
+                const h16x8h hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3],
+                                   (_Float16)x[4], (_Float16)x[5], (_Float16)x[6], (_Float16)x[7]};
+                *reinterpret_cast<h16x8h*>(out + ((size_t)oy * a.OW + ox) * a.Cout + n) = hv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// tiling for the 4-wave form: the candidates of halo_plan, two patch images always, one workgroup per CU
+HaloPlan halo4_plan(const ConvArgs& a) {
+    HaloPlan best;
+    long best_cost[3] = {0, 0, 0};
+    const int ntiles = a.Cout / H4_BN, d = a.dil, H = a.OH, W = a.OW;
+    auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    HaloGeom cands[3];
+    int nc = 0;
+    cands[nc++] = HaloGeom{16, 16, cdiv(W, 16), cdiv(H, 16) * cdiv(W, 16), H, 0, 0, 0, cdiv(H, 16) * cdiv(W, 16)};
+    cands[nc++] = HaloGeom{8, 32, cdiv(W, 32), cdiv(H, 8) * cdiv(W, 32), H, 0, 0, 0, cdiv(H, 8) * cdiv(W, 32)};
+    if (H >= 16 && H % 16 != 0 && H % 16 <= 8) {
+        const int n1 = (H / 16) * cdiv(W, 16), n2 = cdiv(W, 32);
+        cands[nc++] = HaloGeom{16, 16, cdiv(W, 16), n1, (H / 16) * 16, H % 16, 32, n2, n1 + n2};
+    }
+    for (int ci = 0; ci < nc; ci++) {
+        const HaloGeom& g = cands[ci];
+        int lds = h4_lds(g.th1, g.tw1, d), slots = h4_slots(g.th1, g.tw1, d);
+        const long patch = (long)(g.th1 + 2 * d) * (g.tw1 + 2 * d);
+        if (g.th2) {
+            lds = lds > h4_lds(g.th2, g.tw2, d) ? lds : h4_lds(g.th2, g.tw2, d);
+            slots = slots > h4_slots(g.th2, g.tw2, d) ? slots : h4_slots(g.th2, g.tw2, d);
+        }
+        if (lds > 160 * 1024 || slots > H4_TMAX) continue;
+        const long wgs = (long)g.mtiles * ntiles;
+        const long cost[3] = {(wgs + 255) / 256, g.mtiles, patch};
+        bool better = best.na == 0;
+        for (int k = 0; k < 3 && !better; k++) {
+            if (cost[k] < best_cost[k]) better = true;
+            else if (cost[k] > best_cost[k]) break;
+        }
+        if (better) {
+            best.g = g; best.na = 2; best.lds = lds;
+            for (int k = 0; k < 3; k++) best_cost[k] = cost[k];
+        }
+    }
+    return best;
+}
+
 template <int BN, int NA>
 hipError_t launch_halo(const ConvArgs& a, const HaloPlan& pl, hipStream_t s) {
     const int ntiles = a.Cout / BN;
@@ -420,6 +767,36 @@ hipError_t launch_conv3x3_halo(const ConvArgs& a, int bn, hipStream_t s) {
     if (bn == 64) return launch_halo<64, 1>(a, pl, s);
     if (bn == 128) return pl.na == 2 ? launch_halo<128, 2>(a, pl, s) : launch_halo<128, 1>(a, pl, s);
     return pl.na == 2 ? launch_halo<256, 2>(a, pl, s) : launch_halo<256, 1>(a, pl, s);
+}
+
+
+bool conv3x3_halo4_valid(const ConvArgs& a, int mode, int out_f32) {
+    if (mode != 1 || out_f32) return false;
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != a.dil || (a.dil != 1 && a.dil != 2)) return false;
+    if (a.res || a.in2 || a.batch > 1 || a.OH != a.H || a.OW != a.W) return false;
+    if (a.Cin % 64 != 0 || a.Cout % H4_BN != 0) return false;
+    if (halo4_plan(a).na == 0) return false;
+    return (size_t)a.H * a.W * a.Cin * 2 < 0x80000000ull && (size_t)a.Cout * 9 * a.Cin * 2 < 0x80000000ull;
+}
+
+hipError_t launch_conv3x3_halo4(const ConvArgs& a, hipStream_t s) {
+    if (!conv3x3_halo4_valid(a, 1, 0)) return hipErrorInvalidValue;
+    const HaloPlan pl = halo4_plan(a);
+    const int ntiles = a.Cout / H4_BN;
+    // INFUR_H4_ABL (timing ablations, results WRONG): 1 no DMA in the K loop, 2 no barrier, 4 no fragment reads
+    static const int abl = getenv("INFUR_H4_ABL") ? atoi(getenv("INFUR_H4_ABL")) : 0;
+    auto k = abl == 1 ? conv3x3_halo4_kernel<1> : abl == 2 ? conv3x3_halo4_kernel<2> : abl == 3 ? conv3x3_halo4_kernel<3> : abl == 4 ? conv3x3_halo4_kernel<4>
+             : abl == 7 ? conv3x3_halo4_kernel<7> : conv3x3_halo4_kernel<0>;
+    static std::atomic<bool> attr_done[64];
+    int dev = 0;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (!known || !attr_done[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (known) attr_done[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(k, dim3(pl.g.mtiles * ntiles), dim3(256), pl.lds, s, a, pl.g, ntiles);
+    return hipGetLastError();
 }
 
 }  // namespace infur

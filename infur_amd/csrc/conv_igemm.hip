@@ -74,6 +74,9 @@ static const CfgInfo kCfgs[] = {
     // the L2 -> LDS path, not by the MFMA
     {256, 128, {"conv3x3_f32<16x16,128,halo>", "conv3x3_f16<16x16,128,halo>", "conv3x3_f32s<16x16,128,halo>"}},
     {256, 256, {"conv3x3_f32<16x16,256,halo>", "conv3x3_f16<16x16,256,halo>", "conv3x3_f32s<16x16,256,halo>"}},
+    // the same with ONE wave per SIMD and a 128 x 128 wave tile (two thirds of the fragment reads per MFMA), software-pipelined across
+    // the weight steps (conv3x3_halo.hip, "the 4-wave form")
+    {256, 256, {"conv3x3_f32<16x16,256,halo4>", "conv3x3_f16<16x16,256,halo4>", "conv3x3_f32s<16x16,256,halo4>"}},
     // (late round 3: a 128x32 tile of two waves for the logit convs -- M = 32400 gives only 127 workgroups of 256 rows for 256 CUs --
     // is bit-identical and 2 us faster per launch (f32 28.8 -> 26.6 / 20.8 -> 18.6 us, i8 10.6 -> 9.5): the launch is latency-bound,
     // not short of workgroups; not worth a configuration.)
@@ -139,6 +142,7 @@ bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32) 
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     if (mode == 3) mode = 2;  // the fp8 cross-term form stages like the split mode
     if (cfg == 19 || cfg == 20) return conv3x3_halo_valid(a, mode, out_f32, cfg == 19 ? 128 : 256);
+    if (cfg == 21) return conv3x3_halo4_valid(a, mode, out_f32);
     if (cfg >= 13 && mode != 1 && mode != 4) return false;  // LDS-DMA staging: byte operands that need no conversion (f16, i8)
     if (cfg == 18) return mode == 4 && conv1x1_q8_valid(a, mode, out_f32) && conv1x1_q8_nsplit(a) > 1;
     if (cfg == 15) return mode == 4 ? conv1x1_q8_valid(a, mode, out_f32) : conv1x1_areg_valid(a, mode, out_f32);  // (never the f32 logits)

@@ -1060,6 +1060,9 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 20:
             if constexpr (std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value && !SPLIT) return launch_conv3x3_halo(a, cfg == 19 ? 128 : 256, s);
             return hipErrorInvalidValue;
+        case 21:
+            if constexpr (std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value && !SPLIT) return launch_conv3x3_halo4(a, s);
+            return hipErrorInvalidValue;
         case 18:
             if constexpr (std::is_same<T, signed char>::value && std::is_same<OutT, unsigned char>::value) {
                 if (conv1x1_q8_valid(a, 4, 0) && conv1x1_q8_nsplit(a) > 1) return launch_conv1x1_q8(a, conv1x1_q8_nsplit(a), s);

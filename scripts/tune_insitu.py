@@ -23,7 +23,7 @@ JOBS = [("f32", 50, (1920, 1080), 1.0), ("f16", 50, (1920, 1080), 1.0), ("f16", 
 MODE = {"f32": "0", "f16": "1", "f32s": "2", "f32x": "3", "i8": "4"}
 # a change must win 3 % on the layers it touches (INSITU_MIN_GAIN / INSITU_FRAMES / INSITU_CFGS="19,20": a closer look at few candidates)
 FRAMES, MIN_GAIN = int(os.environ.get("INSITU_FRAMES", 7)), float(os.environ.get("INSITU_MIN_GAIN", 0.03))
-NCFG = 21
+NCFG = 22
 CANDS = [int(x) for x in os.environ["INSITU_CFGS"].split(",")] if os.environ.get("INSITU_CFGS") else list(range(NCFG))
 
 
