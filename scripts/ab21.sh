@@ -1,2 +1,4 @@
-mkdir -p gpurun_out/r5m
-for abl in 0 16 32 0; do INFUR_H4_ABL=$abl INFUR_CONV_CFG=21 python scripts/cfg_ab.py 2160 3840 101 f16 2>&1 | grep -E "frame kernels|layer3 conv2 rest|layer4 conv2 first|classifier.0" >> gpurun_out/r5m/abl.log; done; cat gpurun_out/r5m/abl.log
+mkdir -p gpurun_out/r5o
+INSITU_MIN_GAIN=0.015 INSITU_FRAMES=15 INSITU_CFGS=21,16 python scripts/tune_insitu.py f16 > gpurun_out/r5o/insitu.log 2>&1
+cp infur_amd/conv_tune_gfx950.txt gpurun_out/r5o/
+tail -12 gpurun_out/r5o/insitu.log

@@ -43,7 +43,7 @@ def test_all_tile_configurations_are_bit_identical(tmp_path):
     ref = run_with_cfg(0, str(tmp_path / "cfg0.npz"))
     # None = autotuned mix; 13, 14, 16, 17 = LDS-DMA staging, 15 = register-resident 1x1 (f16 only), 19 / 20 = the 3x3 form with the input
     # patch resident in LDS (conv3x3_halo.hip, f16 only)
-    for cfg in list(range(1, 18)) + [19, 20, None]:
+    for cfg in list(range(1, 18)) + [19, 20, 21, None]:
         got = run_with_cfg(cfg, str(tmp_path / f"cfg{cfg}.npz"))
         for k in ref.files:
             assert (ref[k].view(np.uint8) == got[k].view(np.uint8)).all(), (cfg, k)
