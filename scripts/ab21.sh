@@ -1,4 +1,5 @@
-mkdir -p gpurun_out/r5o
-INSITU_MIN_GAIN=0.015 INSITU_FRAMES=15 INSITU_CFGS=21,16 python scripts/tune_insitu.py f16 > gpurun_out/r5o/insitu.log 2>&1
-cp infur_amd/conv_tune_gfx950.txt gpurun_out/r5o/
-tail -12 gpurun_out/r5o/insitu.log
+mkdir -p gpurun_out/r5p
+INFUR_CONV_CFG=21 python scripts/race_screen.py 40 f16 > gpurun_out/r5p/race_h4.log 2>&1; tail -4 gpurun_out/r5p/race_h4.log
+python scripts/race_screen.py 30 f16 > gpurun_out/r5p/race_db.log 2>&1; tail -4 gpurun_out/r5p/race_db.log
+python -m pytest tests -x -q -m gpu > gpurun_out/r5p/gpu_tests.log 2>&1; tail -4 gpurun_out/r5p/gpu_tests.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/r5p/bench_s20.json 2> gpurun_out/r5p/bench_s20.err; tail -c 600 gpurun_out/r5p/bench_s20.json
