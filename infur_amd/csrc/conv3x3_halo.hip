@@ -12,7 +12,8 @@
 // activation fragments from that patch at a per-tap row offset; only the weight tile (BN x 128 B) is new per tap.  Activation
 // ingest falls 5.8x (d = 2), the K step's L2 -> LDS traffic from 48 KB to ~22 KB, LDS write traffic with it.
 //
-// Shape: 8 waves, BN = 64 (layer1: waves 8 x 1, 32 pixels x 64 channels each), BN = 128 (4 x 2, 64 x 64) or BN = 256 (2 x 4, 128 x 64);
+// Shape (the 4-wave form with 128 x 128 wave tiles has its own section below): 8 waves, BN = 64 (layer1: waves 8 x 1, 32 pixels x 64
+// channels each), BN = 128 (4 x 2, 64 x 64) or BN = 256 (2 x 4, 128 x 64);
 // everything arrives by
 // LDS-DMA (buffer_load ... lds, rows of 128 bytes, 16-byte chunk index XOR-swizzled by (row >> 1) & 7 on the SOURCE side, as in
 // conv_igemm_kernel.h); two weight images (tap t + 1 lands while tap t is multiplied), and two patch images when they fit the

@@ -82,7 +82,7 @@ hipError_t launch_conv1x1_q8(const ConvArgs& a, int nsplit, hipStream_t s);
 int conv1x1_q8_nsplit(const ConvArgs& a);  // configuration 18: N tiles shared out over this many workgroups per M tile (0: not a candidate)
 
 // stride-1 3x3 convolutions (pad = dilation 1 / 2 / 4), f16 operands and output, no residual: the input patch of a 16 x 16 output
-// tile stays in LDS for all nine taps (conv3x3_halo.hip).  Configurations 19 (bn = 128) and 20 (bn = 256) of mode 1.
+// tile stays in LDS for all nine taps (conv3x3_halo.hip).  Configurations 19 (bn = 128), 20 (bn = 256) and 21 (the 4-wave form) of mode 1.
 bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn);
 hipError_t launch_conv3x3_halo(const ConvArgs& a, int bn, hipStream_t s);
 // the 4-wave form (configuration 21): BN = 256, one wave per SIMD with a 128 x 128 wave tile, dilation 1 / 2

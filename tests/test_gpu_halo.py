@@ -1,5 +1,5 @@
 """conv3x3_halo.hip (round 4): the stride-1 3x3 convolutions of the f16 mode with the input patch of a 16 x 16 output tile resident
-in LDS for all nine taps -- configurations 19 (BN = 128) and 20 (BN = 256).  Same k order as the tiled forms (chunk-major since
+in LDS for all nine taps -- configurations 19 (BN = 128), 20 (BN = 256) and 21 (BN = 256, one wave per SIMD with 128 x 128 wave tiles).  Same k order as the tiled forms (chunk-major since
 round 4), same MFMA, same epilogue: EVERY conv output of FCN-ResNet50 / 101 must equal configuration 0's bit for bit, at sizes
 whose stride-8 maps are smaller than a tile, ragged against it, and many tiles wide (dilations 1, 2 and 4 all occur: layer2,
 layer3.0 d = 1; layer3.1+ and layer4.0 d = 2; layer4.1+ d = 4; the heads d = 1).  The environment variable is read once per
