@@ -806,10 +806,15 @@ hipError_t launch_conv3x3_halo4(const ConvArgs& a, hipStream_t s) {
     if (!conv3x3_halo4_valid(a, 1, 0)) return hipErrorInvalidValue;
     const HaloPlan pl = halo4_plan(a);
     const int ntiles = a.Cout / H4_BN;
-    // INFUR_H4_ABL (timing ablations, results WRONG): 1 no DMA in the K loop, 2 no barrier, 4 no fragment reads
+    // timing ablations (results WRONG; instrumentation build only: make EXTRA=-DH4_ABLATIONS, then INFUR_H4_ABL = 1 no staging in the K
+    // loop, 2 no barrier, 4 no fragment reads, 7 all three, 16 no stores, 32 no epilogue)
+#ifdef H4_ABLATIONS
     static const int abl = getenv("INFUR_H4_ABL") ? atoi(getenv("INFUR_H4_ABL")) : 0;
-    auto k = abl == 1 ? conv3x3_halo4_kernel<1> : abl == 2 ? conv3x3_halo4_kernel<2> : abl == 3 ? conv3x3_halo4_kernel<3> : abl == 4 ? conv3x3_halo4_kernel<4>
+    auto k = abl == 1 ? conv3x3_halo4_kernel<1> : abl == 2 ? conv3x3_halo4_kernel<2> : abl == 4 ? conv3x3_halo4_kernel<4>
              : abl == 7 ? conv3x3_halo4_kernel<7> : abl == 16 ? conv3x3_halo4_kernel<16> : abl == 32 ? conv3x3_halo4_kernel<32> : conv3x3_halo4_kernel<0>;
+#else
+    auto k = conv3x3_halo4_kernel<0>;
+#endif
     static std::atomic<bool> attr_done[64];
     int dev = 0;
     const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
