@@ -15,6 +15,7 @@
 // fragment as the row operand, f32 accumulation, + bias + residual, ReLU, f16 store): bit-identical results
 // (tests/test_gpu_conv_configs.py), so the autotuner may pick it per layer shape like any other configuration.
 #include <atomic>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -30,7 +31,7 @@ typedef __attribute__((address_space(3))) void lds_void_a;
 namespace {
 
 constexpr unsigned OOBA = 0x80000000u;
-constexpr int AR_BM = 256, AR_BN = 128, AR_ROWB = 2 * 128 + 16;  // staged epilogue row: 64 f32 + pad
+constexpr int AR_BN = 128, AR_ROWB = 2 * 128 + 16;  // staged epilogue row: 64 f32 + pad
 constexpr int AR_B_IMG = AR_BN * 128;                             // one weight image: 128 rows x 128 bytes (64 k)
 constexpr int AR_NIMG = 4;                                        // ring of weight images: K step q + 4 is in flight while q computes
 constexpr int AR_LDS = AR_NIMG * AR_B_IMG + 8 * 32 * AR_ROWB;     // weight images + per-wave epilogue slices
@@ -54,9 +55,14 @@ __device__ __forceinline__ void ar_dma16(const u32x4a rsrc, const unsigned lds, 
 //   <KS, 2, 2>: 4 waves along M x 2 along N, 64 x 64 each (Cin <= 256: the activation fragment is <= 128 VGPRs)
 //   <8, 1, 4>:  8 waves along M, 32 pixels x all 128 channels each (round 3: Cin = 512, the expansions of layer4 -- the
 //               fragment of 32 pixels x 512 channels is 128 VGPRs; every weight fragment then feeds one MFMA instead of two)
-template <int KS, int TMI = 2, int TNJ = 2>
-__global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, const int mtiles) {
-    static_assert(TMI * TNJ == 4 && (TMI == 1 || TMI == 2), "8 waves cover 256 x 128");
+//   <KS, 1, 4, 4>: FOUR waves x 32 pixels = 128 pixels per workgroup (round 4): at 1080p the stride-8 map has M = 32,400 pixels = 127
+//               workgroups of 256 -- half the chip idle; 254 workgroups of 128 put one on every CU (the form 3 of conv1x1_b2b.hip)
+template <int KS, int TMI = 2, int TNJ = 2, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) conv1x1_areg_kernel(const ConvArgs a, const int mtiles) {
+    static_assert(TMI * TNJ == 4 && (TMI == 1 || TMI == 2), "a wave covers 4 blocks of 32 x 32");
+    static_assert(NW == 8 || (NW == 4 && TNJ == 4), "8 waves cover 256 x 128, 4 waves 128 x 128");
+    constexpr int BM = NW * TMI * TNJ * 32 * 32 / AR_BN;  // pixels per workgroup
+    constexpr int PPW = 16 / NW;                          // weight pieces (1 KB) per wave and K step
     constexpr int WN = 4 / TNJ;  // waves along N
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,7 +75,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
         const int q = mtiles >> 3, r = mtiles & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int m0 = tile * AR_BM;
+    const int m0 = tile * BM;
     const int ntiles = (a.Cout + AR_BN - 1) / AR_BN;
 
     // ---- the wave's activation fragments, loaded once: rows wm * 32 TMI + i * 32 + (lane & 31), all Cin channels ----
@@ -96,11 +102,11 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
         wt_v.w = 0x00020000u;
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_void_a*)smem;
-    unsigned b_voff[2];  // per piece: row (within the N tile) * Kb + swizzled chunk * 16
-    int b_row[2];
+    unsigned b_voff[PPW];  // per piece: row (within the N tile) * Kb + swizzled chunk * 16
+    int b_row[PPW];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int row = 8 * (wave * 2 + i) + (lane >> 3);
+    for (int i = 0; i < PPW; i++) {
+        const int row = 8 * (wave * PPW + i) + (lane >> 3);
         b_row[i] = row;
         b_voff[i] = (unsigned)row * (unsigned)Kb + (unsigned)(((lane & 7) ^ ar_swz(row)) * 16);
     }
@@ -116,9 +122,9 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
         const unsigned img = lds0 + (unsigned)((q & (AR_NIMG - 1)) * AR_B_IMG);
         const unsigned soff = (unsigned)(nt * AR_BN) * (unsigned)Kb + (unsigned)(ks * 128);
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < PPW; i++) {
             const bool ok = nt * AR_BN + b_row[i] < a.Cout;
-            ar_dma16(wt_v, __builtin_amdgcn_readfirstlane(img + (unsigned)((wave * 2 + i) * 1024)), ok ? b_voff[i] : OOBA, __builtin_amdgcn_readfirstlane(soff));  // (OOB + soff stays beyond num_records: zeros)
+            ar_dma16(wt_v, __builtin_amdgcn_readfirstlane(img + (unsigned)((wave * PPW + i) * 1024)), ok ? b_voff[i] : OOBA, __builtin_amdgcn_readfirstlane(soff));  // (OOB + soff stays beyond num_records: zeros)
         }
     };
     for (int q = 0; q < AR_NIMG && q < Q; q++) dma_step(q);
@@ -170,9 +176,9 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
             // older loads, so only the DMA pieces are counted: a store still in flight makes the wait longer, never unsafe.
             const int younger = (q + 2 < Q ? 1 : 0) + (q + 3 < Q ? 1 : 0);
             if (younger == 2)
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
             else if (younger == 1)
-                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -229,11 +235,12 @@ __global__ void __launch_bounds__(512, 2) conv1x1_areg_kernel(const ConvArgs a, 
     }
 }
 
-template <int KS, int TMI = 2, int TNJ = 2>
+template <int KS, int TMI = 2, int TNJ = 2, int NW = 8>
 hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = NW * TMI * TNJ * 32 * 32 / AR_BN;
     const int M = a.OH * a.OW;
-    const int mtiles = (M + AR_BM - 1) / AR_BM;
-    auto k = conv1x1_areg_kernel<KS, TMI, TNJ>;
+    const int mtiles = (M + BM - 1) / BM;
+    auto k = conv1x1_areg_kernel<KS, TMI, TNJ, NW>;
     static std::atomic<bool> attr_done[64];
     int dev = 0;
     const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
@@ -242,7 +249,7 @@ hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         if (known) attr_done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k, dim3(mtiles), dim3(512), AR_LDS, s, a, mtiles);
+    hipLaunchKernelGGL(k, dim3(mtiles), dim3(NW * 64), AR_LDS, s, a, mtiles);
     return hipGetLastError();
 }
 
@@ -256,6 +263,19 @@ bool conv1x1_areg_valid(const ConvArgs& a, int mode, int out_f32) {
 }
 
 hipError_t launch_conv1x1_areg(const ConvArgs& a, hipStream_t s) {
+    // the 128-pixel form where 256-pixel workgroups would leave more than a third of the 256 CUs without one (INFUR_AREG_BM=128 / 256:
+    // measurement hook)
+    static const int bm_env = getenv("INFUR_AREG_BM") ? atoi(getenv("INFUR_AREG_BM")) : 0;
+    const bool small = bm_env == 128 || (bm_env != 256 && (a.OH * a.OW + 255) / 256 <= 170);
+    if (small) {
+        switch (a.Cin) {
+            case 64: return launch_ks<1, 1, 4, 4>(a, s);
+            case 128: return launch_ks<2, 1, 4, 4>(a, s);
+            case 256: return launch_ks<4, 1, 4, 4>(a, s);
+            case 512: return launch_ks<8, 1, 4, 4>(a, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (a.Cin) {
         case 64: return launch_ks<1>(a, s);
         case 128: return launch_ks<2>(a, s);
