@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-CONV_KERNELS = ("conv_igemm_", "conv1x1_")  # tiled implicit GEMM; A-resident 1x1 and the fused conv3 -> next conv1 pair (f16 mode)
+CONV_KERNELS = ("conv_igemm_", "conv1x1_", "conv3x3_", "conv_hl")  # tiled implicit GEMM; A-resident 1x1 and the fused conv3 -> next conv1 pair (f16 mode)
 COPY_CEILING_GBS = 5450.0  # measured: a streaming copy of 0.5-4 GB sustains 5.3-5.6 TB/s read + write on this pool (profiles/r03_copy_ceiling.md)
 
 
@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side measurements of BASELINE configs[2] (1080p stream at scale 0.5, PCIe inclusive) and "
                          "configs[4] (4K FCN-ResNet101 f16)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s", "f32x", "i8"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s", "f32x", "f16hl", "i8"],
                     help="conv-stack arithmetic: f32 (BASELINE configs[1], the default and the parity mode) or f16 "
                          "operands with f32 accumulation (configs[4]'s mode)")
     ap.add_argument("--winograd-min-cin", type=int, default=0,
@@ -437,6 +437,7 @@ def main():
             # f32s: three f16 MFMAs per product -> the ceiling for f32-equivalent FLOPs is a third of the f16 peak
             peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "f32s": PEAK_F16_MFMA_TFLOPS / 3.0,
                     "f32x": PEAK_F16_MFMA_TFLOPS / 2.0,  # f32x: one f16 MFMA + one fp8 MX MFMA (half an f16 unit per term) per product
+                    "f16hl": PEAK_F16_MFMA_TFLOPS / 2.0,  # the same two units on three-byte tensors
                     "i8": 2.0 * PEAK_F16_MFMA_TFLOPS}[a.dtype]  # dense i8 MFMA: twice the f16 rate (TOP/s; >= 3944 measured in the guide)
             conv = [r for r in recs if r["kernel"].startswith(CONV_KERNELS)]
             # dominant kernel = the tile configuration of conv_igemm that takes the most time in a frame over the
@@ -465,7 +466,7 @@ def main():
                 nbuf = {"1buf": "1", "1frag": "3", "dma": "4", "dmai": "5"}.get(parts[2], "2") if len(parts) > 2 else "2"
                 waves = {"128,256": "2, 4", "256,128": "4, 2", "256,32": "4, 1", "256,256": "2, 4"}.get(f"{bm},{bn}", "2, 2")
                 el = {"f16": "_Float16, _Float16", "i8": "signed char, unsigned char"}.get(a.dtype, "float, float")
-                split = {"f32": "false", "f16": "false", "f32s": "true", "f32x": "true", "i8": "false"}[a.dtype]
+                split = {"f32": "false", "f16": "false", "f32s": "true", "f32x": "true", "i8": "false", "f16hl": "false"}[a.dtype]
                 # all instantiations of this tile (plain / 1x1-GEMM addressing / residual prefetch), launch-weighted
                 pre = f"conv_igemm_kernel<{el}, {bm}, {bn}, {waves}, {nbuf}, {split}"
                 ts = [t for k, t in json.load(open(tj))["kernels"].items() if k.startswith(pre)]

@@ -67,7 +67,7 @@ enum {
                             split into an f16 pair hi + lo (22 significand bits) and the product is
                             accumulated in f32 from three f16 MFMAs (lo*hi + hi*lo + hi*hi).  f32-grade
                             logits (tests: <= 2e-5 of the f32 oracle) at a multiple of the f32 MFMA rate */
-    INFUR_DTYPE_F32_SPLIT_FP8 = 3 /* as INFUR_DTYPE_F32_SPLIT, but only hi*hi runs on the f16 MFMA; the two cross terms
+    INFUR_DTYPE_F32_SPLIT_FP8 = 3, /* as INFUR_DTYPE_F32_SPLIT, but only hi*hi runs on the f16 MFMA; the two cross terms
                             hi*lo + lo*hi run on the bf8 (OCP e5m2) MX MFMA at twice the f16 rate: 2 MFMA units per
                             product instead of 3.  e5m2 has f16's exponent range, so no tensor-level scale is involved and
                             the error does not depend on the tensors' dynamic range: products exact to ~2^-13, logits
@@ -77,6 +77,16 @@ enum {
                             7x room, ~15x closer than INFUR_DTYPE_F16; a side mode, never the bench headline: at 1080p
                             it is only ~6 % faster than INFUR_DTYPE_F32_SPLIT, whose logits are 9x closer still.
                             (Round 3 used e4m3 under static scales: 7.1e-4 / 5.1e-2 on the same hostile set.) */
+    /* (4 is not an option value: the integer arithmetic of a quantised model is selected by the model file) */
+    INFUR_DTYPE_F16_HL = 5 /* round 5: THREE-BYTE tensors -- every activation and weight tensor is an f16 hi plane plus an e5m2
+                            (OCP bf8) lo plane of (x - hi) * 2^11, written by the producing kernel's epilogue and staged by
+                            LDS-DMA by its consumers (no register staging, no conversion): 3 bytes per element through HBM, L2 and
+                            the CU's ingest path instead of the split modes' 4.  Products as INFUR_DTYPE_F32_SPLIT_FP8 (hi*hi
+                            on the f16 MFMA, both cross terms on the bf8 MX MFMA: 2 units) with the hi bytes of the cross terms
+                            taken by TRUNCATION from the f16 fragments (one v_perm per four values; the mean of the truncation
+                            is folded into the lo planes).  ~14 significant bits per operand and per stored tensor: the mode
+                            built to satisfy both halves of north_star's sentence (logits within 1e-3, f16-matrix-core rate).
+                            Stride-1 3x3 convs with Cin >= 128 run in the Winograd domain as in the f32 modes. */
 };
 
 typedef struct infur_ctx infur_ctx;

@@ -33,6 +33,7 @@ DTYPE_F32 = 0
 DTYPE_F16 = 1
 DTYPE_F32_SPLIT = 2
 DTYPE_F32_SPLIT_FP8 = 3  # split mode with the cross terms on the fp8 MX MFMA ("f32x")
+DTYPE_F16_HL = 5  # three-byte tensors (f16 hi + e5m2 lo planes), two MFMA units per product ("f16hl")
 
 
 class Options(C.Structure):

@@ -111,6 +111,15 @@ int conv_igemm_num_configs() { return kNumCfgs; }
 int conv_igemm_config_tile_area(int cfg) { return cfg < 0 || cfg >= kNumCfgs ? 0 : kCfgs[cfg].bm * kCfgs[cfg].bn; }
 
 const char* conv_igemm_config_name(int cfg, int mode) {
+    if (mode == 5) {  // the three-byte mode's own kernel (conv_hl.hip) on the tile shapes of these four entries
+        switch (cfg) {
+            case 11: return "conv_hl<256,256>";
+            case 0: return "conv_hl<128,128>";
+            case 6: return "conv_hl<256,128>";
+            case 5: return "conv_hl<128,256>";
+            default: return "conv_hl<?>";
+        }
+    }
     if (cfg < 0 || cfg >= kNumCfgs || mode < 0 || mode > 4) return "conv_igemm<?>";
     if (mode >= 3) {  // "conv_igemm_f32s<...>" -> "conv_igemm_f32x<...>" / "conv_igemm_i8<...>"
         static std::string names[2][64];
@@ -140,6 +149,7 @@ int conv_igemm_default_config(const ConvArgs& a) {
 // a configuration is a candidate when its N tile is not mostly padding (and, for the LDS-DMA forms, in the f16 mode)
 bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32) {
     if (cfg < 0 || cfg >= kNumCfgs) return false;
+    if (mode == 5) return conv_hl_config_valid(a, cfg, out_f32);
     if (mode == 3) mode = 2;  // the fp8 cross-term form stages like the split mode
     if (cfg == 19 || cfg == 20) return conv3x3_halo_valid(a, mode, out_f32, cfg == 19 ? 128 : 256);
     if (cfg == 21) return conv3x3_halo4_valid(a, mode, out_f32);
@@ -153,6 +163,7 @@ bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32) 
 }
 
 hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, hipStream_t s) {
+    if (mode == 5) return launch_conv_hl(a, out_f32, cfg, s);
     if (mode == 0) return conv_igemm_launch_f32(a, cfg, s);
     if (mode == 2) return conv_igemm_launch_split(a, 0, cfg, s);
     if (mode == 3) return conv_igemm_launch_split(a, 1, cfg, s);  // f32 tensors, f16 MFMA + fp8 MX MFMA for the cross terms

@@ -145,6 +145,7 @@ int32_t talloc(infur_ctx* c, int h, int w, int ch, int es, Tensor* t) {
     RETIF(pool_acquire(c, t->bytes(), &slot));
     t->slot = slot;
     t->p = c->pool[slot].p;
+    t->lo = es == 3 ? (uint8_t*)t->p + hl_lo_offset(t->elems()) : nullptr;
     return INFUR_OK;
 }
 
@@ -155,7 +156,9 @@ inline bool ctx_f16(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_D
 inline bool ctx_fp8x(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F32_SPLIT_FP8; }
 inline int ctx_mode(const infur_ctx* c) { return ctx_fp8x(c) ? (int)INFUR_DTYPE_F32_SPLIT : (int)c->opt.compute_dtype; }
 inline int conv_mode(const infur_ctx* c) { return ctx_fp8x(c) ? 3 : ctx_mode(c); }
-inline int act_es(const infur_ctx* c) { return ctx_f16(c) ? 2 : 4; }
+// INFUR_DTYPE_F16_HL (= conv mode 5): three-byte tensors (f16 hi + e5m2 lo planes), conv_hl.hip
+inline bool ctx_hl(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F16_HL; }
+inline int act_es(const infur_ctx* c) { return ctx_f16(c) ? 2 : (ctx_hl(c) ? 3 : 4); }
 
 // ---- roctx ranges ----
 // The reference wraps its stages in `tracing` spans / events (infur/src/main.rs:18-24, RUST_LOG); here INFUR_ROCTX=1 makes every
@@ -337,6 +340,7 @@ inline int wino_planes(const infur_ctx* c) { return (wino_mt(c) + 2) * (wino_mt(
 bool wino_eligible(const infur_ctx* c, const ConvLayer& L) {
     if (ctx_f16(c) || L.k != 3 || L.stride != 1 || L.pad != L.dil) return false;
     const uint32_t thr = c->opt.winograd_min_cin ? c->opt.winograd_min_cin : 128u;  // measured: 128 beats 256 (+1.4 %) and 64
+    if (ctx_hl(c) && ((L.cin % 128) != 0 || (L.cout % 128) != 0)) return false;  // (the three-byte transforms work on 128-channel groups)
     return thr != 0xFFFFFFFFu && (uint32_t)L.cin >= thr && (L.cin % 32) == 0 && (L.cout % 4) == 0;
 }
 
@@ -390,8 +394,34 @@ static UpQuant head_quant(const infur_ctx* c, int k) {
 // INFUR_DTYPE_F32_SPLIT: scale every conv's GEMM weights (and Winograd-domain weights) by the power of
 // two that puts max |w| in [2^13, 2^14) -- lo = w - hi then stays a normal f16 for all weights within
 // 2^-16 of the largest -- and replace them in place by (hi, lo) f16 pairs.  The stem is not a GEMM.
+// INFUR_DTYPE_F16_HL takes the same route with a different last step: the scaled tensor becomes an f16 hi plane (in place of the
+// f32 tensor) and an e5m2 lo plane behind it (launch_hl_pack_weights through a scratch buffer: the planes overlap their source).
 int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
     const size_t n = g.size();
+    const bool hl = ctx_hl(c);
+    struct Scratch {
+        void* p = nullptr;
+        ~Scratch() { if (p) (void)hipFree(p); }
+    } scratch;
+    if (hl) {
+        size_t most = 0;
+        for (const ConvLayer& L : g) {
+            most = std::max(most, (size_t)L.cout * L.cin * L.k * L.k);
+            if (L.d_u) most = std::max(most, (size_t)wino_planes(c) * L.cout * L.cin);
+        }
+        HIPCHK(c, hipMalloc(&scratch.p, hl_tensor_bytes(most)));
+    }
+    // f32 [planes][per] at `w`, plane p scaled by sc[p] -> hi planes at w, lo planes at w + hl_lo_offset(planes * per); *lo_out = the lo base
+    auto hl_pack = [&](float* w, size_t planes, size_t per, const float* sc, void** lo_out) -> int32_t {
+        const size_t tot = planes * per;
+        uint8_t* t_hi = (uint8_t*)scratch.p;
+        uint8_t* t_lo = t_hi + hl_lo_offset(tot);
+        for (size_t pl = 0; pl < planes; pl++)
+            HIPCHK(c, launch_hl_pack_weights(w + pl * per, per, sc[pl], t_hi + pl * per * 2, t_lo + pl * per, c->stream));
+        HIPCHK(c, hipMemcpyAsync(w, t_hi, hl_tensor_bytes(tot), hipMemcpyDeviceToDevice, c->stream));
+        *lo_out = (uint8_t*)w + hl_lo_offset(tot);
+        return INFUR_OK;
+    };
     const size_t P = (size_t)wino_planes(c);
     // per conv: [0] max |w|, [1] max |conv3 ++ downsample matrix|, [2 .. 2 + P) max |U| of every Winograd plane
     const size_t per = 2 + P;
@@ -420,7 +450,10 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         ConvLayer& L = g[i];
         L.w_scale = pow2_for(mx[per * i]);
         if (L.role == 's') continue;
-        HIPCHK(c, launch_split_weights((float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, L.w_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
+        if (hl)
+            RETIF(hl_pack((float*)L.d_w, 1, (size_t)L.cout * L.cin * L.k * L.k, &L.w_scale, &L.d_wl));
+        else
+            HIPCHK(c, launch_split_weights((float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, L.w_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         if (L.d_u) {
             // Every Winograd plane gets its OWN power-of-two scale: U = G g G^T mixes G's entries (1 ... 1/180 for F(6x6)), so the
             // planes' magnitudes span four decades before the weights' own spread; under one scale per layer the small planes
@@ -429,14 +462,16 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
             // multiplies its accumulators by d_uacc[p] = 1 / (activation scale * scale of plane p).
             const int mt = wino_mt(c);
             const float a_scale = mt == 6 ? 0.0625f : (mt == 4 ? 0.125f : 1.0f);  // = split_wino_scale(mt)
-            std::vector<float> acc(P);
+            std::vector<float> acc(P), scs(P);
             float smin = 0.f;
             for (size_t pl = 0; pl < P; pl++) {
                 const float sc = pow2_for(mx[per * i + 2 + pl]);
+                scs[pl] = sc;
                 acc[pl] = 1.0f / (a_scale * sc);
                 if (pl == 0 || sc < smin) smin = sc;
-                HIPCHK(c, launch_split_weights(L.d_u + pl * (size_t)L.cout * L.cin, (size_t)L.cout * L.cin, sc, ctx_fp8x(c) ? 1 : 0, c->stream));
+                if (!hl) HIPCHK(c, launch_split_weights(L.d_u + pl * (size_t)L.cout * L.cin, (size_t)L.cout * L.cin, sc, ctx_fp8x(c) ? 1 : 0, c->stream));
             }
+            if (hl) RETIF(hl_pack(L.d_u, P, (size_t)L.cout * L.cin, scs.data(), &L.d_ul));
             L.u_scale = smin;
             HIPCHK(c, hipMemcpyAsync(L.d_uacc, acc.data(), P * sizeof(float), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));  // (acc goes out of scope)
@@ -518,6 +553,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         ConvLayer& L = g[i];
         const ConvLayer& D = g[i + 1];
         if (L.role != '3' || D.role != 'd') continue;
+        if (ctx_hl(c)) continue;  // (the three-byte mode runs the downsample branch as its own launch + residual)
         const size_t es = ctx_f16(c) ? 2 : 4;
         L.d_wcat = (uint8_t*)d_weights + off;
         off += align_up((size_t)L.cout * (L.cin + D.cin) * 4, 256);
@@ -534,7 +570,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         off += align_up((size_t)L.cout * L.cin * 2, 256);
         HIPCHK(c, launch_b2b_pack_w3(L.d_w, L.d_w3i, L.cin, c->stream));
     }
-    if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT) RETIF(split_weights(c, g));
+    if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT || ctx_hl(c)) RETIF(split_weights(c, g));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     model_free(c);  // the old model goes only now
     c->d_weights = d_weights;
@@ -583,6 +619,7 @@ struct EventPair {  // the tuner's two events, released on every return path
 
 int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cfg) {
     *cfg = conv_igemm_default_config(a);
+    if (mode == 5 && !conv_igemm_config_valid(a, *cfg, mode, out_f32)) *cfg = 0;  // (128 x 128: valid for every mode-5 shape)
     // test hook: INFUR_CONV_CFG=<k> forces configuration k wherever it is a candidate
     static const int forced = getenv("INFUR_CONV_CFG") ? atoi(getenv("INFUR_CONV_CFG")) : -1;
     if (forced >= 0) {
@@ -661,6 +698,7 @@ ConvArgs conv_args(const ConvLayer& L, const Tensor& in, const Tensor* res, cons
     a.in = in.p; a.wt = L.d_w; a.bias = L.d_b; a.res = res ? res->p : nullptr; a.out = out.p;
     a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = out.h; a.OW = out.w; a.Cout = L.cout;
     a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = L.relu ? 1 : 0;
+    a.in_lo = in.lo; a.wt_lo = L.d_wl; a.res_lo = res ? res->lo : nullptr; a.out_lo = out.lo;  // (three-byte mode; null otherwise)
     return a;
 }
 
@@ -668,8 +706,44 @@ ConvArgs conv_args(const ConvLayer& L, const Tensor& in, const Tensor* res, cons
 int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, Tensor* out) {
     const int oh = conv_out(in.h, L.k, L.stride, L.pad, L.dil), ow = conv_out(in.w, L.k, L.stride, L.pad, L.dil);
     const int mode = ctx_mode(c);
-    const int out_f32 = (mode != 1 || L.role == 'c') ? 1 : 0;  // the logits leave the conv stack in f32
-    RETIF(talloc(c, oh, ow, L.cout, out_f32 ? 4 : 2, out));
+    const bool hl = ctx_hl(c);
+    const int out_f32 = ((mode != 1 && !hl) || L.role == 'c') ? 1 : 0;  // the logits leave the conv stack in f32
+    RETIF(talloc(c, oh, ow, L.cout, out_f32 ? 4 : (hl ? 3 : 2), out));
+    if (L.d_u && !res && hl) {
+        // three-byte mode: V and the conv output are hi / lo planes, the Winograd-domain product M stays f32
+        const int mt = wino_mt(c), P = wino_planes(c);
+        const int T = wino_num_tiles(in.h, in.w, L.dil, mt);
+        Tensor V, M;
+        RETIF(talloc(c, P, T, in.c, 3, &V));
+        RETIF(talloc(c, P, T, L.cout, 4, &M));
+        const double direct = 2.0 * oh * ow * (double)L.cout * L.cin * 9.0;
+        {
+            ProfScope ps(c, L.name + "/in", "wino_input_hl", 0, (double)in.elems() * 3 + (double)V.elems() * 3, 0.0);
+            HIPCHK(c, launch_wino_input_hl(in.p, in.lo, in.h, in.w, in.c, L.dil, mt, split_wino_scale(mt), V.p, V.lo, c->stream));
+        }
+        ConvArgs g;
+        g.in = V.p; g.in_lo = V.lo; g.wt = L.d_u; g.wt_lo = L.d_ul; g.bias = nullptr; g.res = nullptr; g.out = M.p;
+        g.H = 1; g.W = T; g.Cin = in.c; g.OH = 1; g.OW = T; g.Cout = L.cout;
+        g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
+        g.batch = P;
+        g.in_bs = (size_t)T * in.c * 2; g.wt_bs = (size_t)L.cout * L.cin * 2; g.out_bs = (size_t)T * L.cout * 4;
+        g.acc_scale_b = L.d_uacc;
+        int gcfg = -1;
+        RETIF(pick_cfg(c, g, 5, 1, &gcfg));
+        {
+            ProfScope ps(c, L.name, conv_igemm_config_name(gcfg, 5), 2.0 * P * T * (double)L.cout * L.cin,
+                         (double)V.elems() * 3 + (double)M.bytes() + (double)P * L.cout * L.cin * 3, direct);
+            HIPCHK(c, launch_conv_igemm(g, 5, 1, gcfg, c->stream));
+        }
+        pool_release(c, V);
+        {
+            ProfScope ps(c, L.name + "/out", "wino_output_hl", 0, (double)M.bytes() + (double)out->elems() * 3, 0.0);
+            HIPCHK(c, launch_wino_output_hl((const float*)M.p, oh, ow, L.cout, L.dil, mt, L.d_b, L.relu ? 1 : 0, out->p, out->lo, c->stream));
+        }
+        pool_release(c, M);
+        if (c->opt.keep_activations) c->kept.push_back(*out);
+        return INFUR_OK;
+    }
     if (L.d_u && !res) {
         // Winograd F(mt x mt, 3x3): input transform -> (mt+2)^2 batched GEMMs -> output transform (+bias, ReLU)
         const int mt = wino_mt(c), P = wino_planes(c);
@@ -719,6 +793,7 @@ int32_t run_conv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tenso
         a.acc_scale = 1.0f / (a.a_scale * L.w_scale);
         a.amax = L.role == 'c' ? nullptr : c->d_range;  // the logits feed no GEMM
     }
+    if (hl) a.acc_scale = 1.0f / L.w_scale;  // (activations are stored unscaled: e5m2 lo planes share f16's exponent range)
     int cfg = -1;
     RETIF(pick_cfg(c, a, conv_mode(c), out_f32, &cfg));
     {
@@ -1250,23 +1325,32 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
         RETIF(talloc(c, ph, pw, 64, act_es(c), &x));
         const void* wimg = nullptr;
         if (ctx_mode(c) == INFUR_DTYPE_F16) RETIF(stem16_image(c, (const float*)stem.d_w, 1.0f, 0, &wimg));
-        if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT) RETIF(stem16_image(c, (const float*)stem.d_w, stem.w_scale, 1, &wimg));
+        if (ctx_mode(c) == INFUR_DTYPE_F32_SPLIT || ctx_hl(c)) RETIF(stem16_image(c, (const float*)stem.d_w, stem.w_scale, 1, &wimg));
         ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes(),
                      2.0 * sh * sw * 64 * 147);
         // exact f32 MFMA in the f32 mode; in the f16-rate modes the stem runs on the f16 matrix cores as the conv stack does
         HIPCHK(c, launch_stem_pool(d_bgr, h, w, (const float*)stem.d_w, wimg, stem.d_b, stem_lut(c), x.p, ctx_mode(c), sh, sw, ph, pw,
-                                   kSplitActScale, stem.w_scale, c->d_range, c->stream));
+                                   kSplitActScale, stem.w_scale, c->d_range, c->stream));  // (mode 5: hi / lo planes, x.lo = x.p + hl_lo_offset)
     } else {
+        const int es01 = ctx_hl(c) ? 4 : act_es(c);  // three-byte mode: stem and pool in f32 (the exact f32 stem), converted below
         {
-            RETIF(talloc(c, sh, sw, 64, act_es(c), &s));
+            RETIF(talloc(c, sh, sw, 64, es01, &s));
             ProfScope ps(c, stem.name, "stem_conv7x7", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)s.bytes());
             HIPCHK(c, launch_stem_conv7x7(d_bgr, h, w, (const float*)stem.d_w, stem.d_b, stem_lut(c), s.p, ctx_f16(c) ? 1 : 0, sh, sw, c->stream));
         }
         if (c->opt.keep_activations) c->kept.push_back(s);
+        Tensor xp;
         {
-            RETIF(talloc(c, ph, pw, 64, act_es(c), &x));
-            ProfScope ps(c, "backbone.maxpool", "maxpool3x3s2", 0, (double)s.bytes() + (double)x.bytes());
-            HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, x.p, ctx_f16(c) ? 1 : 0, ph, pw, c->d_range, c->stream));
+            RETIF(talloc(c, ph, pw, 64, es01, &xp));
+            ProfScope ps(c, "backbone.maxpool", "maxpool3x3s2", 0, (double)s.bytes() + (double)xp.bytes());
+            HIPCHK(c, launch_maxpool3x3s2(s.p, s.h, s.w, 64, xp.p, ctx_f16(c) ? 1 : 0, ph, pw, c->d_range, c->stream));
+        }
+        if (ctx_hl(c)) {
+            RETIF(talloc(c, ph, pw, 64, 3, &x));
+            HIPCHK(c, launch_hl_from_f32((const float*)xp.p, xp.elems(), x.p, x.lo, c->stream));
+            pool_release(c, xp);
+        } else {
+            x = xp;
         }
         pool_release(c, s);
     }
@@ -1434,7 +1518,7 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
             if (opts->struct_size != sizeof(infur_options)) return INFUR_E_INVALID_ARG;
             o = *opts;
         }
-        if (o.compute_dtype > INFUR_DTYPE_F32_SPLIT_FP8) return INFUR_E_INVALID_ARG;
+        if (o.compute_dtype > INFUR_DTYPE_F32_SPLIT_FP8 && o.compute_dtype != INFUR_DTYPE_F16_HL) return INFUR_E_INVALID_ARG;
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || o.device < 0 || o.device >= n) return INFUR_E_HIP;
         if (hipSetDevice(o.device) != hipSuccess) return INFUR_E_HIP;
@@ -1872,6 +1956,8 @@ int32_t infur_debug_read_activation(infur_ctx* c, uint32_t index, float* host, s
         RETIF(ensure(c, c->st_f32a, t.elems() * 4));
         if (t.es == 1)  // a quantised activation: the byte values
             HIPCHK(c, launch_u8_nhwc_to_planar((const uint8_t*)t.p, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
+        else if (t.es == 3)  // three-byte format: hi + lo / kHlLoScale
+            HIPCHK(c, launch_hl_nhwc_to_planar(t.p, t.lo, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
         else
             HIPCHK(c, launch_nhwc_to_planar(t.p, t.es == 2, t.h, t.w, t.c, (float*)c->st_f32a.p, c->stream));
         HIPCHK(c, hipMemcpyAsync(host, c->st_f32a.p, t.elems() * 4, hipMemcpyDeviceToHost, c->stream));

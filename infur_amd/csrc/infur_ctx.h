@@ -27,9 +27,11 @@ struct Tensor {  // NHWC activation (f32 or f16) living in the pool
     void* p = nullptr;
     int h = 0, w = 0, c = 0;
     int slot = -1;
-    int es = 4;  // element size: 4 = f32, 2 = f16
+    int es = 4;  // element size: 4 = f32, 2 = f16, 1 = u8 (quantised), 3 = three-byte format: f16 hi plane at p, e5m2 lo plane at lo
+    void* lo = nullptr;
     size_t elems() const { return (size_t)h * w * c; }
-    size_t bytes() const { return elems() * (size_t)es; }
+    // (es == 3: the lo plane starts at the next 256-byte boundary behind the hi plane -- kernels.h: hl_lo_offset)
+    size_t bytes() const { return es == 3 ? ((elems() * 2 + 255) & ~(size_t)255) + ((elems() + 255) & ~(size_t)255) : elems() * (size_t)es; }
 };
 
 struct ConvLayer {
@@ -43,6 +45,9 @@ struct ConvLayer {
     // INFUR_DTYPE_F32_SPLIT: d_w / d_u hold f16 (hi, lo) pairs of w * w_scale / u * u_scale (powers of two)
     float w_scale = 1.0f, u_scale = 1.0f;
     float* d_uacc = nullptr;  // split modes: per Winograd plane, 1 / (activation scale * that plane's weight scale)
+    // INFUR_DTYPE_F16_HL: d_w / d_u hold the f16 hi planes of w * w_scale / u * (plane scale), d_wl / d_ul the e5m2 lo planes
+    void* d_wl = nullptr;
+    void* d_ul = nullptr;
     // conv3 of a stage's first block: its weights and the downsample branch's side by side ([cout][cin + ds.cin],
     // context dtype), the two biases summed -- the two-source GEMM of run_conv_dual
     void* d_wcat = nullptr;
@@ -71,7 +76,7 @@ struct ConvLayer {
     template <class F>
     void map_device_pointers(F&& f) {
         auto ap = [&](auto*& p) { p = static_cast<std::remove_reference_t<decltype(p)>>(f((void*)p)); };
-        ap(d_w); ap(d_b); ap(d_u); ap(d_uacc); ap(d_wcat); ap(d_bcat); ap(d_w3i);
+        ap(d_w); ap(d_b); ap(d_u); ap(d_uacc); ap(d_wl); ap(d_ul); ap(d_wcat); ap(d_bcat); ap(d_w3i);
         ap(d_qbias); ap(d_qmult); ap(d_w2); ap(d_qbias2); ap(d_qmult2);
     }
 };

@@ -52,6 +52,12 @@ struct ConvArgs {
     // Requires KH = KW = 1, pad = 0, stride = 1; wt rows are Cin + Cin2 long; OH x OW = ceil(H2/stride2) x ...
     const void* in2 = nullptr;  // [H2][W2][Cin2]
     int H2 = 0, W2 = 0, Cin2 = 0, stride2 = 1;
+    // mode 5 (INFUR_DTYPE_F16_HL, conv_hl.hip): every tensor is an f16 hi plane (in / wt / res / out above) plus an e5m2 lo plane of
+    // the same shape (hl_format.h); batched use: lo plane b starts at base + b * (in_bs / 2).  out_f32 launches write plain f32.
+    const void* in_lo = nullptr;
+    const void* wt_lo = nullptr;
+    const void* res_lo = nullptr;
+    void* out_lo = nullptr;
 };
 
 // conv as implicit GEMM on the matrix cores.  mode 0: f32 operands on the f32 MFMA (Cin % 32 == 0);
@@ -64,12 +70,20 @@ struct ConvArgs {
 // mode 4: quantised (ConvArgs::q_*): u8 NHWC activations, s8 OHWI weights (Cin % 128 == 0), output u8 or (out_f32) dequantised f32.
 // cfg: tile configuration index (conv_igemm_num_configs), -1 = built-in heuristic.  Every
 // configuration produces bit-identical results; only the speed differs.
+// mode 5: three-byte tensors (f16 hi + e5m2 lo planes, ConvArgs::*_lo), hi * hi on the f16 MFMA + both cross terms on the bf8 MX MFMA,
+// every operand staged by LDS-DMA (conv_hl.hip); Cin % 32 == 0; configurations 11, 0, 6, 5 (their tile shapes).
 hipError_t launch_conv_igemm(const ConvArgs& a, int mode, int out_f32, int cfg, hipStream_t s);
 int conv_igemm_num_configs();
 int conv_igemm_config_tile_area(int cfg);  // BM * BN of a configuration (operand re-reads fall with it)
 int conv_igemm_default_config(const ConvArgs& a);
 bool conv_igemm_config_valid(const ConvArgs& a, int cfg, int mode, int out_f32);
 const char* conv_igemm_config_name(int cfg, int mode);
+
+// mode 5 (conv_hl.hip)
+bool conv_hl_config_valid(const ConvArgs& a, int cfg, int out_f32);
+hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s);
+// weights of mode 5, one-off at load: f32 [n] (kernel K order) * scale -> f16 hi [n], e5m2 lo [n] (n % 4 == 0)
+hipError_t launch_hl_pack_weights(const float* w, size_t n, float scale, void* hi, void* lo, hipStream_t s);
 
 // 1x1 convolution with Cin in {64, 128, 256}, f16 operands (mode 1), f16 output: the activation tile stays in registers
 // while the workgroup walks all N tiles (conv1x1_areg.hip).  Reached through launch_conv_igemm as one more configuration.
@@ -117,6 +131,19 @@ hipError_t launch_wino_input(const float* in, int H, int W, int C, int d, int mt
 hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int mt, const float* bias, int relu,
                               float* out, unsigned* amax, hipStream_t s);
 hipError_t launch_wino_weights(const float* w_oihw, int O, int I, int mt, float* U, hipStream_t s);
+// the same transforms on three-byte tensors (mode 5; C, Cout % 128 == 0): input hi / lo planes -> V * v_scale as hi / lo planes
+// [(mt+2)^2][T][C]; f32 M -> the conv's output as hi / lo planes
+hipError_t launch_wino_input_hl(const void* in_hi, const void* in_lo, int H, int W, int C, int d, int mt, float v_scale, void* V_hi, void* V_lo,
+                                hipStream_t s);
+hipError_t launch_wino_output_hl(const float* M, int H, int W, int Cout, int d, int mt, const float* bias, int relu, void* out_hi, void* out_lo,
+                                 hipStream_t s);
+
+// three-byte tensors (hl_format.h): the lo plane of an [elems] tensor starts hl_lo_offset(elems) bytes after the hi plane
+__host__ __device__ inline size_t hl_lo_offset(size_t elems) { return (elems * 2 + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t hl_tensor_bytes(size_t elems) { return hl_lo_offset(elems) + ((elems + 255) & ~(size_t)255); }
+// f32 [n] -> hi / lo planes (n % 8 == 0); NHWC hi / lo planes -> planar f32 [C][H][W] (read-back)
+hipError_t launch_hl_from_f32(const float* in, size_t n, void* hi, void* lo, hipStream_t s);
+hipError_t launch_hl_nhwc_to_planar(const void* hi, const void* lo, int H, int W, int C, float* out, hipStream_t s);
 
 // stem: packed BGR u8 -> (LUT normalise, BGR->RGB) -> conv 7x7/2 pad 3 (3->64) + bias + ReLU,
 // NHWC out (f32, or f16 when f16 != 0; the arithmetic is f32 either way).

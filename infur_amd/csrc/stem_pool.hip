@@ -9,6 +9,7 @@
 //  * weight repacks (one-off at model load).
 #include <cstdlib>
 
+#include "hl_format.h"
 #include "kernels.h"
 #include "qepilogue.h"
 
@@ -245,6 +246,17 @@ __device__ __forceinline__ void stem_stage_and_pool(float* smem, const f32x16s (
             unsigned char* o = reinterpret_cast<unsigned char*>(out) + ((size_t)py * PW + pxo) * (size_t)q.cstride + c4 * 4;
             *reinterpret_cast<unsigned*>(o) = w;
             if (q.cstride == 128) *reinterpret_cast<unsigned*>(o + 64) = 0u;  // channel padding
+            continue;
+        }
+        if constexpr (sizeof(OutT) == 3) {  // HlTag: hi / lo planes of the three-byte format (hl_format.h), lo plane behind the hi plane
+            const float x4[4] = {m.x, m.y, m.z, m.w};
+            hl_f16x4 hv;
+            unsigned lv;
+            hl_split4(x4, hv, lv);
+            const size_t e = ((size_t)py * PW + pxo) * 64 + c4 * 4;
+            *reinterpret_cast<hl_f16x4*>(reinterpret_cast<_Float16*>(out) + e) = hv;
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(out) + hl_lo_offset((size_t)PH * PW * 64) + e) = lv;
+            vmax = fmaxf(vmax, fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w)));
             continue;
         }
         OutT* o = out + ((size_t)py * PW + pxo) * 64 + c4 * 4;
@@ -570,12 +582,15 @@ hipError_t launch_stem_pool(const uint8_t* bgr, int H, int W, const float* wt, c
     dim3 grid((PW + SP_PC - 1) / SP_PC, (PH + SP_PR - 1) / SP_PR);
     static const int abl = getenv("INFUR_STEM_ABL") ? atoi(getenv("INFUR_STEM_ABL")) : 0;
     static const int exact = getenv("INFUR_STEM_F32") ? atoi(getenv("INFUR_STEM_F32")) : 0;  // measurement hook: f32 MFMA stem in every mode
-    if ((mode == 1 || mode == 2) && !exact && !wimg) return hipErrorInvalidValue;
+    if ((mode == 1 || mode == 2 || mode == 5) && !(exact && mode != 5) && !wimg) return hipErrorInvalidValue;
     if (mode == 1 && !exact)
         hipLaunchKernelGGL((stem_pool16_kernel<_Float16, false>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (_Float16*)out, SH, SW, PH,
                            PW, 1.0f, 1.0f, 1.0f, amax, (const u32x4s*)wimg);
     else if (mode == 2 && !exact)
         hipLaunchKernelGGL((stem_pool16_kernel<float, true>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (float*)out, SH, SW, PH, PW,
+                           a_scale, w_scale, 1.0f / (a_scale * w_scale), amax, (const u32x4s*)wimg);
+    else if (mode == 5)  // the split arithmetic (three f16 MFMAs per product: 10 GFLOP of the frame), three-byte output
+        hipLaunchKernelGGL((stem_pool16_kernel<HlTag, true>), grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (HlTag*)out, SH, SW, PH, PW,
                            a_scale, w_scale, 1.0f / (a_scale * w_scale), amax, (const u32x4s*)wimg);
     else if (mode == 1)
         hipLaunchKernelGGL(stem_pool_kernel<_Float16>, grid, dim3(256), 0, s, bgr, H, W, wt, bias, lut, (_Float16*)out, SH, SW, PH, PW, amax);

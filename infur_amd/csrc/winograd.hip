@@ -19,6 +19,7 @@
 // (ry, rx, ty, tx) and its (m+2)^2 input patch sits at rows d*(m*ty - 1 + i) + ry.
 #include <cstdlib>
 
+#include "hl_format.h"
 #include "kernels.h"
 
 namespace infur {
@@ -362,6 +363,136 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ---- the two transforms on THREE-BYTE tensors (INFUR_DTYPE_F16_HL, hl_format.h) ----
+// Same two-pass LDS scheme as above with 8 channels per lane: a lane's accesses are 16 bytes of the f16 hi plane + 8 bytes of the
+// e5m2 lo plane (16 lanes = 256 + 128 contiguous bytes of 128 channels).  A workgroup = one tile x 128 channels, 8 groups of 16
+// lanes.  The input transform reads x = hi + lo / kHlLoScale, transforms in f32 and writes V * v_scale as hi / lo planes
+// [(mt+2)^2][T][C] for the batched HL GEMM (conv_hl.hip); the output transform reads that GEMM's f32 result and writes the conv's
+// output as hi / lo planes.  Same 1-D functions in the same order as the f32 forms.
+typedef float f32x8w __attribute__((ext_vector_type(8)));
+constexpr int WH_L = 16;  // lanes per group = 128 channels
+
+__device__ __forceinline__ f32x8w hl_load8(const _Float16* hi, const unsigned char* lo, size_t e) {
+    float x[8];
+    hl_join8(*reinterpret_cast<const hl_f16x8*>(hi + e), *reinterpret_cast<const hl_u32x2*>(lo + e), x);
+    f32x8w v;
+#pragma unroll
+    for (int t = 0; t < 8; t++) v[t] = x[t];
+    return v;
+}
+__device__ __forceinline__ void hl_store8(_Float16* hi, unsigned char* lo, size_t e, const f32x8w v) {
+    float x[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) x[t] = v[t];
+    hl_f16x8 hv;
+    hl_u32x2 lv;
+    hl_split8(x, hv, lv);
+    *reinterpret_cast<hl_f16x8*>(hi + e) = hv;
+    *reinterpret_cast<hl_u32x2*>(lo + e) = lv;
+}
+
+template <int MT>
+__global__ void __launch_bounds__(128)
+    wino_input_hl_kernel(const _Float16* __restrict__ in_hi, const unsigned char* __restrict__ in_lo, WinoGeom g, int C, int T, float v_scale,
+                         _Float16* __restrict__ V_hi, unsigned char* __restrict__ V_lo) {
+    constexpr int AL = MT + 2;
+    static_assert(AL <= 8, "one row / column per 16-lane group of a 128-thread workgroup");
+    __shared__ f32x8w lds[AL * AL * WH_L];
+    hl_set_fp16_ovfl();
+    const int tid = threadIdx.x, q = tid >> 4, cvl = tid & 15;
+    const int cgroups = C / (8 * WH_L);
+    const size_t units = (size_t)T * cgroups;
+    const size_t plane = (size_t)T * C;
+    for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const int cg = (int)(u % cgroups), t = (int)(u / cgroups);
+        const int c0 = cg * 8 * WH_L + cvl * 8;
+        int ry, rx, ty, tx;
+        tile_coords(g, t, ry, rx, ty, tx);
+        if (q < AL) {
+            const int x = g.d * (MT * tx - 1 + q) + rx;
+            f32x8w d[AL], col[AL];
+#pragma unroll
+            for (int a = 0; a < AL; a++) {
+                const int y = g.d * (MT * ty - 1 + a) + ry;
+                f32x8w v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) v = hl_load8(in_hi, in_lo, ((size_t)y * g.W + x) * C + c0);
+                d[a] = v;
+            }
+            bt_1d<MT, 1, 1>(d, col);
+#pragma unroll
+            for (int a = 0; a < AL; a++) lds[(a * AL + q) * WH_L + cvl] = col[a];
+        }
+        __syncthreads();
+        if (q < AL) {
+            f32x8w rin[AL], row[AL];
+#pragma unroll
+            for (int b = 0; b < AL; b++) rin[b] = lds[(q * AL + b) * WH_L + cvl];
+            bt_1d<MT, 1>(rin, row);
+            const size_t o = (size_t)t * C + c0;
+#pragma unroll
+            for (int b = 0; b < AL; b++) hl_store8(V_hi, V_lo, o + (size_t)(q * AL + b) * plane, row[b] * v_scale);
+        }
+        __syncthreads();
+    }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(128)
+    wino_output_hl_kernel(const float* __restrict__ M, WinoGeom g, int Cout, int T, const float* __restrict__ bias, int relu,
+                          _Float16* __restrict__ out_hi, unsigned char* __restrict__ out_lo) {
+    constexpr int AL = MT + 2;
+    static_assert(AL <= 8, "one row / column per 16-lane group of a 128-thread workgroup");
+    __shared__ f32x8w lds[MT * AL * WH_L];
+    hl_set_fp16_ovfl();
+    const int tid = threadIdx.x, q = tid >> 4, cvl = tid & 15;
+    const int cgroups = Cout / (8 * WH_L);
+    const size_t units = (size_t)T * cgroups;
+    const size_t plane = (size_t)T * Cout;
+    for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const int cg = (int)(u % cgroups), t = (int)(u / cgroups);
+        const int n0 = cg * 8 * WH_L + cvl * 8;
+        int ry, rx, ty, tx;
+        tile_coords(g, t, ry, rx, ty, tx);
+        if (q < AL) {
+            const float* mp = M + (size_t)t * Cout + n0;
+            f32x8w col[AL], s[MT];
+#pragma unroll
+            for (int a = 0; a < AL; a++) {
+                const f32x4w v0 = *reinterpret_cast<const f32x4w*>(mp + (size_t)(a * AL + q) * plane);
+                const f32x4w v1 = *reinterpret_cast<const f32x4w*>(mp + (size_t)(a * AL + q) * plane + 4);
+                col[a] = f32x8w{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            }
+            at_1d<MT, 1, 1>(col, s);
+#pragma unroll
+            for (int a = 0; a < MT; a++) lds[(a * AL + q) * WH_L + cvl] = s[a];
+        }
+        __syncthreads();
+        if (q < MT) {
+            f32x8w rin[AL], yv[MT];
+#pragma unroll
+            for (int b = 0; b < AL; b++) rin[b] = lds[(q * AL + b) * WH_L + cvl];
+            at_1d<MT, 1>(rin, yv);
+            const f32x4w b0 = *reinterpret_cast<const f32x4w*>(bias + n0), b1 = *reinterpret_cast<const f32x4w*>(bias + n0 + 4);
+            const f32x8w bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            const int y = g.d * (MT * ty + q) + ry;
+            if (y < g.H) {
+#pragma unroll
+                for (int b = 0; b < MT; b++) {
+                    const int x = g.d * (MT * tx + b) + rx;
+                    if (x >= g.W) continue;
+                    f32x8w v = yv[b] + bv;
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    hl_store8(out_hi, out_lo, ((size_t)y * g.W + x) * Cout + n0, v);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- weight transform: U[xi][o][c] = (G g G^T)[xi],  g = w[o][c][3][3] (OIHW) ----
 template <int MT>
 __global__ void wino_weight_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ U) {
@@ -465,6 +596,42 @@ hipError_t launch_wino_output(const float* M, int H, int W, int Cout, int d, int
         hipLaunchKernelGGL((wino_output_kernel<4, f32x4w>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
     else
         hipLaunchKernelGGL((wino_output_kernel<4, f32x2>), dim3(blocks), dim3(256), 0, s, M, g, Cout, T, bias, relu, out, amax);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino_input_hl(const void* in_hi, const void* in_lo, int H, int W, int C, int d, int mt, float v_scale, void* V_hi, void* V_lo,
+                                hipStream_t s) {
+    if (C % (8 * WH_L) != 0) return hipErrorInvalidValue;
+    const WinoGeom g = geom(H, W, d, mt);
+    const int T = d * d * g.TY * g.TX;
+    const dim3 grid(grid_units((size_t)T * (C / (8 * WH_L))));
+    const _Float16* ih = static_cast<const _Float16*>(in_hi);
+    const unsigned char* il = static_cast<const unsigned char*>(in_lo);
+    _Float16* vh = static_cast<_Float16*>(V_hi);
+    unsigned char* vl = static_cast<unsigned char*>(V_lo);
+    if (mt == 6)
+        hipLaunchKernelGGL(wino_input_hl_kernel<6>, grid, dim3(128), 0, s, ih, il, g, C, T, v_scale, vh, vl);
+    else if (mt == 4)
+        hipLaunchKernelGGL(wino_input_hl_kernel<4>, grid, dim3(128), 0, s, ih, il, g, C, T, v_scale, vh, vl);
+    else
+        hipLaunchKernelGGL(wino_input_hl_kernel<2>, grid, dim3(128), 0, s, ih, il, g, C, T, v_scale, vh, vl);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino_output_hl(const float* M, int H, int W, int Cout, int d, int mt, const float* bias, int relu, void* out_hi, void* out_lo,
+                                 hipStream_t s) {
+    if (Cout % (8 * WH_L) != 0) return hipErrorInvalidValue;
+    const WinoGeom g = geom(H, W, d, mt);
+    const int T = d * d * g.TY * g.TX;
+    const dim3 grid(grid_units((size_t)T * (Cout / (8 * WH_L))));
+    _Float16* oh = static_cast<_Float16*>(out_hi);
+    unsigned char* ol = static_cast<unsigned char*>(out_lo);
+    if (mt == 6)
+        hipLaunchKernelGGL(wino_output_hl_kernel<6>, grid, dim3(128), 0, s, M, g, Cout, T, bias, relu, oh, ol);
+    else if (mt == 4)
+        hipLaunchKernelGGL(wino_output_hl_kernel<4>, grid, dim3(128), 0, s, M, g, Cout, T, bias, relu, oh, ol);
+    else
+        hipLaunchKernelGGL(wino_output_hl_kernel<2>, grid, dim3(128), 0, s, M, g, Cout, T, bias, relu, oh, ol);
     return hipGetLastError();
 }
 

@@ -109,7 +109,8 @@ class Context:
         o = _lib.Options()
         L.infur_options_default(C.byref(o))
         o.device = device
-        o.compute_dtype = {"f32": _lib.DTYPE_F32, "f16": _lib.DTYPE_F16, "f32s": _lib.DTYPE_F32_SPLIT, "f32x": _lib.DTYPE_F32_SPLIT_FP8}[dtype]
+        o.compute_dtype = {"f32": _lib.DTYPE_F32, "f16": _lib.DTYPE_F16, "f32s": _lib.DTYPE_F32_SPLIT, "f32x": _lib.DTYPE_F32_SPLIT_FP8,
+                           "f16hl": _lib.DTYPE_F16_HL}[dtype]
         self.dtype = dtype
         o.compute_aux = 1 if compute_aux else 0
         o.profile = 1 if profile else 0
