@@ -68,8 +68,8 @@ __device__ __forceinline__ void hl_dma16(const u32x4r rsrc, const unsigned lds, 
 __host__ __device__ constexpr int hl_swz64(int row) { return (row >> 2) & 3; }
 __host__ __device__ constexpr int hl_swz32(int row) { return (row >> 3) & 1; }
 constexpr int hl_image_bytes(int bm, int bn) { return (bm + bn) * 96; }
-constexpr int hl_lds_bytes(int bm, int bn, int wm, int wn) {
-    const int operands = 3 * hl_image_bytes(bm, bn);
+constexpr int hl_lds_bytes(int bm, int bn, int wm, int wn, int nimg) {
+    const int operands = nimg * hl_image_bytes(bm, bn);
     const int staging = wm * wn * 32 * (bn / wn * 4 + 16);
     return operands > staging ? operands : staging;
 }
@@ -78,8 +78,16 @@ constexpr int hl_ceil_div(int a, int b) { return (a + b - 1) / b; }
 // top bytes of the four f16 in (d0, d1): [d0.b1, d0.b3, d1.b1, d1.b3]
 __device__ __forceinline__ int hl_top4(const unsigned d0, const unsigned d1) { return (int)__builtin_amdgcn_perm(d1, d0, 0x07050301u); }
 
-template <int BM, int BN, int WM, int WN, bool G1, bool OUTF32>
+// DUAL (with G1): the K loop runs over two activation tensors in turn (ConvArgs.in, then ConvArgs.in2 sampled with stride2) against
+// one weight matrix whose rows are the two 1x1 kernels side by side -- a bottleneck's conv3 and the downsample branch of a stage's
+// first block in one launch (conv_igemm_kernel.h: DUAL): the branch output is neither written nor re-read as a residual.
+// NIMG: LDS images in the ring.  3 = the DMA of step k + 2 in flight across the barrier of step k (eight waves, one workgroup per
+// CU).  2 = one step ahead: half-size tiles of FOUR waves with 128 x 64 wave tiles fit TWO independent workgroups per CU (72 KB
+// each, one wave per SIMD each) -- the epilogue of one overlaps the K loop of the other, which is what the output-bound 1x1
+// expansions (conv3: K = 256 / 512, a tile's epilogue moves as many bytes as its K loop ingests) are short of.
+template <int BM, int BN, int WM, int WN, bool G1, bool OUTF32, bool DUAL = false, int NIMG = 3>
 __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
+    static_assert(!DUAL || (G1 && !OUTF32), "DUAL is a form of the 1x1 GEMM addressing");
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int IMG = hl_image_bytes(BM, BN);
@@ -113,9 +121,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int M = a.OH * a.OW;
-    const int Ktot = a.KH * a.KW * a.Cin;
+    const int Ktot = DUAL ? a.Cin + a.Cin2 : a.KH * a.KW * a.Cin;
     const int cchunks = a.Cin / HL_KC;
-    const int ksteps = a.KH * a.KW * cchunks;
+    const int ksteps = DUAL ? cchunks + a.Cin2 / HL_KC : a.KH * a.KW * cchunks;
 
     // descriptors of the four planes (batched use: plane b of the hi tensor starts at b * in_bs, of the lo tensor at b * in_bs / 2)
     auto mk = [](const void* p, unsigned bytes) {
@@ -132,6 +140,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     const u32x4r al_v = mk(static_cast<const char*>(a.in_lo) + (size_t)bidx * (a.in_bs / 2), (unsigned)in_elems);
     const u32x4r bh_v = mk(static_cast<const char*>(a.wt) + (size_t)bidx * a.wt_bs, (unsigned)(wt_elems * 2));
     const u32x4r bl_v = mk(static_cast<const char*>(a.wt_lo) + (size_t)bidx * (a.wt_bs / 2), (unsigned)wt_elems);
+    const size_t in2_elems = DUAL ? (size_t)a.H2 * a.W2 * a.Cin2 : 0;
+    const u32x4r a2h_v = mk(DUAL ? a.in2 : a.in, (unsigned)(in2_elems * 2));
+    const u32x4r a2l_v = mk(DUAL ? a.in2_lo : a.in_lo, (unsigned)in2_elems);
     const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
 
     // per-lane source coordinates of the pieces this wave issues.  hi piece p: rows 16 p .. 16 p + 15, lane l = row l >> 2 at
@@ -153,6 +164,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         if constexpr (G1) {
             ah_y[i] = m < M ? (int)((unsigned)(oy * a.stride * a.W + ox * a.stride) * (unsigned)(a.Cin * 2) + ch) : (int)HL_OOB;
             ah_x[i] = 0;
+            if constexpr (DUAL)  // the same output pixel in the second tensor
+                ah_x[i] = m < M ? (int)((unsigned)(oy * a.stride2 * a.W2 + ox * a.stride2) * (unsigned)(a.Cin2 * 2) + ch) : (int)HL_OOB;
         } else {
             ah_y[i] = m < M ? oy * a.stride - a.pad : -0x100000;
             ah_x[i] = ox * a.stride - a.pad;
@@ -170,6 +183,8 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         if constexpr (G1) {
             al_y[i] = m < M ? (int)((unsigned)(oy * a.stride * a.W + ox * a.stride) * (unsigned)a.Cin + ch) : (int)HL_OOB;
             al_x[i] = 0;
+            if constexpr (DUAL)
+                al_x[i] = m < M ? (int)((unsigned)(oy * a.stride2 * a.W2 + ox * a.stride2) * (unsigned)a.Cin2 + ch) : (int)HL_OOB;
         } else {
             al_y[i] = m < M ? oy * a.stride - a.pad : -0x100000;
             al_x[i] = ox * a.stride - a.pad;
@@ -198,10 +213,18 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     auto sdst = [&](unsigned off) { return __builtin_amdgcn_readfirstlane(lds0 + ld_img + off); };
     auto load_a = [&]() {
         if constexpr (G1) {
+            if (DUAL && kl >= cchunks) {  // wave-uniform: the second tensor's K steps
+                const unsigned k2 = (unsigned)(kl - cchunks);
 #pragma unroll
-            for (int i = 0; i < I_AH; i++) hl_dma16(ah_v, sdst(ah_dst[i]), (unsigned)ah_y[i], (unsigned)kl * 64u);
+                for (int i = 0; i < I_AH; i++) hl_dma16(a2h_v, sdst(ah_dst[i]), (unsigned)ah_x[i], k2 * 64u);
 #pragma unroll
-            for (int i = 0; i < I_AL; i++) hl_dma16(al_v, sdst(al_dst[i]), (unsigned)al_y[i], (unsigned)kl * 32u);
+                for (int i = 0; i < I_AL; i++) hl_dma16(a2l_v, sdst(al_dst[i]), (unsigned)al_x[i], k2 * 32u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < I_AH; i++) hl_dma16(ah_v, sdst(ah_dst[i]), (unsigned)ah_y[i], (unsigned)kl * 64u);
+#pragma unroll
+                for (int i = 0; i < I_AL; i++) hl_dma16(al_v, sdst(al_dst[i]), (unsigned)al_y[i], (unsigned)kl * 32u);
+            }
         } else {
             const int dy = ky * a.dil, dx = kx * a.dil;
 #pragma unroll
@@ -235,7 +258,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         const int w2 = kx == a.KW;
         kx = w2 ? 0 : kx;
         ky += w2;
-        ld_img = ld_img + IMG == 3 * IMG ? 0u : ld_img + IMG;
+        ld_img = ld_img + IMG == NIMG * IMG ? 0u : ld_img + IMG;
     };
 
     f32x16 acc[TM][TN];
@@ -256,11 +279,11 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     const int b_hi1 = B_HI + (wn * TN * 32 + r) * 64 + (((2 * h + 1) ^ hl_swz64(r)) * 16);
     const int b_lo = B_LO + (wn * TN * 32 + r) * 32 + ((h ^ hl_swz32(r)) * 16);
 
-    // prologue: steps 0 and 1 into images 0 and 1
+    // prologue: steps 0 and 1 into images 0 and 1 (ring of two: step 0)
     load_a();
     load_b();
     load_next();
-    if (ksteps > 1) {
+    if (NIMG == 3 && ksteps > 1) {
         load_a();
         load_b();
         load_next();
@@ -270,10 +293,38 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     }
     __builtin_amdgcn_s_barrier();
 
+    // Residual prefetch (tiles with <= 64 accumulators per lane: room for the whole residual tile in registers): the loads go out at
+    // the start of the first K step that issues no DMA any more (ks = ksteps - 2) -- every DMA piece still in flight is then OLDER
+    // than they are, so the step-end wait becomes vmcnt(NRES) and the residual's HBM latency hides behind the last two steps
+    // instead of standing in front of every 32-row block of the epilogue (conv_igemm_kernel.h: RESPF, measured there: the epilogue
+    // of a K = 512 conv outlasted its K loop).  Unconditional loads (a guard's branch makes hipcc wait for each load in turn).
+    constexpr int E_CPL = 8, E_LPR = TN * 32 / E_CPL, E_RPI = 64 / E_LPR, E_NIT = 32 / E_RPI;
+    constexpr bool CANPF = !OUTF32 && TM * TN * 16 <= 64;
+    constexpr int NRES = TM * E_NIT * 2;
+    const bool pf = CANPF && a.res != nullptr;
+    f16x8 prh[CANPF ? TM : 1][CANPF ? E_NIT : 1];
+    u32x2 prl[CANPF ? TM : 1][CANPF ? E_NIT : 1];
+    const int pf_step = ksteps >= 2 ? ksteps - 2 : 0;  // (ring of two: the residual loads are then OLDER than the last step's DMA)
+
     unsigned cur = 0;  // byte offset of the image being multiplied
     for (int ks = 0; ks < ksteps; ks++) {
+        if constexpr (CANPF) {
+            if (pf && ks == pf_step) {
+                const int e_row = lane / E_LPR, e_col = lane % E_LPR;
+                const int n = n0 + wn * TN * 32 + e_col * E_CPL;
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int it = 0; it < E_NIT; it++) {
+                        const int m = m0 + wm * TM * 32 + i * 32 + it * E_RPI + e_row;
+                        const size_t e = (m < M && n < a.Cout) ? (size_t)m * a.Cout + n : 0;
+                        prh[i][it] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(a.res) + e);
+                        prl[i][it] = *reinterpret_cast<const u32x2*>(static_cast<const unsigned char*>(a.res_lo) + e);
+                    }
+            }
+        }
         const char* I = smem + cur;
-        const bool more = kl < ksteps;  // step ks + 2 exists: its pieces go out between the slices
+        const bool more = kl < ksteps;  // step ks + 2 (ring of two: ks + 1) exists: its pieces go out between the slices
         uint4 fa[TM], fb[TN], fal[TM], fbl[TN];
         i32x8 a8[TM], b8[TN];
         // slice 0
@@ -333,12 +384,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
 #pragma unroll
             for (int j = 0; j < TN; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 1, 1, 0, 127 - kHlLoShift, 0, 127);
-        if (more)
+        if (NIMG == 3 && more)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
+        else if (pf && !more)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRES) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        cur = cur + IMG == 3 * IMG ? 0u : cur + IMG;
+        cur = cur + IMG == NIMG * IMG ? 0u : cur + IMG;
     }
 
     // ---- epilogue: * acc_scale, + bias, + residual (HL), ReLU; HL planes or f32 out.  Each wave passes its 32-pixel row blocks
@@ -349,7 +402,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     const bool vec_ok = (a.Cout & (CPL - 1)) == 0;
     if (vec_ok) {
         constexpr int ROWB = TN * 128 + 16;
-        static_assert(NW * 32 * ROWB <= hl_lds_bytes(BM, BN, WM, WN), "epilogue staging exceeds the LDS allocation");
+        static_assert(NW * 32 * ROWB <= hl_lds_bytes(BM, BN, WM, WN, NIMG), "epilogue staging exceeds the LDS allocation");
         constexpr int LPR = TN * 32 / CPL, RPI = 64 / LPR;
         const int e_row = lane / LPR, e_col = lane % LPR;
         const int n = n0 + wn * TN * 32 + e_col * CPL;
@@ -360,6 +413,25 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         for (int t = 0; t < CPL; t++) bv[t] = (has_bias && n_ok) ? a.bias[n + t] : 0.f;
         const _Float16* res_hi = static_cast<const _Float16*>(a.res);
         const unsigned char* res_lo = static_cast<const unsigned char*>(a.res_lo);
+        // Tiles too big for the prefetch above (256 x 256: 128 accumulators per lane): ALL residual loads of the wave go out here, at
+        // once -- the fragment registers of the K loop are dead by now, so there is room for them -- instead of per 32-row block:
+        // one HBM round trip per wave instead of TM of them (one workgroup per CU: nothing else would cover the other three).
+        constexpr bool LATE = !OUTF32 && !CANPF;
+        f16x8 lrh[LATE ? TM : 1][LATE ? E_NIT : 1];
+        u32x2 lrl[LATE ? TM : 1][LATE ? E_NIT : 1];
+        if constexpr (LATE) {
+            if (res_hi) {
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int it = 0; it < E_NIT; it++) {
+                        const int m = m0 + wm * TM * 32 + i * 32 + it * E_RPI + (lane / E_LPR);
+                        const size_t e = (m < M && n_ok) ? (size_t)m * a.Cout + n : 0;
+                        lrh[i][it] = *reinterpret_cast<const f16x8*>(res_hi + e);
+                        lrl[i][it] = *reinterpret_cast<const u32x2*>(res_lo + e);
+                    }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -396,15 +468,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
                 if (res_hi) {
 #pragma unroll
                     for (int it = 0; it < 32 / RPI; it++) {
-                        const int m = mb + it * RPI + e_row;
-                        f16x8 vh = {};
-                        u32x2 vl = {0u, 0u};
-                        if (m < M && n_ok) {
-                            vh = *reinterpret_cast<const f16x8*>(res_hi + (size_t)m * a.Cout + n);
-                            vl = *reinterpret_cast<const u32x2*>(res_lo + (size_t)m * a.Cout + n);
+                        if constexpr (CANPF) {
+                            rh[it] = prh[i][it];
+                            rl[it] = prl[i][it];
+                        } else {
+                            rh[it] = lrh[i][it];
+                            rl[it] = lrl[i][it];
                         }
-                        rh[it] = vh;
-                        rl[it] = vl;
                     }
                 }
 #pragma unroll
@@ -462,12 +532,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool G1, bool OUTF32>
+template <int BM, int BN, int WM, int WN, bool G1, bool OUTF32, bool DUAL = false, int NIMG = 3>
 static hipError_t launch_hl_g(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)hl_lds_bytes(BM, BN, WM, WN);
-    auto k = conv_hl_kernel<BM, BN, WM, WN, G1, OUTF32>;
+    const size_t lds = (size_t)hl_lds_bytes(BM, BN, WM, WN, NIMG);
+    auto k = conv_hl_kernel<BM, BN, WM, WN, G1, OUTF32, DUAL, NIMG>;
     static std::atomic<bool> attr_done[64];
     int dev = 0;
     const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
@@ -480,23 +550,29 @@ static hipError_t launch_hl_g(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NIMG = 3>
 static hipError_t launch_hl_t(const ConvArgs& a, int out_f32, hipStream_t s) {
     const bool g1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
-    if (out_f32) return g1 ? launch_hl_g<BM, BN, WM, WN, true, true>(a, s) : launch_hl_g<BM, BN, WM, WN, false, true>(a, s);
-    return g1 ? launch_hl_g<BM, BN, WM, WN, true, false>(a, s) : launch_hl_g<BM, BN, WM, WN, false, false>(a, s);
+    if (a.in2) return launch_hl_g<BM, BN, WM, WN, true, false, true, NIMG>(a, s);  // (conv_hl_config_valid: 1x1, stride 1, hi / lo out)
+    if (out_f32) return g1 ? launch_hl_g<BM, BN, WM, WN, true, true, false, NIMG>(a, s) : launch_hl_g<BM, BN, WM, WN, false, true, false, NIMG>(a, s);
+    return g1 ? launch_hl_g<BM, BN, WM, WN, true, false, false, NIMG>(a, s) : launch_hl_g<BM, BN, WM, WN, false, false, false, NIMG>(a, s);
 }
 
 // configurations of mode 5 (indices of conv_igemm.hip's table whose tile dimensions they share): 11 = 256x256 (8 waves of
-// 128x64), 0 = 128x128 (4 waves of 64x64), 6 = 256x128 (8 waves of 64x64), 5 = 128x256 (8 waves of 64x64)
+// 128x64), 0 = 128x128 (4 waves of 64x64), 6 = 256x128 (8 waves of 64x64), 5 = 128x256 (8 waves of 64x64); 12 = 256x128 and
+// 14 = 128x256 as FOUR waves of 128x64 with a ring of two images: two workgroups per CU
 bool conv_hl_config_valid(const ConvArgs& a, int cfg, int out_f32) {
-    if (cfg != 11 && cfg != 0 && cfg != 6 && cfg != 5) return false;
-    if (!a.in_lo || !a.wt_lo || a.in2) return false;
+    if (cfg != 11 && cfg != 0 && cfg != 6 && cfg != 5 && cfg != 12 && cfg != 14 && cfg != 13) return false;
+    if (!a.in_lo || !a.wt_lo) return false;
+    if (a.in2 && (!a.in2_lo || out_f32 || a.res || a.KH != 1 || a.KW != 1 || a.pad != 0 || a.stride != 1 || a.Cin2 % HL_KC != 0 || a.batch > 1 ||
+                  (size_t)a.H2 * a.W2 * a.Cin2 * 2 >= 0x80000000ull))
+        return false;
     if (a.Cin % HL_KC != 0) return false;
     if ((size_t)a.H * a.W * a.Cin * 2 >= 0x80000000ull || (size_t)a.Cout * a.KH * a.KW * a.Cin * 2 >= 0x80000000ull) return false;
     if (out_f32 ? (a.res != nullptr) : (!a.out_lo || (a.res != nullptr) != (a.res_lo != nullptr) || (a.Cout & 7))) return false;
-    if (a.batch > 1 && (a.in_bs & 1 || a.wt_bs & 1)) return false;
-    const int bn = (cfg == 11 || cfg == 5) ? 256 : 128;
+    if (a.batch > 1 && (a.in_bs & 1 || a.wt_bs & 1 || !out_f32)) return false;
+    if ((size_t)a.Cout * (a.in2 ? a.Cin + a.Cin2 : a.KH * a.KW * a.Cin) * 2 >= 0x80000000ull) return false;
+    const int bn = (cfg == 11 || cfg == 5 || cfg == 14 || cfg == 13) ? 256 : 128;
     return bn <= a.Cout || bn == 128;  // Cout < 128 (layer1, the logits): the 128-wide N tile with its surplus rows out of range
 }
 
@@ -508,6 +584,9 @@ hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s
         case 0: return launch_hl_t<128, 128, 2, 2>(a, out_f32, s);
         case 6: return launch_hl_t<256, 128, 4, 2>(a, out_f32, s);
         case 5: return launch_hl_t<128, 256, 2, 4>(a, out_f32, s);
+        case 12: return launch_hl_t<256, 128, 2, 2, 2>(a, out_f32, s);
+        case 14: return launch_hl_t<128, 256, 1, 4, 2>(a, out_f32, s);
+        case 13: return launch_hl_t<256, 256, 4, 2>(a, out_f32, s);  // 8 waves of 64 x 128: a wave's epilogue rows are 128 channels wide
         default: return hipErrorInvalidValue;
     }
 }

@@ -117,6 +117,9 @@ const char* conv_igemm_config_name(int cfg, int mode) {
             case 0: return "conv_hl<128,128>";
             case 6: return "conv_hl<256,128>";
             case 5: return "conv_hl<128,256>";
+            case 12: return "conv_hl<256,128,4w>";
+            case 14: return "conv_hl<128,256,4w>";
+            case 13: return "conv_hl<256,256,wn2>";
             default: return "conv_hl<?>";
         }
     }

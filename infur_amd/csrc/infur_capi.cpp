@@ -409,6 +409,8 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
             most = std::max(most, (size_t)L.cout * L.cin * L.k * L.k);
             if (L.d_u) most = std::max(most, (size_t)wino_planes(c) * L.cout * L.cin);
         }
+        for (size_t i = 0; i + 1 < n; i++)
+            if (g[i].d_wcat) most = std::max(most, (size_t)g[i].cout * (g[i].cin + g[i + 1].cin));
         HIPCHK(c, hipMalloc(&scratch.p, hl_tensor_bytes(most)));
     }
     // f32 [planes][per] at `w`, plane p scaled by sc[p] -> hi planes at w, lo planes at w + hl_lo_offset(planes * per); *lo_out = the lo base
@@ -478,7 +480,10 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         }
         if (L.d_wcat) {
             L.wcat_scale = pow2_for(mx[per * i + 1]);
-            HIPCHK(c, launch_split_weights((float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), L.wcat_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
+            if (hl)
+                RETIF(hl_pack((float*)L.d_wcat, 1, (size_t)L.cout * (L.cin + g[i + 1].cin), &L.wcat_scale, &L.d_wcatl));
+            else
+                HIPCHK(c, launch_split_weights((float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), L.wcat_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         }
     }
     return INFUR_OK;
@@ -553,7 +558,6 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
         ConvLayer& L = g[i];
         const ConvLayer& D = g[i + 1];
         if (L.role != '3' || D.role != 'd') continue;
-        if (ctx_hl(c)) continue;  // (the three-byte mode runs the downsample branch as its own launch + residual)
         const size_t es = ctx_f16(c) ? 2 : 4;
         L.d_wcat = (uint8_t*)d_weights + off;
         off += align_up((size_t)L.cout * (L.cin + D.cin) * 4, 256);
@@ -823,13 +827,19 @@ int32_t run_conv_dual(infur_ctx* c, const ConvLayer& L3, const ConvLayer& D, con
         a.acc_scale = 1.0f / (a.a_scale * L3.wcat_scale);
         a.amax = c->d_range;
     }
+    const bool hl = ctx_hl(c);
+    if (hl) {
+        a.in_lo = t2.lo; a.in2_lo = x.lo; a.wt_lo = L3.d_wcatl; a.out_lo = out->lo;
+        a.acc_scale = 1.0f / L3.wcat_scale;
+    }
     const double flops = 2.0 * oh * ow * (double)L3.cout * (L3.cin + D.cin);
     const double bytes = (double)t2.bytes() + (double)oh * ow * x.c * x.es + (double)out->bytes() + (double)L3.cout * (L3.cin + D.cin) * t2.es;
     int cfg = -1;
-    RETIF(pick_cfg(c, a, conv_mode(c), mode != 1 ? 1 : 0, &cfg));
+    const int out_f32 = (mode != 1 && !hl) ? 1 : 0;
+    RETIF(pick_cfg(c, a, conv_mode(c), out_f32, &cfg));
     {
         ProfScope ps(c, L3.name + "+downsample", conv_igemm_config_name(cfg, conv_mode(c)), flops, bytes);
-        HIPCHK(c, launch_conv_igemm(a, conv_mode(c), mode != 1 ? 1 : 0, cfg, c->stream));
+        HIPCHK(c, launch_conv_igemm(a, conv_mode(c), out_f32, cfg, c->stream));
     }
     return INFUR_OK;
 }

@@ -48,6 +48,7 @@ struct ConvLayer {
     // INFUR_DTYPE_F16_HL: d_w / d_u hold the f16 hi planes of w * w_scale / u * (plane scale), d_wl / d_ul the e5m2 lo planes
     void* d_wl = nullptr;
     void* d_ul = nullptr;
+    void* d_wcatl = nullptr;  // lo plane of d_wcat
     // conv3 of a stage's first block: its weights and the downsample branch's side by side ([cout][cin + ds.cin],
     // context dtype), the two biases summed -- the two-source GEMM of run_conv_dual
     void* d_wcat = nullptr;
@@ -76,7 +77,7 @@ struct ConvLayer {
     template <class F>
     void map_device_pointers(F&& f) {
         auto ap = [&](auto*& p) { p = static_cast<std::remove_reference_t<decltype(p)>>(f((void*)p)); };
-        ap(d_w); ap(d_b); ap(d_u); ap(d_uacc); ap(d_wl); ap(d_ul); ap(d_wcat); ap(d_bcat); ap(d_w3i);
+        ap(d_w); ap(d_b); ap(d_u); ap(d_uacc); ap(d_wl); ap(d_ul); ap(d_wcatl); ap(d_wcat); ap(d_bcat); ap(d_w3i);
         ap(d_qbias); ap(d_qmult); ap(d_w2); ap(d_qbias2); ap(d_qmult2);
     }
 };

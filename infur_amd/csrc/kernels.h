@@ -58,6 +58,7 @@ struct ConvArgs {
     const void* wt_lo = nullptr;
     const void* res_lo = nullptr;
     void* out_lo = nullptr;
+    const void* in2_lo = nullptr;
 };
 
 // conv as implicit GEMM on the matrix cores.  mode 0: f32 operands on the f32 MFMA (Cin % 32 == 0);

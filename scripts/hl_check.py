@@ -56,13 +56,22 @@ def probe(tag, blob, frame_fn, sizes):
                 if worst > 5e-3 or "--layers" in sys.argv:
                     print("\n".join(lines), flush=True)
                 c.close()
+                # the frame path proper: fused stem + pool, conv3 + downsample as one two-source launch (no per-layer read-back)
+                c = Context(device=0, dtype=dtype, winograd_tile=max(tile, 0), winograd_min_cin=0xFFFFFFFF if tile < 0 else 0)
+                m = Model(c).control(ModelCmd.LoadBlob(blob))
+                FramePath(c, 0).advance(fr, 1.0)
+                lo, la = m.lowres()
+                (e, er), (ea, era) = H.errors(lo, ref), H.errors(la, ref_aux)
+                print(f"{dtype:6s} {name:7s} fused frame path: logits {max(e, ea):.2e} / {max(er, era):.2e}", flush=True)
+                c.close()
 
 
 sizes = [(240, 320)] + ([(1080, 1920)] if full else [])
-probe("synthetic", W.synth_blob(), lambda h, w: W.synth_frame(h, w, index=3), sizes[:1])
-probe("hostile", H.hostile_blob(), lambda h, w: H.saturated_frame(h, w, index=2), sizes)
+if "--time-only" not in sys.argv:
+  probe("synthetic", W.synth_blob(), lambda h, w: W.synth_frame(h, w, index=3), sizes[:1])
+  probe("hostile", H.hostile_blob(), lambda h, w: H.saturated_frame(h, w, index=2), sizes)
 
-if "--time" in sys.argv:
+if "--time" in sys.argv or "--time-only" in sys.argv:
     blob = W.synth_blob()
     fr = W.synth_frame(1080, 1920, index=1)
     for dtype in modes:
