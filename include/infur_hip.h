@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define INFUR_ABI_VERSION 4
+#define INFUR_ABI_VERSION 5
 
 /* status codes */
 enum {
@@ -221,7 +221,10 @@ int32_t infur_model_warmup(infur_ctx* ctx, uint32_t w, uint32_t h);
  * tile configurations measured) is captured from the same enqueue code -- one graph per (input pointer, output pointer, w, h,
  * factor, mode), at most 12 cached -- and launched as one graph from then on; any allocation, release, model or tuning change
  * drops the cached graphs.  Results are the eager path's bits.  Ignored (eager) while options.profile or
- * options.keep_activations is set.  infur_ctx_graph_stats: captures / replays so far, graphs cached now (any pointer may be NULL). */
+ * options.keep_activations is set.  infur_ctx_graph_stats: captures / replays so far, graphs cached now (any pointer may be NULL).
+ * The context's stream (infur_ctx_stream) does NOT change when replay is enabled (ABI 5; ABI 3-4 replaced a library-owned stream by a
+ * private one, which left hosts holding a stale handle): a library-owned stream is reserved for this context while it is the only
+ * one using it; a stream that is already shared with another context of the device simply never captures (the frames run eagerly). */
 int32_t infur_ctx_set_graph_replay(infur_ctx* ctx, uint32_t enable);
 int32_t infur_ctx_graph_stats(const infur_ctx* ctx, uint64_t* captures, uint64_t* replays, uint32_t* cached);
 /* output-stride-8 logits of the last advance, [num_classes, lh, lw] f32 planar (host) */
@@ -297,6 +300,33 @@ int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint3
  * INFUR_E_INVALID_ARG when nothing is pending. */
 int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t rgba_capacity, uint8_t* scaled_bgr,
                              uint64_t* frame_id, uint32_t* ow, uint32_t* oh);
+
+/* ---- zero-copy ingest / egress (ABI 5) ----
+ * The reference's decoder fills a caller-owned, REUSED frame buffer in place (ff-video/src/decoder.rs:156-165,
+ * infur/src/processing.rs:121-131); submit() / collect() above each add one pageable <-> pinned memcpy per frame instead (6.2 MB in,
+ * 8.3 + 6.2 MB out at 1080p).  These four calls lend the ring's own PINNED slots to the caller:
+ *   acquire   sizes the next slot for a w x h frame (scaled by `factor`) and returns its pinned input buffer, w*h*3 bytes: the
+ *             producer read()s the next frame straight into it.  INFUR_E_CAPACITY when every slot is in flight (collect / release
+ *             one first).  Acquiring again before commit returns the same slot, re-sized.
+ *   commit    enqueues H2D -> scale / model / decode -> D2H for the acquired slot, exactly what submit() enqueues after its copy;
+ *             w, h, factor must be the acquired ones.  submit() while a slot is acquired is INFUR_E_INVALID_ARG.
+ *   collect_view  waits for the oldest pending frame and returns pointers INTO its pinned output slot (mask ow*oh*4 bytes, scaled
+ *             frame ow*oh*3 bytes); they stay valid -- and the slot stays out of circulation -- until
+ *   release   (or a copying collect() of the same frame) gives the slot back.
+ * Copying and zero-copy calls may be mixed frame by frame; results and their order are the same. */
+int32_t infur_stream_acquire(infur_stream* st, uint32_t w, uint32_t h, float factor, uint8_t** bgr_slot);
+int32_t infur_stream_commit(infur_stream* st, uint32_t w, uint32_t h, float factor, uint32_t scale_mode, uint64_t frame_id);
+int32_t infur_stream_collect_view(infur_stream* st, const uint8_t** rgba, const uint8_t** scaled_bgr, uint64_t* frame_id,
+                                  uint32_t* ow, uint32_t* oh);
+int32_t infur_stream_release(infur_stream* st);
+
+/* Pinned host memory for buffers the CALLER owns and reuses (frames it decodes into, masks it displays from): the batch calls
+ * (infur_batch_advance, infur_group_batch_advance, infur_batch_advance_multi) recognise such buffers and move them by DMA
+ * directly -- no staging copy on either side; they return only when every frame is done, so nothing is read or written behind
+ * the caller's back.  Pageable buffers keep working (staged through the ring).  Portable: usable with every device of the process. */
+int32_t infur_host_alloc(size_t bytes, void** p);
+int32_t infur_host_free(void* p);
+uint32_t infur_host_is_pinned(const void* p); /* 1: hipHostMalloc / hipHostRegister memory */
 
 /* ---- frame batch (BASELINE configs[3]: a batch of independent frames; across GPUs the host
  * layer gives each rank a contiguous slice, infur_amd/dist.py) ----

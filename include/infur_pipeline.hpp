@@ -10,6 +10,7 @@
 // on this header; tests/cpp/pipeline_test.cpp re-expresses app.rs:175-253 on it.
 #pragma once
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <memory>
 
@@ -28,6 +29,14 @@ public:
     virtual uint32_t height() const = 0;
     /// fills `img` (already width x height), returns the 1-based frame id through `id` (decoder.rs:163-164)
     virtual VideoStatus read_frame(BgrImage& img, uint64_t& id) = 0;
+    /// the same into caller-owned memory of width * height * 3 bytes -- a pinned slot of the streaming ring (StreamPath::run_zero_copy).
+    /// Default: through a temporary image; RawVideoSource reads the pipe straight into `dst`.
+    virtual VideoStatus read_into(uint8_t* dst, uint64_t& id) {
+        BgrImage tmp = empty_image();
+        const VideoStatus v = read_frame(tmp, id);
+        if (v == VideoStatus::Ok) std::memcpy(dst, tmp.data.data(), tmp.data.size());
+        return v;
+    }
     virtual void close() {}
     BgrImage empty_image() const { return BgrImage(width(), height()); }
 };
@@ -41,12 +50,13 @@ public:
     ~RawVideoSource() override { close(); }
     uint32_t width() const override { return w_; }
     uint32_t height() const override { return h_; }
-    VideoStatus read_frame(BgrImage& img, uint64_t& id) override {
+    VideoStatus read_frame(BgrImage& img, uint64_t& id) override { return read_into(img.data.data(), id); }
+    VideoStatus read_into(uint8_t* dst, uint64_t& id) override {
         if (!f_) return VideoStatus::NoSource;
         const size_t n = (size_t)w_ * h_ * 3;
         size_t got = 0;
         while (got < n) {  // read_exact
-            const size_t k = std::fread(img.data.data() + got, 1, n - got, f_);
+            const size_t k = std::fread(dst + got, 1, n - got, f_);
             if (k == 0) break;
             got += k;
         }
@@ -273,6 +283,54 @@ public:
         if (scaled && (scaled->width != ow || scaled->height != oh)) *scaled = BgrImage(ow, oh);
         return infur_stream_collect(st_, mask.rgba.data(), mask.rgba.size(), scaled ? scaled->data.data() : nullptr, &frame_id, &ow, &oh);
     }
+    // ---- zero-copy ingest / egress (ABI 5): the ring's pinned slots lent to the caller ----
+    /// a mask (and the scaled frame) in place in the ring's pinned output slot: valid until release()
+    struct View {
+        const uint8_t* rgba = nullptr;
+        const uint8_t* scaled_bgr = nullptr;
+        uint32_t width = 0, height = 0;
+        uint64_t frame_id = 0;
+    };
+    Status acquire(uint32_t w, uint32_t h, float factor, uint8_t*& slot) { return infur_stream_acquire(st_, w, h, factor, &slot); }
+    Status commit(uint32_t w, uint32_t h, float factor, uint64_t frame_id) { return infur_stream_commit(st_, w, h, factor, mode_, frame_id); }
+    Status collect_view(View& v) { return infur_stream_collect_view(st_, &v.rgba, &v.scaled_bgr, &v.frame_id, &v.width, &v.height); }
+    Status release() { return infur_stream_release(st_); }
+    /// as run(), without the two pageable <-> pinned copies per frame: the source reads each frame straight into the next pinned slot
+    /// (what the reference's decoder does with its reused BgrImage, ff-video/src/decoder.rs:156-165) and `sink(view)` sees the mask in
+    /// place in the pinned output slot
+    Status run_zero_copy(FrameSource& src, float factor, const std::function<void(const View&)>& sink, uint64_t* n_frames = nullptr) {
+        uint64_t n = 0, id = 0;
+        Status err = INFUR_OK;
+        auto drain_one = [&]() -> Status {
+            View v;
+            Status s = collect_view(v);
+            if (s != INFUR_OK) return s;
+            sink(v);
+            n++;
+            return release();
+        };
+        for (;;) {
+            if (pending() >= depth_ && (err = drain_one()) != INFUR_OK) break;
+            uint8_t* slot = nullptr;
+            if ((err = acquire(src.width(), src.height(), factor, slot)) != INFUR_OK) break;
+            const VideoStatus v = src.read_into(slot, id);
+            if (v != VideoStatus::Ok) {
+                if (v != VideoStatus::FinishedNormally) err = INFUR_E_IO;
+                break;  // (the acquired slot is simply never committed: the next acquire re-uses it)
+            }
+            if ((err = commit(src.width(), src.height(), factor, id)) != INFUR_OK) break;
+        }
+        while (pending()) {
+            const Status s = drain_one();
+            if (s != INFUR_OK) {
+                if (err == INFUR_OK) err = s;
+                break;
+            }
+        }
+        if (n_frames) *n_frames = n;
+        return err;
+    }
+
     /// pump a source through the ring: `sink(id, mask)` is called once per frame, in order.  Returns the first error
     /// (video errors other than FinishedNormally map to INFUR_E_IO); frames already in flight are drained first.
     Status run(FrameSource& src, float factor, const std::function<void(uint64_t, const ColorImage&)>& sink, uint64_t* n_frames = nullptr) {

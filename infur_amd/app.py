@@ -333,6 +333,53 @@ class StreamPath:
                                               C.byref(oh)))
         return fid.value, rgba, scaled
 
+    # ---- zero-copy ingest / egress (ABI 5): the ring's pinned slots lent to the caller ----
+    def acquire(self, w: int, h: int, factor: float) -> np.ndarray:
+        """-> the next slot's pinned input buffer as an [h, w, 3] u8 array to fill in place (what the reference's decoder does with its
+        reused BgrImage, ff-video/src/decoder.rs:156-165); then ``commit``."""
+        p = C.c_void_p(None)
+        self.ctx.check(self.ctx.L.infur_stream_acquire(self.h, w, h, float(np.float32(factor)), C.byref(p)))
+        buf = (C.c_uint8 * (w * h * 3)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(h, w, 3)
+
+    def commit(self, w: int, h: int, factor: float, frame_id: int) -> None:
+        self.ctx.check(self.ctx.L.infur_stream_commit(self.h, w, h, float(np.float32(factor)), self.scale_mode, frame_id))
+
+    def collect_view(self, want_scaled: bool = False):
+        """-> (frame_id, rgba view [oh,ow,4], scaled view or None): arrays over the pinned output slot, valid until ``release``."""
+        L = self.ctx.L
+        fid, ow, oh = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        pr, ps = C.c_void_p(None), C.c_void_p(None)
+        self.ctx.check(L.infur_stream_collect_view(self.h, C.byref(pr), C.byref(ps) if want_scaled else None, C.byref(fid), C.byref(ow), C.byref(oh)))
+        n = ow.value * oh.value
+        rgba = np.frombuffer((C.c_uint8 * (n * 4)).from_address(pr.value), np.uint8).reshape(oh.value, ow.value, 4)
+        scaled = None
+        if want_scaled and ps.value:
+            scaled = np.frombuffer((C.c_uint8 * (n * 3)).from_address(ps.value), np.uint8).reshape(oh.value, ow.value, 3)
+        return fid.value, rgba, scaled
+
+    def release(self) -> None:
+        self.ctx.check(self.ctx.L.infur_stream_release(self.h))
+
+    def run_zero_copy(self, frames, factor: float, fill=None):
+        """As ``run`` through acquire / commit / collect_view / release: ``fill(slot, item)`` writes the frame into the pinned slot (default:
+        ``slot[...] = item``, one copy -- a real producer read()s the pipe into the slot instead); yields (id, COPY of the mask)."""
+        fill = fill or (lambda slot, img: np.copyto(slot, img))
+        for fid, img in frames:
+            if self.pending() >= self.depth:
+                i, rgba, _ = self.collect_view()
+                out = rgba.copy()
+                self.release()
+                yield i, out
+            h, w = img.shape[:2]
+            fill(self.acquire(w, h, factor), img)
+            self.commit(w, h, factor, fid)
+        while self.pending():
+            i, rgba, _ = self.collect_view()
+            out = rgba.copy()
+            self.release()
+            yield i, out
+
     def run(self, frames, factor: float):
         """Generator: push frames (iterable of (id, img)) through the ring, yield (id, rgba) in order."""
         for fid, img in frames:
@@ -346,6 +393,33 @@ class StreamPath:
         if getattr(self, "h", None):
             self.ctx.L.infur_stream_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """A numpy array over pinned host memory from ``infur_host_alloc``: frames / masks the caller owns and reuses; the batch calls
+    (``FramePath.advance_batch``, ``Group.batch_advance``) move such buffers by DMA without their staging copies."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.L = _lib.load()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p(None)
+        rc = self.L.infur_host_alloc(n, C.byref(p))
+        if rc != 0:
+            raise MemoryError(f"infur_host_alloc({n}) failed: {_lib.status_string(rc)}")
+        self.p = p
+        self.array = np.frombuffer((C.c_uint8 * n).from_address(p.value), dtype).reshape(shape)
+
+    def close(self):
+        if getattr(self, "p", None) is not None and self.p:
+            self.array = None
+            self.L.infur_host_free(self.p)
+            self.p = None
 
     def __del__(self):
         try:

@@ -355,7 +355,9 @@ HaloPlan halo_plan(const ConvArgs& a, int bn) {
         cands[nc++] = HaloGeom{16, 16, cdiv(W, 16), n1, (H / 16) * 16, H % 16, 32, n2, n1 + n2};
     }
     for (int ci = 0; ci < nc; ci++)
-        for (int na = (a.Cin == 64 ? 1 : 2); na >= 1; na--) {  // (one channel chunk: there is no next patch to prefetch)
+        // (one channel chunk: there is no next patch to prefetch; BN = 64 exists in the single-patch-image form only -- launch_conv3x3_halo
+        //  runs launch_halo<64, 1> -- so its plan, LDS size and workgroups-per-CU estimate must describe that form: ADVICE r4)
+        for (int na = ((a.Cin == 64 || bn == 64) ? 1 : 2); na >= 1; na--) {
             const HaloGeom& g = cands[ci];
             int lds = h_lds(bn, na, g.th1, g.tw1, d), pieces = h_pieces(g.th1, g.tw1, d);
             long patch = (long)(g.th1 + 2 * d) * (g.tw1 + 2 * d);
@@ -581,10 +583,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo4_kernel(const ConvArgs a,
             H4_M(fa0, fb0, 7); H4_PIN; H4_RB(fb1, q % 3, 1, 3); H4_PIN;
             // the next chunk's patch, one piece per wave and step: written here one step after it was asked for
             H4_M(fa0, fb0, 8); H4_PIN;
-            if (!(ABL & 1) && q >= 1 && q - 1 < T && more_chunks) *reinterpret_cast<u32x4h*>(p_dst + (aimg ^ 1) * pimg + (q - 1) * 4096) = preg;
+            if constexpr (q >= 1 && q - 1 < H4_TMAX)  // (steps 15 .. 17 never carry a patch piece: T <= H4_TMAX, enforced by the host)
+                if (!(ABL & 1) && q - 1 < T && more_chunks) *reinterpret_cast<u32x4h*>(p_dst + (aimg ^ 1) * pimg + (q - 1) * 4096) = preg;
             H4_PIN;
             H4_M(fa0, fb0, 9); H4_PIN;
-            if (!(ABL & 1) && q < T && more_chunks) preg = __builtin_amdgcn_raw_buffer_load_b128(in_rs, a_voff[q], (unsigned)((cc + 1) * 128), 0);
+            if constexpr (q < H4_TMAX)  // (a_voff has H4_TMAX entries: no instantiation indexes past it)
+                if (!(ABL & 1) && q < T && more_chunks) preg = __builtin_amdgcn_raw_buffer_load_b128(in_rs, a_voff[q], (unsigned)((cc + 1) * 128), 0);
             H4_PIN;
             mma(fa0, fb0, 10, 16);
             // ---- image q + 1 is published (written during step q - 1, before this barrier), image q is free ----

@@ -1486,6 +1486,9 @@ hipStream_t g_pool[kMaxDev][kPool];
 bool g_pool_made[kMaxDev];
 unsigned g_pool_next[kMaxDev];
 int g_pool_users[kMaxDev][kPool];
+// a slot whose single user has graph replay enabled: it stays that context's alone (pool_stream skips it), so the decision "this
+// stream may capture" cannot be invalidated by a context created on another thread during the capture window
+bool g_pool_excl[kMaxDev][kPool];
 }  // namespace
 
 static hipStream_t pool_stream(int device, int* slot) {
@@ -1500,15 +1503,37 @@ static hipStream_t pool_stream(int device, int* slot) {
             }
         g_pool_made[device] = true;
     }
-    *slot = (int)(g_pool_next[device]++ % kPool);
-    g_pool_users[device][*slot]++;
-    return g_pool[device][*slot];
+    for (int tries = 0; tries < kPool; tries++) {
+        const int k = (int)(g_pool_next[device]++ % kPool);
+        if (g_pool_excl[device][k]) continue;  // reserved by a capturing context
+        *slot = k;
+        g_pool_users[device][k]++;
+        return g_pool[device][k];
+    }
+    // every pool stream is reserved: a private stream (slot stays -1, the caller owns and destroys it)
+    hipStream_t own = nullptr;
+    if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return own;
 }
 
 static void pool_stream_release(int device, int slot) {
     if (device < 0 || device >= kMaxDev || slot < 0 || slot >= kPool) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool_users[device][slot] > 0) g_pool_users[device][slot]--;
+    if (g_pool_users[device][slot] == 0) g_pool_excl[device][slot] = false;
+}
+
+// reserve (or give back) the context's pool stream for capture: succeeds only while the context is the slot's single user
+static bool pool_stream_reserve(const infur_ctx* c, bool on) {
+    if (c->pool_slot < 0) return true;  // the caller's stream or a private one: nothing to reserve
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!on) {
+        g_pool_excl[c->device][c->pool_slot] = false;
+        return true;
+    }
+    if (g_pool_users[c->device][c->pool_slot] != 1) return false;
+    g_pool_excl[c->device][c->pool_slot] = true;
+    return true;
 }
 
 // does another live context hold this context's (pool) stream?
@@ -1533,6 +1558,10 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || o.device < 0 || o.device >= n) return INFUR_E_HIP;
         if (hipSetDevice(o.device) != hipSuccess) return INFUR_E_HIP;
         infur_ctx* c = new infur_ctx();
+        struct Guard {  // an exception below (the look-up tables are std::vectors) must give the stream-pool slot and the context back
+            infur_ctx* c;
+            ~Guard() { if (c) infur_ctx_destroy(c); }
+        } guard{c};
         c->opt = o;
         c->device = o.device;
         if (o.stream) {
@@ -1551,9 +1580,9 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
             // hardware queue anyway; a host with its own stream policy passes its stream in the options.
             c->stream = pool_stream(o.device, &c->pool_slot);
             if (!c->stream) {
-                delete c;
                 return INFUR_E_HIP;
             }
+            c->own_stream = c->pool_slot < 0;  // (every pool stream reserved by a capturing context: a private stream)
         }
         std::vector<float> pre(768);
         std::vector<uint32_t> col(20 * 256);
@@ -1569,10 +1598,8 @@ int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
                   hipMemcpy(c->d_color_lut, col.data(), col.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                   ((o.compute_dtype != INFUR_DTYPE_F32_SPLIT && o.compute_dtype != INFUR_DTYPE_F32_SPLIT_FP8) ||
                    (hipMalloc((void**)&c->d_range, 2 * sizeof(unsigned)) == hipSuccess && hipMemset(c->d_range, 0, 2 * sizeof(unsigned)) == hipSuccess));
-        if (!ok) {
-            infur_ctx_destroy(c);
-            return INFUR_E_HIP;
-        }
+        if (!ok) return INFUR_E_HIP;  // (guard destroys the context)
+        guard.c = nullptr;
         *out = c;
         return INFUR_OK;
     } catch (const std::bad_alloc&) {
@@ -2230,22 +2257,15 @@ int32_t infur_ctx_set_graph_replay(infur_ctx* c, uint32_t enable) {
         (void)hipSetDevice(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         graphs_drop(c);
-    } else if (c->pool_slot >= 0 && c->streams.empty() && !c->batch_ring) {
-        // A capturing context gets a stream of its OWN: pool streams are shared from the ninth context of a device on, and a
-        // kernel another context's thread enqueues between BeginCapture and EndCapture would be recorded into this context's
-        // graph, not executed (ThreadLocal capture mode only restricts the capturing thread).  With a ring already attached the
-        // stream stays (the ring's events are tied to it) and a shared stream simply never captures (frame_advance_dev).
-        hipStream_t own = nullptr;
-        (void)hipSetDevice(c->device);
-        if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess) {
-            (void)hipStreamSynchronize(c->stream);
-            pool_stream_release(c->device, c->pool_slot);
-            c->pool_slot = -1;
-            c->stream = own;
-            c->own_stream = true;
-        } else {
-            (void)hipGetLastError();
-        }
+        (void)pool_stream_reserve(c, false);
+    } else {
+        // The context's stream NEVER changes behind infur_ctx_stream() (a host that had read the handle kept enqueueing
+        // producers of d_bgr on the old stream).  Pool streams are shared from the ninth context of a device on, and a kernel another
+        // context's thread enqueues between BeginCapture and EndCapture would be recorded into this context's graph, not executed
+        // (ThreadLocal capture mode only restricts the capturing thread) -- so the slot is RESERVED instead: while this context is
+        // its only user, pool_stream hands it to nobody else.  A slot that is already shared stays shared and simply never captures
+        // (frame_advance_dev runs eagerly: stream_is_shared).
+        (void)pool_stream_reserve(c, true);
     }
     c->graph_streak = 0;
     return INFUR_OK;
@@ -2306,6 +2326,9 @@ struct infur_stream {
         uint32_t ow = 0, oh = 0;
         int32_t status = INFUR_OK;
         bool busy = false;
+        // zero-copy egress: the mask goes by DMA straight into a pinned buffer of the caller (infur_batch_advance with buffers from
+        // infur_host_alloc); nullptr: into h_out
+        uint8_t* direct_out = nullptr;
     };
     infur_ctx* ctx = nullptr;  // owner: holds the copy streams' device, receives the error messages
     // compute lanes: frame i runs on lanes[i % n] (lanes[0] == ctx).  Frames are independent, so a second context of
@@ -2314,6 +2337,11 @@ struct infur_stream {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::vector<Slot> slots;
     uint64_t head = 0, tail = 0;  // tail = next to collect, head = next to submit
+    // zero-copy ingest / egress (infur_stream_acquire / _commit, _collect_view / _release): the slot at `head` is lent to the producer
+    // (acq_*: what it was sized for), the slot at `tail` is lent to the consumer (viewing)
+    bool acquired = false, viewing = false;
+    uint32_t acq_w = 0, acq_h = 0, acq_ow = 0, acq_oh = 0;
+    uint32_t acq_factor_bits = 0;
 };
 
 namespace {
@@ -2369,6 +2397,7 @@ static void stream_orphan(infur_stream* st) {
     if (st->s_d2h) (void)hipStreamDestroy(st->s_d2h);
     st->s_h2d = st->s_d2h = nullptr;
     st->head = st->tail = 0;
+    st->acquired = st->viewing = false;
     for (infur_ctx* l : st->lanes)  // the stream is registered with every lane's context: any of them may go first
         for (size_t i = 0; i < l->streams.size(); i++)
             if (l->streams[i] == st) {
@@ -2438,42 +2467,70 @@ int32_t infur_stream_add_lane(infur_stream* st, infur_ctx* other) {
     return INFUR_OK;
 }
 
-int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
-                            uint64_t frame_id) {
-    try {
-        if (!st || !st->ctx || !bgr) return INFUR_E_INVALID_ARG;  // (a stream whose context was destroyed is dead)
-        enter(st->ctx);
-        infur_ctx* c = st->ctx;
-        int32_t rc = infur_scale_validate(factor);
-        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-        uint32_t ow = 0, oh = 0;
-        rc = infur_scale_out_dims(w, h, factor, &ow, &oh);
-        if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-        infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
-        if (!lane->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
-        // (a model may have been (re)loaded on one context after the lane was added: both kinds of arithmetic in one stream would
-        //  alternate frame by frame)
-        if (lane->quant != st->lanes[0]->quant || lane->depth != st->lanes[0]->depth)
-            return fail(c, INFUR_E_INVALID_ARG, "the stream's lanes hold different models (quantised / float, or different depths): replicate one model to all of them");
-        const size_t depth = st->slots.size();
-        if (st->head - st->tail >= depth)
-            return fail(c, INFUR_E_CAPACITY, "all %zu slots are in flight: collect before submitting more", depth);
-        infur_stream::Slot& sl = st->slots[st->head % depth];
-        const size_t in_bytes = (size_t)w * h * 3, rgba_bytes = (size_t)ow * oh * 4, sc_bytes = (size_t)ow * oh * 3;
-        if (in_bytes == 0 || rgba_bytes == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
-        RETIF(slot_reserve(c, sl, in_bytes, rgba_bytes + sc_bytes));
-        memcpy(sl.h_in, bgr, in_bytes);  // the caller's buffer is free again when submit returns
-        sl.id = frame_id;
-        sl.ow = ow;
-        sl.oh = oh;
-        // From here on work that reads / writes this slot's buffers is in flight.  The slot is handed out again by the next
-        // submit (head does not advance on failure) and slot_reserve may free its buffers, so every failing return below
-        // first waits for whatever was enqueued (quiesce).
-        auto quiesce = [&]() {
-            (void)hipStreamSynchronize(st->s_h2d);
-            (void)hipStreamSynchronize(lane->stream);
-            (void)hipStreamSynchronize(st->s_d2h);
-        };
+namespace {
+inline uint32_t f32_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+// pinned host memory (hipHostMalloc / hipHostRegister): DMA can read and write it directly
+bool host_is_pinned(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the runtime: not an error of ours)
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// checks + slot reservation shared by submit and acquire: the slot at `head`, sized for a w x h frame scaled by `factor`
+int32_t stream_prepare(infur_stream* st, uint32_t w, uint32_t h, float factor, infur_stream::Slot** slot, uint32_t* ow_out, uint32_t* oh_out) {
+    infur_ctx* c = st->ctx;
+    int32_t rc = infur_scale_validate(factor);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    uint32_t ow = 0, oh = 0;
+    rc = infur_scale_out_dims(w, h, factor, &ow, &oh);
+    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
+    infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
+    if (!lane->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
+    // (a model may have been (re)loaded on one context after the lane was added: both kinds of arithmetic in one stream would
+    //  alternate frame by frame)
+    if (lane->quant != st->lanes[0]->quant || lane->depth != st->lanes[0]->depth)
+        return fail(c, INFUR_E_INVALID_ARG, "the stream's lanes hold different models (quantised / float, or different depths): replicate one model to all of them");
+    const size_t depth = st->slots.size();
+    if (st->head - st->tail >= depth)
+        return fail(c, INFUR_E_CAPACITY, "all %zu slots are in flight: collect before submitting more", depth);
+    infur_stream::Slot& sl = st->slots[st->head % depth];
+    const size_t in_bytes = (size_t)w * h * 3, rgba_bytes = (size_t)ow * oh * 4, sc_bytes = (size_t)ow * oh * 3;
+    if (in_bytes == 0 || rgba_bytes == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
+    RETIF(slot_reserve(c, sl, in_bytes, rgba_bytes + sc_bytes));
+    *slot = &sl;
+    *ow_out = ow;
+    *oh_out = oh;
+    return INFUR_OK;
+}
+
+// enqueues H2D -> scale / model / decode -> D2H for the slot at `head`.  src: pinned host memory holding the frame (the slot's own
+// h_in, or a pinned buffer of the caller); direct_out: pinned destination of the mask instead of the slot's h_out (or nullptr)
+int32_t stream_enqueue(infur_stream* st, infur_stream::Slot& sl, const uint8_t* src, uint32_t w, uint32_t h, float factor, uint32_t mode,
+                       uint64_t frame_id, uint32_t ow, uint32_t oh, uint8_t* direct_out) {
+    infur_ctx* c = st->ctx;
+    infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
+    const size_t in_bytes = (size_t)w * h * 3, rgba_bytes = (size_t)ow * oh * 4, sc_bytes = (size_t)ow * oh * 3;
+    sl.id = frame_id;
+    sl.ow = ow;
+    sl.oh = oh;
+    sl.direct_out = direct_out;
+    // From here on work that reads / writes this slot's buffers is in flight.  The slot is handed out again by the next
+    // submit (head does not advance on failure) and slot_reserve may free its buffers, so every failing return below
+    // first waits for whatever was enqueued (quiesce).
+    auto quiesce = [&]() {
+        (void)hipStreamSynchronize(st->s_h2d);
+        (void)hipStreamSynchronize(lane->stream);
+        (void)hipStreamSynchronize(st->s_d2h);
+    };
 #define SUBMIT_CHK(expr)                                                                                                     \
     do {                                                                                                                     \
         hipError_t e__ = (expr);                                                                                             \
@@ -2482,27 +2539,95 @@ int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, ui
             return fail(c, INFUR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__);        \
         }                                                                                                                    \
     } while (0)
-        SUBMIT_CHK(hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
-        SUBMIT_CHK(hipEventRecord(sl.ev_h2d, st->s_h2d));
-        SUBMIT_CHK(hipStreamWaitEvent(lane->stream, sl.ev_h2d, 0));
-        uint8_t* d_rgba = (uint8_t*)sl.d_out;
-        uint8_t* d_sc = d_rgba + rgba_bytes;
-        uint32_t a = 0, b = 0;
-        sl.status = infur_frame_advance_dev(lane, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
-        if (sl.status != INFUR_OK) {
-            const std::string msg = lane->err;  // (quiesce must not lose the message)
-            quiesce();
-            c->err = msg;
-            return sl.status;
-        }
-        SUBMIT_CHK(hipEventRecord(sl.ev_comp, lane->stream));
-        SUBMIT_CHK(hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
+    SUBMIT_CHK(hipMemcpyAsync(sl.d_in, src, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
+    SUBMIT_CHK(hipEventRecord(sl.ev_h2d, st->s_h2d));
+    SUBMIT_CHK(hipStreamWaitEvent(lane->stream, sl.ev_h2d, 0));
+    uint8_t* d_rgba = (uint8_t*)sl.d_out;
+    uint8_t* d_sc = d_rgba + rgba_bytes;
+    uint32_t a = 0, b = 0;
+    sl.status = infur_frame_advance_dev(lane, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
+    if (sl.status != INFUR_OK) {
+        const std::string msg = lane->err;  // (quiesce must not lose the message)
+        quiesce();
+        c->err = msg;
+        return sl.status;
+    }
+    SUBMIT_CHK(hipEventRecord(sl.ev_comp, lane->stream));
+    SUBMIT_CHK(hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
+    if (direct_out)  // (the mask alone: a caller-owned destination has no room for the scaled frame)
+        SUBMIT_CHK(hipMemcpyAsync(direct_out, sl.d_out, rgba_bytes, hipMemcpyDeviceToHost, st->s_d2h));
+    else
         SUBMIT_CHK(hipMemcpyAsync(sl.h_out, sl.d_out, rgba_bytes + sc_bytes, hipMemcpyDeviceToHost, st->s_d2h));
-        SUBMIT_CHK(hipEventRecord(sl.ev_done, st->s_d2h));
+    SUBMIT_CHK(hipEventRecord(sl.ev_done, st->s_d2h));
 #undef SUBMIT_CHK
-        sl.busy = true;
-        st->head++;
+    sl.busy = true;
+    st->head++;
+    st->acquired = false;
+    return INFUR_OK;
+}
+
+// submit with optional zero-copy: pinned_src -- `bgr` is pinned and stays untouched until the frame is collected (the batch calls:
+// they return only when everything is done); direct_out -- pinned destination for the mask
+int32_t stream_submit_impl(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode, uint64_t frame_id,
+                           bool pinned_src, uint8_t* direct_out) {
+    if (!st || !st->ctx || !bgr) return INFUR_E_INVALID_ARG;  // (a stream whose context was destroyed is dead)
+    enter(st->ctx);
+    if (st->acquired) return fail(st->ctx, INFUR_E_INVALID_ARG, "a slot is acquired: commit it before submitting another frame");
+    infur_stream::Slot* sl = nullptr;
+    uint32_t ow = 0, oh = 0;
+    RETIF(stream_prepare(st, w, h, factor, &sl, &ow, &oh));
+    if (!pinned_src) memcpy(sl->h_in, bgr, (size_t)w * h * 3);  // the caller's buffer is free again when submit returns
+    return stream_enqueue(st, *sl, pinned_src ? bgr : sl->h_in, w, h, factor, mode, frame_id, ow, oh, direct_out);
+}
+}  // namespace
+
+int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
+                            uint64_t frame_id) {
+    try {
+        return stream_submit_impl(st, bgr, w, h, factor, mode, frame_id, false, nullptr);
+    } catch (const std::bad_alloc&) {
+        return fail(st ? st->ctx : nullptr, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(st ? st->ctx : nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
+}
+
+// ---- zero-copy ingest: the producer fills the ring's own pinned slot (ff-video/src/decoder.rs:156-165 reads into a reused BgrImage) ----
+int32_t infur_stream_acquire(infur_stream* st, uint32_t w, uint32_t h, float factor, uint8_t** bgr_slot) {
+    try {
+        if (!st || !st->ctx || !bgr_slot) return INFUR_E_INVALID_ARG;
+        enter(st->ctx);
+        *bgr_slot = nullptr;
+        infur_stream::Slot* sl = nullptr;
+        uint32_t ow = 0, oh = 0;
+        RETIF(stream_prepare(st, w, h, factor, &sl, &ow, &oh));  // (acquiring again re-sizes the same slot: nothing is in flight on it)
+        st->acquired = true;
+        st->acq_w = w;
+        st->acq_h = h;
+        st->acq_ow = ow;
+        st->acq_oh = oh;
+        st->acq_factor_bits = f32_bits(factor);
+        *bgr_slot = sl->h_in;
         return INFUR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(st ? st->ctx : nullptr, INFUR_E_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(st ? st->ctx : nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
+    }
+}
+
+int32_t infur_stream_commit(infur_stream* st, uint32_t w, uint32_t h, float factor, uint32_t mode, uint64_t frame_id) {
+    try {
+        if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
+        enter(st->ctx);
+        infur_ctx* c = st->ctx;
+        if (!st->acquired) return fail(c, INFUR_E_INVALID_ARG, "no slot is acquired");
+        if (w != st->acq_w || h != st->acq_h || f32_bits(factor) != st->acq_factor_bits)
+            return fail(c, INFUR_E_INVALID_ARG, "commit of a %ux%u frame (factor %g) into a slot acquired for %ux%u", w, h, (double)factor, st->acq_w, st->acq_h);
+        infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
+        if (!lane->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");  // (unloaded between acquire and commit)
+        infur_stream::Slot& sl = st->slots[st->head % st->slots.size()];
+        return stream_enqueue(st, sl, sl.h_in, w, h, factor, mode, frame_id, st->acq_ow, st->acq_oh, nullptr);
     } catch (const std::bad_alloc&) {
         return fail(st ? st->ctx : nullptr, INFUR_E_CAPACITY, "out of host memory");
     } catch (const std::exception& e) {
@@ -2528,16 +2653,65 @@ int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t cap, uint8_
     infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
     const size_t rgba_bytes = (size_t)sl.ow * sl.oh * 4, sc_bytes = (size_t)sl.ow * sl.oh * 3;
     if (rgba && cap < rgba_bytes) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", rgba_bytes, cap);
+    if (scaled && sl.direct_out) return fail(c, INFUR_E_INVALID_ARG, "this frame's mask went straight to a caller-owned buffer: the scaled frame was not kept");
     HIPCHK(c, hipEventSynchronize(sl.ev_done));
-    if (rgba) memcpy(rgba, sl.h_out, rgba_bytes);
+    if (rgba && rgba != sl.direct_out) memcpy(rgba, sl.direct_out ? sl.direct_out : sl.h_out, rgba_bytes);
     if (scaled) memcpy(scaled, sl.h_out + rgba_bytes, sc_bytes);
     if (frame_id) *frame_id = sl.id;
     if (ow) *ow = sl.ow;
     if (oh) *oh = sl.oh;
     sl.busy = false;
+    sl.direct_out = nullptr;
+    st->viewing = false;
     st->tail++;
     return INFUR_OK;
 }
+
+// ---- zero-copy egress: the oldest finished frame's mask (and scaled frame) in place, in the ring's pinned slot ----
+int32_t infur_stream_collect_view(infur_stream* st, const uint8_t** rgba, const uint8_t** scaled, uint64_t* frame_id, uint32_t* ow, uint32_t* oh) {
+    if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
+    enter(st->ctx);
+    infur_ctx* c = st->ctx;
+    if (st->head == st->tail) return fail(c, INFUR_E_INVALID_ARG, "no frame is pending");
+    infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
+    HIPCHK(c, hipEventSynchronize(sl.ev_done));
+    const size_t rgba_bytes = (size_t)sl.ow * sl.oh * 4;
+    if (rgba) *rgba = sl.direct_out ? sl.direct_out : sl.h_out;
+    if (scaled) *scaled = sl.direct_out ? nullptr : sl.h_out + rgba_bytes;
+    if (frame_id) *frame_id = sl.id;
+    if (ow) *ow = sl.ow;
+    if (oh) *oh = sl.oh;
+    st->viewing = true;  // the slot stays the consumer's until infur_stream_release (or a copying collect of the same frame)
+    return INFUR_OK;
+}
+
+int32_t infur_stream_release(infur_stream* st) {
+    if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
+    infur_ctx* c = st->ctx;
+    if (!st->viewing || st->head == st->tail) return fail(c, INFUR_E_INVALID_ARG, "no frame is being viewed");
+    infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
+    sl.busy = false;
+    sl.direct_out = nullptr;
+    st->viewing = false;
+    st->tail++;
+    return INFUR_OK;
+}
+
+// ---- pinned host memory for the caller's own frame / mask buffers: the batch calls move such buffers by DMA, without the
+//      pageable -> pinned staging copy (and back) they otherwise make ----
+int32_t infur_host_alloc(size_t bytes, void** p) {
+    if (!p || bytes == 0) return INFUR_E_INVALID_ARG;
+    *p = nullptr;
+    // portable: every device of the process may DMA it (a group's workers each move their own slice of one batch)
+    return hipHostMalloc(p, bytes, hipHostMallocPortable) == hipSuccess ? INFUR_OK : INFUR_E_CAPACITY;
+}
+
+int32_t infur_host_free(void* p) {
+    if (!p) return INFUR_OK;
+    return hipHostFree(p) == hipSuccess ? INFUR_OK : INFUR_E_INVALID_ARG;
+}
+
+uint32_t infur_host_is_pinned(const void* p) { return host_is_pinned(p) ? 1u : 0u; }
 
 // ---- frame batch ----
 int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const uint32_t* ws, const uint32_t* hs, uint32_t n,
@@ -2569,7 +2743,15 @@ int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const ui
         };
         for (uint32_t i = 0; i < n && rc == INFUR_OK; i++) {
             if (infur_stream_pending(st) >= 3) rc = collect_one();
-            if (rc == INFUR_OK) rc = infur_stream_submit(st, frames[i], ws[i], hs[i], factor, mode, i);
+            if (rc == INFUR_OK) {
+                // caller-owned PINNED buffers (infur_host_alloc) are moved by DMA directly -- this call returns only when every frame
+                // is done, so they are not touched behind the caller's back; pageable ones go through the ring's pinned slots
+                const bool pin_in = host_is_pinned(frames[i]);
+                uint32_t eow = 0, eoh = 0;
+                const bool dims_ok = infur_scale_out_dims(ws[i], hs[i], factor, &eow, &eoh) == INFUR_OK;
+                uint8_t* direct = (dims_ok && caps[i] >= (size_t)eow * eoh * 4 && host_is_pinned(rgba[i])) ? rgba[i] : nullptr;
+                rc = stream_submit_impl(st, frames[i], ws[i], hs[i], factor, mode, i, pin_in, direct);
+            }
         }
         while (rc == INFUR_OK && infur_stream_pending(st) > 0) rc = collect_one();
         if (rc != INFUR_OK) {  // frames may still be in flight into the caller's view of the ring: drop it, the next call builds a new one

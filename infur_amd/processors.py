@@ -439,19 +439,26 @@ class FramePath:
         self.ctx.check(rc)
         return rgba, scaled
 
-    def advance_batch(self, imgs, factor: float = 1.0):
-        """A batch of independent frames (BASELINE configs[3]) -> list of masks, in order."""
+    def advance_batch(self, imgs, factor: float = 1.0, outs=None):
+        """A batch of independent frames (BASELINE configs[3]) -> list of masks, in order.  ``outs``: caller-owned mask arrays to fill
+        (e.g. ``app.PinnedArray(...).array``: pinned frames and masks travel by DMA without the staging copies)."""
         L = self.ctx.L
         imgs = [_check_bgr(i) for i in imgs]
         n = len(imgs)
         f = float(np.float32(factor))
+        given = outs
         outs = []
-        for im in imgs:
+        for k, im in enumerate(imgs):
             ow, oh = C.c_uint32(0), C.c_uint32(0)
             rc = L.infur_scale_out_dims(im.shape[1], im.shape[0], f, C.byref(ow), C.byref(oh))
             if rc:
                 raise ScaleProcError(rc)
-            outs.append(np.empty((oh.value, ow.value, 4), np.uint8))
+            if given is not None:
+                if given[k].shape != (oh.value, ow.value, 4) or given[k].dtype != np.uint8 or not given[k].flags.c_contiguous:
+                    raise ValueError(f"outs[{k}] must be a contiguous uint8 array of shape {(oh.value, ow.value, 4)}")
+                outs.append(given[k])
+            else:
+                outs.append(np.empty((oh.value, ow.value, 4), np.uint8))
         fp = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
         op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         ws = (C.c_uint32 * n)(*[im.shape[1] for im in imgs])
@@ -509,17 +516,23 @@ class Group:
     def weights_broadcast(self, root: int = 0) -> None:
         self.check(self.L.infur_group_weights_broadcast(self.g, root))
 
-    def advance_batch(self, imgs, factor: float = 1.0, scale_mode: int = _lib.SCALE_NEAREST):
+    def advance_batch(self, imgs, factor: float = 1.0, scale_mode: int = _lib.SCALE_NEAREST, outs=None):
         imgs = [_check_bgr(i) for i in imgs]
         n = len(imgs)
         f = float(np.float32(factor))
+        given = outs
         outs = []
-        for im in imgs:
+        for k, im in enumerate(imgs):
             ow, oh = C.c_uint32(0), C.c_uint32(0)
             rc = self.L.infur_scale_out_dims(im.shape[1], im.shape[0], f, C.byref(ow), C.byref(oh))
             if rc:
                 raise ScaleProcError(rc)
-            outs.append(np.empty((oh.value, ow.value, 4), np.uint8))
+            if given is not None:
+                if given[k].shape != (oh.value, ow.value, 4) or given[k].dtype != np.uint8 or not given[k].flags.c_contiguous:
+                    raise ValueError(f"outs[{k}] must be a contiguous uint8 array of shape {(oh.value, ow.value, 4)}")
+                outs.append(given[k])
+            else:
+                outs.append(np.empty((oh.value, ow.value, 4), np.uint8))
         fp = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
         op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         ws = (C.c_uint32 * n)(*[im.shape[1] for im in imgs])

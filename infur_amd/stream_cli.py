@@ -25,8 +25,10 @@ def main(argv=None) -> int:
     ap.add_argument("--bilinear", action="store_true", help="bilinear Scale instead of the reference's nearest")
     ap.add_argument("--model", default="")
     ap.add_argument("--synthetic-weights", action="store_true")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f32s", "f32x", "f16"],
-                    help="f32: exact f32 MFMA; f32s: f32 tensors on the f16 matrix cores (hi+lo pairs), same logits, ~1.9x; f32x: f32s with the cross terms on the fp8 MFMA, logits 1.5e-4, ~2.1x; f16")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32s", "f32x", "f16hl", "f16"],
+                    help="f32: exact f32 MFMA; f32s: f32 tensors on the f16 matrix cores (hi+lo pairs), same logits, ~1.9x; f32x: f32s with the cross terms on the fp8 MFMA, logits 1.5e-4, ~2.1x; "
+                         "f16hl: three-byte tensors, logits 1.5e-4, ~2.5x; f16: logits 2e-3, ~4x")
+    ap.add_argument("--copy", action="store_true", help="the copying submit / collect calls instead of reading the pipe straight into the ring's pinned slots")
     ap.add_argument("--depth", type=int, default=2, help="frames in flight")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--input", default="-", help="raw bgr24 file (default stdin)")
@@ -53,21 +55,45 @@ def main(argv=None) -> int:
     src = RawVideoSource(fin, a.width, a.height, close_stream=a.input != "-")
     sp = StreamPath(ctx, depth=a.depth, scale_mode=_lib.SCALE_BILINEAR if a.bilinear else _lib.SCALE_NEAREST)
 
-    def frames():
-        img = src.empty_image()
+    n, t0 = 0, time.perf_counter()
+    if a.copy:
+        def frames():
+            img = src.empty_image()
+            while True:
+                try:
+                    fid = src.read_frame(img)
+                except VideoProcError as e:
+                    if e.kind == "FinishedNormally":
+                        return
+                    raise
+                yield fid, img  # submit() copies the frame into a pinned slot before returning
+
+        for _fid, rgba in sp.run(frames(), a.scale):
+            fout.write(memoryview(rgba).cast("B"))
+            n += 1
+    else:
+        # zero-copy: the pipe is read straight into the next pinned slot (the reference's decoder fills its reused BgrImage the same
+        # way, ff-video/src/decoder.rs:156-165) and the mask is written out of the pinned output slot
+        def drain_one():
+            _fid, rgba, _ = sp.collect_view()
+            fout.write(memoryview(rgba).cast("B"))
+            sp.release()
+
         while True:
+            if sp.pending() >= a.depth:
+                drain_one()
+                n += 1
+            slot = sp.acquire(a.width, a.height, a.scale)
             try:
-                fid = src.read_frame(img)
+                fid = src.read_frame(slot)
             except VideoProcError as e:
                 if e.kind == "FinishedNormally":
-                    return
+                    break
                 raise
-            yield fid, img  # submit() copies the frame into a pinned slot before returning
-
-    n, t0 = 0, time.perf_counter()
-    for _fid, rgba in sp.run(frames(), a.scale):
-        fout.write(memoryview(rgba).cast("B"))
-        n += 1
+            sp.commit(a.width, a.height, a.scale, fid)
+        while sp.pending():
+            drain_one()
+            n += 1
     fout.flush()
     el = time.perf_counter() - t0
     sys.stderr.write(f"infur stream: {n} frames in {el:.2f} s ({n / max(el, 1e-9):.1f} frames/s)\n")

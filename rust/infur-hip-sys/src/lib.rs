@@ -58,7 +58,7 @@ pub const INFUR_E_RCCL: i32 = 8;
 pub const INFUR_E_INVALID_ARG: i32 = 9;
 pub const INFUR_E_IO: i32 = 10;
 pub const INFUR_E_CAPACITY: i32 = 11;
-pub const INFUR_ABI_VERSION: u32 = 4;
+pub const INFUR_ABI_VERSION: u32 = 5;
 pub const INFUR_SCALE_NEAREST: u32 = 0;
 pub const INFUR_SCALE_BILINEAR: u32 = 1;
 pub const INFUR_DTYPE_F32: u32 = 0;
@@ -67,6 +67,9 @@ pub const INFUR_DTYPE_F16: u32 = 1;
 pub const INFUR_DTYPE_F32_SPLIT: u32 = 2;
 /// split mode with the two cross terms on the fp8 (e4m3) MX MFMA: logits ~1.5e-4 from f32, ~8 % faster than F32_SPLIT
 pub const INFUR_DTYPE_F32_SPLIT_FP8: u32 = 3;
+/// three-byte tensors (f16 hi + e5m2 lo planes written by the producer, staged by LDS-DMA), two MFMA units per product:
+/// logits ~1.5e-4 from f32 on heavy-tailed weights, ~2.5x the f32 MFMA rate (round 5; 4 is not an option value)
+pub const INFUR_DTYPE_F16_HL: u32 = 5;
 
 extern "C" {
     pub fn infur_abi_version() -> u32;
@@ -106,6 +109,16 @@ extern "C" {
     pub fn infur_stream_next_dims(s: *const infur_stream, frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
     pub fn infur_stream_collect(s: *mut infur_stream, rgba: *mut u8, cap: usize, scaled_bgr: *mut u8,
                                 frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
+    // zero-copy ingest / egress (ABI 5): the ring's pinned slots lent to the caller
+    pub fn infur_stream_acquire(s: *mut infur_stream, w: u32, h: u32, factor: f32, bgr_slot: *mut *mut u8) -> i32;
+    pub fn infur_stream_commit(s: *mut infur_stream, w: u32, h: u32, factor: f32, mode: u32, frame_id: u64) -> i32;
+    pub fn infur_stream_collect_view(s: *mut infur_stream, rgba: *mut *const u8, scaled_bgr: *mut *const u8,
+                                     frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
+    pub fn infur_stream_release(s: *mut infur_stream) -> i32;
+    // pinned host memory for caller-owned frame / mask buffers (moved by DMA by the batch calls)
+    pub fn infur_host_alloc(bytes: usize, p: *mut *mut c_void) -> i32;
+    pub fn infur_host_free(p: *mut c_void) -> i32;
+    pub fn infur_host_is_pinned(p: *const c_void) -> u32;
     /// n frames through one context's depth-3 ring, masks in frame order (BASELINE configs[3] on one GPU)
     pub fn infur_batch_advance(c: *mut infur_ctx, frames: *const *const u8, ws: *const u32, hs: *const u32, n: u32,
                                factor: f32, mode: u32, rgba: *const *mut u8, caps: *const usize,

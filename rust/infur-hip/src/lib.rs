@@ -61,6 +61,13 @@ impl Ctx {
         let msg = unsafe { CStr::from_ptr(sys::infur_last_error(self.0)) }.to_string_lossy().into_owned();
         HipError { code: rc, msg }
     }
+    /// the context's own message for `rc` (infur_last_error), falling back to the status string
+    fn from_ctx(ctx: &Ctx, rc: i32) -> Self {
+        let p = unsafe { sys::infur_last_error(ctx.0) };
+        if p.is_null() { return Self::status(rc); }
+        let msg = unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned();
+        if msg.is_empty() { Self::status(rc) } else { HipError { code: rc, msg } }
+    }
 }
 impl Drop for Ctx {
     fn drop(&mut self) { unsafe { sys::infur_ctx_destroy(self.0) } }
@@ -302,4 +309,51 @@ impl Processor for HipColorCode {
                                  img.pixels.as_mut_ptr() as *mut u8);
         }
     }
+}
+
+// ---------------------------------------------------------------- streaming ring with zero-copy slots (main.rs:27-99,105; ABI 5)
+/// The bounded queue of frames in flight (`sync_channel(2)`, main.rs:105) over `infur_stream_*`.  `next_slot` / `commit` let the
+/// decoder fill the ring's own pinned buffer in place -- what `ff-video/src/decoder.rs:156-165` does with its reused `BgrImage` --
+/// and `view` / `release` hand the finished mask out of the pinned output slot: no pageable <-> pinned copy on either side.
+/// UNTESTED like the rest of the crate (no Rust toolchain in the build image).
+pub struct HipStream { raw: *mut sys::infur_stream, ctx: Rc<Ctx>, depth: u32, mode: u32 }
+/// A finished frame in place in the ring's pinned output slot; the slot returns to the ring when the view is dropped.
+pub struct MaskView<'a> { stream: &'a mut HipStream, pub frame_id: u64, pub size: [usize; 2], pub rgba: &'a [u8], pub scaled_bgr: &'a [u8] }
+impl<'a> Drop for MaskView<'a> {
+    fn drop(&mut self) { unsafe { sys::infur_stream_release(self.stream.raw); } }
+}
+impl HipStream {
+    pub fn new(ctx: Rc<Ctx>, depth: u32) -> Result<Self, HipError> {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { sys::infur_stream_create(ctx.0, depth, &mut raw) };
+        if rc != sys::INFUR_OK { return Err(HipError::from_ctx(&ctx, rc)); }
+        Ok(Self { raw, ctx, depth, mode: sys::INFUR_SCALE_NEAREST })
+    }
+    pub fn pending(&self) -> u32 { unsafe { sys::infur_stream_pending(self.raw) } }
+    pub fn depth(&self) -> u32 { self.depth }
+    /// the next slot's pinned input buffer, `w * h * 3` bytes of packed bgr24 for the decoder to `read_exact` into
+    pub fn next_slot(&mut self, w: u32, h: u32, factor: f32) -> Result<&mut [u8], HipError> {
+        let mut p: *mut u8 = std::ptr::null_mut();
+        let rc = unsafe { sys::infur_stream_acquire(self.raw, w, h, factor, &mut p) };
+        if rc != sys::INFUR_OK { return Err(HipError::from_ctx(&self.ctx, rc)); }
+        Ok(unsafe { std::slice::from_raw_parts_mut(p, (w as usize) * (h as usize) * 3) })
+    }
+    pub fn commit(&mut self, w: u32, h: u32, factor: f32, frame_id: u64) -> Result<(), HipError> {
+        let rc = unsafe { sys::infur_stream_commit(self.raw, w, h, factor, self.mode, frame_id) };
+        if rc != sys::INFUR_OK { return Err(HipError::from_ctx(&self.ctx, rc)); }
+        Ok(())
+    }
+    /// waits for the oldest pending frame
+    pub fn view(&mut self) -> Result<MaskView<'_>, HipError> {
+        let (mut rgba, mut sc): (*const u8, *const u8) = (std::ptr::null(), std::ptr::null());
+        let (mut id, mut ow, mut oh) = (0u64, 0u32, 0u32);
+        let rc = unsafe { sys::infur_stream_collect_view(self.raw, &mut rgba, &mut sc, &mut id, &mut ow, &mut oh) };
+        if rc != sys::INFUR_OK { return Err(HipError::from_ctx(&self.ctx, rc)); }
+        let n = (ow as usize) * (oh as usize);
+        let (r, s) = unsafe { (std::slice::from_raw_parts(rgba, n * 4), std::slice::from_raw_parts(sc, n * 3)) };
+        Ok(MaskView { stream: self, frame_id: id, size: [ow as usize, oh as usize], rgba: r, scaled_bgr: s })
+    }
+}
+impl Drop for HipStream {
+    fn drop(&mut self) { unsafe { sys::infur_stream_destroy(self.raw) } }
 }

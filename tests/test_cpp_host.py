@@ -90,7 +90,7 @@ def test_cpp_pipeline_cli_matches_python_path(pipeline_cli, blob50, ctx, tmp_pat
     Model(ctx).control(ModelCmd.LoadBlob(blob50))
     fp = FramePath(ctx)
     want = b"".join(np.ascontiguousarray(fp.advance(f, 0.5)[0]).tobytes() for f in frames)
-    for extra in ([], ["--lanes", "2", "--depth", "3"], ["--app"]):
+    for extra in ([], ["--lanes", "2", "--depth", "3"], ["--app"], ["--copy"], ["--copy", "--lanes", "2", "--depth", "3"]):
         r = subprocess.run([pipeline_cli, "--width", "160", "--height", "96", "--scale", "0.5", "--model", str(p)] + extra,
                            input=clip + (b"" if extra else b"\x01\x02\x03"), capture_output=True, timeout=300)
         if extra:

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from infur_amd import weights as W
-from infur_amd.app import (AppCmd, ProcessingApp, RawVideoSource, StreamPath, SyntheticSource, VideoCmd,
+from infur_amd.app import (AppCmd, PinnedArray, ProcessingApp, RawVideoSource, StreamPath, SyntheticSource, VideoCmd,
                            VideoProcError)
 from infur_amd.processors import Context, FramePath, InfurError, ModelCmd, ValidScaleError
 from infur_amd import _lib
@@ -153,6 +153,108 @@ def test_streaming_equals_direct(ctx, model):
     sp.close()
 
 
+def test_zero_copy_streaming_equals_copying(ctx, model):
+    """VERDICT r4 item 2 (ABI 5): acquire / commit / collect_view / release lend the ring's PINNED slots to the caller -- the decoder
+    fills the frame in place (ff-video/src/decoder.rs:156-165 does that with its reused BgrImage), the mask is read in place.  Same
+    masks, same order as the copying calls; the two kinds may be mixed frame by frame; misuse is refused, not undefined."""
+    frames = [(i + 1, W.synth_frame(135, 240, index=i)) for i in range(7)]
+    sp = StreamPath(ctx, depth=2)
+    ref = list(sp.run(frames, 0.5))
+    got = list(sp.run_zero_copy(frames, 0.5))
+    assert [g[0] for g in got] == [f[0] for f in frames]
+    for (fid, a), (_, b) in zip(got, ref):
+        assert a.shape == (67, 120, 4) and (a == b).all(), fid
+    # a source that read()s straight into the slot: RawVideoSource.read_frame takes any writable array
+    clip = io.BytesIO(b"".join(f.tobytes() for _, f in frames))
+    src = RawVideoSource(clip, 240, 135)
+    out = []
+    for _ in frames:
+        if sp.pending() >= 2:
+            fid, rgba, _s = sp.collect_view()
+            out.append((fid, rgba.copy()))
+            sp.release()
+        slot = sp.acquire(240, 135, 0.5)
+        assert slot.shape == (135, 240, 3) and ctx.L.infur_host_is_pinned(slot.ctypes.data) == 1
+        fid = src.read_frame(slot)
+        sp.commit(240, 135, 0.5, fid)
+    while sp.pending():
+        fid, rgba, scaled = sp.collect_view(want_scaled=True)
+        assert scaled.shape == (67, 120, 3)
+        again = sp.collect_view()  # idempotent until released
+        assert again[0] == fid and again[1].ctypes.data == rgba.ctypes.data
+        out.append((fid, rgba.copy()))
+        sp.release()
+    assert [o[0] for o in out] == [f[0] for f in frames]
+    for (_, a), (_, b) in zip(out, ref):
+        assert (a == b).all()
+    # mixed: zero-copy in, copying out; copying in, view out
+    np.copyto(sp.acquire(240, 135, 0.5), frames[0][1])
+    sp.commit(240, 135, 0.5, 50)
+    sp.submit(frames[1][1], 0.5, 51)
+    fid, rgba, _s = sp.collect()
+    assert fid == 50 and (rgba == ref[0][1]).all()
+    fid, view, _s = sp.collect_view()
+    assert fid == 51 and (view == ref[1][1]).all()
+    fid2, rgba2, _s = sp.collect()  # a copying collect of the viewed frame releases it
+    assert fid2 == 51 and (rgba2 == ref[1][1]).all() and sp.pending() == 0
+    # misuse
+    with pytest.raises(InfurError) as e:
+        sp.commit(240, 135, 0.5, 1)  # nothing acquired
+    assert e.value.code == _lib.E_INVALID_ARG
+    with pytest.raises(InfurError):
+        sp.release()  # nothing viewed
+    sp.acquire(240, 135, 0.5)
+    with pytest.raises(InfurError) as e:
+        sp.commit(240, 136, 0.5, 1)  # not the acquired frame size
+    assert e.value.code == _lib.E_INVALID_ARG
+    with pytest.raises(InfurError) as e:
+        sp.submit(frames[0][1], 0.5, 2)  # a slot is acquired
+    assert e.value.code == _lib.E_INVALID_ARG
+    big = sp.acquire(480, 270, 1.0)  # acquiring again re-sizes the same slot
+    assert big.shape == (270, 480, 3)
+    np.copyto(big, W.synth_frame(270, 480, index=9))
+    sp.commit(480, 270, 1.0, 7)
+    np.copyto(sp.acquire(240, 135, 0.5), frames[2][1])
+    sp.commit(240, 135, 0.5, 8)
+    with pytest.raises(InfurError) as e:
+        sp.acquire(240, 135, 0.5)  # both slots in flight
+    assert e.value.code == _lib.E_CAPACITY
+    fid, rgba, _s = sp.collect_view()
+    assert fid == 7 and rgba.shape == (270, 480, 4) and (rgba == FramePath(ctx).advance(W.synth_frame(270, 480, index=9), 1.0)[0]).all()
+    sp.release()
+    assert sp.collect()[0] == 8
+    with pytest.raises(InfurError) as e:
+        sp.acquire(240, 135, -1.0)
+    assert e.value.code == _lib.E_INVALID_SCALE
+    sp.close()
+
+
+def test_batch_with_pinned_caller_buffers(ctx, model):
+    """frames and masks in memory from infur_host_alloc travel by DMA, without the pageable <-> pinned staging copies: same masks"""
+    imgs = [W.synth_frame(96 + 8 * (i % 3), 128, index=i) for i in range(7)]
+    fp = FramePath(ctx)
+    ref = fp.advance_batch(imgs, 0.5)
+    pin_in = [PinnedArray(im.shape) for im in imgs]
+    pin_out = [PinnedArray(r.shape) for r in ref]
+    for p, im in zip(pin_in, imgs):
+        np.copyto(p.array, im)
+    assert ctx.L.infur_host_is_pinned(pin_in[0].array.ctypes.data) == 1 and ctx.L.infur_host_is_pinned(imgs[0].ctypes.data) == 0
+    for o in pin_out:
+        o.array[...] = 7
+    got = fp.advance_batch([p.array for p in pin_in], 0.5, outs=[o.array for o in pin_out])
+    for g, o, r in zip(got, pin_out, ref):
+        assert g is o.array and (g == r).all()
+    # mixed: pinned frames, pageable masks and the other way round
+    got = fp.advance_batch([p.array for p in pin_in], 0.5)
+    assert all((g == r).all() for g, r in zip(got, ref))
+    for o in pin_out:
+        o.array[...] = 9
+    got = fp.advance_batch(imgs, 0.5, outs=[o.array for o in pin_out])
+    assert all((g == r).all() for g, r in zip(got, ref))
+    for p in pin_in + pin_out:
+        p.close()
+
+
 def test_streaming_full_size_throughput(ctx, model):
     """configs[2]: 1080p frames, scale 0.5, streamed from host memory; report frames/s incl. PCIe."""
     import time
@@ -201,3 +303,10 @@ def test_stream_cli_raw_bgr24_in_rgba_out(ctx, model, tmp_path):
     for g, f in zip(got, frames):
         ref, _ = fp.advance(f, 0.5)
         assert (g == ref).all()
+    # the default reads the pipe straight into the ring's pinned slots; --copy is the copying submit / collect path
+    fout2 = tmp_path / "masks_copy.rgba"
+    r = subprocess.run([sys.executable, "-m", "infur_amd.stream_cli", "--width", "160", "--height", "96", "--scale", "0.5", "--copy",
+                        "--synthetic-weights", "--input", str(fin), "--output", str(fout2)], cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert fout2.read_bytes() == fout.read_bytes()

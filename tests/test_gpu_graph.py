@@ -75,45 +75,73 @@ def test_stream_ring_with_graph_replay_equals_direct():
         sp.close()
 
 
-def test_capture_never_runs_on_a_stream_another_context_uses():
-    """the library lends streams from a per-device pool of eight, so the ninth context of a device shares the first one's.
-    A context with graph replay must not capture such a stream (another context's kernels, enqueued from another thread during the
-    capture, would be recorded into ITS graph and not executed): it moves to a private stream when replay is switched on.  Nine
-    contexts, replay on the first, a thread hammering frames through the ninth while the first captures and replays."""
+def _hammer_while_replaying(ctxs, first, other, blob, expect_capture):
     import threading
 
-    blob = W.synth_blob(depth=50)
     frames = [W.synth_frame(96, 128, index=i) for i in range(3)]
+    for c in (first, other):
+        Model(c).control(ModelCmd.LoadBlob(blob))
+    ref = [FramePath(other).advance(f, 1.0)[0] for f in frames]
+    stop, bad = threading.Event(), []
+
+    def hammer():
+        fp = FramePath(other)
+        k = 0
+        while not stop.is_set():
+            out, _ = fp.advance(frames[k % 3], 1.0)
+            if not (out == ref[k % 3]).all():
+                bad.append(k)
+            k += 1
+
+    t = threading.Thread(target=hammer)
+    t.start()
+    fp0 = FramePath(first)
+    try:
+        for it in range(30):
+            out, _ = fp0.advance(frames[it % 3], 1.0)
+            assert (out == ref[it % 3]).all(), it
+    finally:
+        stop.set()
+        t.join()
+    assert not bad
+    cap, rep, cached = first.graph_stats()
+    if expect_capture:
+        assert cap >= 1 and rep >= 10, (cap, rep, cached)
+    else:
+        assert cap == 0 and rep == 0, (cap, rep, cached)
+
+
+def test_capture_never_runs_on_a_stream_another_context_uses():
+    """ADVICE r3 + r4: the library lends streams from a per-device pool of eight, so the ninth context of a device shares the first
+    one's.  A context with graph replay must not capture such a stream (another context's kernels, enqueued from another thread
+    during the capture, would be recorded into ITS graph and not executed) -- and it must not swap its stream either (ABI 3-4 did:
+    a host that had read infur_ctx_stream() kept a stale handle).  ABI 5: the handle never changes; an already shared stream never
+    captures (frames run eagerly, correct); a stream reserved while its context is the only user is handed to nobody else."""
+    blob = W.synth_blob(depth=50)
+    # (a) nine contexts first, replay switched on afterwards on one whose stream is shared: stays eager, same handle, right results
     ctxs = [Context(device=0, dtype="f16") for _ in range(9)]
     try:
-        for c in (ctxs[0], ctxs[8]):
-            Model(c).control(ModelCmd.LoadBlob(blob))
-        ref = [FramePath(ctxs[8]).advance(f, 1.0)[0] for f in frames]
-        ctxs[0].check(ctxs[0].L.infur_ctx_set_graph_replay(ctxs[0].h, 1))
-        stop, bad = threading.Event(), []
-
-        def hammer():
-            fp = FramePath(ctxs[8])
-            k = 0
-            while not stop.is_set():
-                out, _ = fp.advance(frames[k % 3], 1.0)
-                if not (out == ref[k % 3]).all():
-                    bad.append(k)
-                k += 1
-
-        t = threading.Thread(target=hammer)
-        t.start()
-        fp0 = FramePath(ctxs[0])
-        try:
-            for it in range(30):
-                out, _ = fp0.advance(frames[it % 3], 1.0)
-                assert (out == ref[it % 3]).all(), it
-        finally:
-            stop.set()
-            t.join()
-        assert not bad
-        cap, rep, cached = ctxs[0].graph_stats()
-        assert cap >= 1 and rep >= 10, (cap, rep, cached)
+        L = ctxs[0].L
+        before = L.infur_ctx_stream(ctxs[0].h)
+        assert before == L.infur_ctx_stream(ctxs[8].h)  # the ninth context shares the first one's pool stream
+        ctxs[0].check(L.infur_ctx_set_graph_replay(ctxs[0].h, 1))
+        assert L.infur_ctx_stream(ctxs[0].h) == before
+        _hammer_while_replaying(ctxs, ctxs[0], ctxs[8], blob, expect_capture=False)
     finally:
         for c in ctxs:
+            c.close()
+    # (b) replay switched on while the context is alone on its stream: the slot is reserved, the ninth context gets another one,
+    #     the first captures and replays while the ninth hammers
+    first = Context(device=0, dtype="f16")
+    rest = []
+    try:
+        L = first.L
+        before = L.infur_ctx_stream(first.h)
+        first.check(L.infur_ctx_set_graph_replay(first.h, 1))
+        assert L.infur_ctx_stream(first.h) == before
+        rest = [Context(device=0, dtype="f16") for _ in range(8)]
+        assert all(L.infur_ctx_stream(c.h) != before for c in rest)
+        _hammer_while_replaying([first] + rest, first, rest[-1], blob, expect_capture=True)
+    finally:
+        for c in [first] + rest:
             c.close()

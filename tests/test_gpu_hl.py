@@ -1,0 +1,222 @@
+"""INFUR_DTYPE_F16_HL ("f16hl", round 5): three-byte tensors (f16 hi + e5m2 lo planes written by the producer's epilogue, staged by
+LDS-DMA), hi * hi on the f16 MFMA + both cross terms on the bf8 MX MFMA with the hi bytes taken by truncation from the f16 fragments
+(infur_amd/csrc/conv_hl.hip, hl_format.h).  The mode built for BOTH halves of north_star's sentence: logits within 1e-3 of the f32
+reference at f16-matrix-core rate.  Graded here against the torch-CPU oracle on the synthetic weights (max-abs / max-abs, like
+tests/test_gpu_split.py); the hostile parameter set, the float64 reference and the per-element metric are in tests/test_gpu_hostile.py.
+
+Measured on an MI355X (scripts/hl_check.py, scripts/hl_full_frame_probe.py; profiles/r05_f16hl_*): synthetic weights 320x240 direct
+convs 9.0e-5, F(4x4) 1.6e-4, F(6x6) (the default) 2.9e-4; 1920x1080 F(6x6) 3.2e-4.  Hostile 1920x1080: 1.5e-4 max-abs / 9.6e-3 per element."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from infur_amd import weights as W
+from infur_amd.processors import Context, FramePath, Model, ModelCmd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+HL_TOL = 6e-4        # logits, max-abs / max-abs, F(6x6) default (north_star: 1e-3)
+HL_TOL_DIRECT = 2e-4  # the product + tensor-format error alone (no Winograd transform amplifying it)
+HL_LAYER_TOL = 1e-3   # worst conv output of the per-layer read-back
+
+
+def rel_err(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (270, 480), (540, 960)])
+def test_hl_logits_and_mask(oracle, blob50, shape):
+    from oracle.infur_oracle import TorchModel
+
+    tm = TorchModel(blob50)
+    h, w = shape
+    fr = W.synth_frame(h, w, index=3)
+    c = Context(device=0, dtype="f16hl")
+    m = Model(c).control(ModelCmd.LoadBlob(blob50))
+    rgba, _ = FramePath(c).advance(fr, 1.0)
+    lo, la = m.lowres()
+    tl, ta = tm.forward_lowres(oracle.pack_normalize(fr))
+    e_out, e_aux = rel_err(lo, tl.numpy()), rel_err(la, ta.numpy())
+    print(f"f16hl R50 {w}x{h}: logits rel err out={e_out:.2e} aux={e_aux:.2e}")
+    assert e_out < HL_TOL and e_aux < HL_TOL
+    # post stage bit-exact given the logits this mode produced
+    assert (rgba == oracle.colorcode(oracle.upsample_bilinear(lo, h, w))).all()
+    # class map against the oracle's own logits: differences only where the top-2 gap is inside the band
+    ref = oracle.upsample_bilinear(tl.numpy(), h, w)
+    kr, _ = oracle.argmax(ref)
+    kg, _ = oracle.argmax(oracle.upsample_bilinear(lo, h, w))
+    srt = np.sort(np.maximum(ref, 0.0), axis=0)
+    gap = srt[-1] - srt[-2]
+    bad = kr != kg
+    print(f"   class map differs on {bad.mean():.5%} of pixels")
+    assert not (bad & (gap >= HL_TOL * np.abs(ref).max())).any()
+    assert bad.mean() < 1e-2
+    c.close()
+
+
+@pytest.mark.parametrize("tile", [-1, 4, 6])
+def test_hl_per_layer(oracle, blob50, tile):
+    """every conv output (read back through the three-byte format) against the torch-CPU restatement: direct 3x3 convs, F(4x4), F(6x6)"""
+    from oracle.infur_oracle import TorchModel
+
+    fr = W.synth_frame(135, 241, index=5)
+    taps = {}
+    TorchModel(blob50).forward_lowres(oracle.pack_normalize(fr), taps=taps)
+    c = Context(device=0, dtype="f16hl", keep_activations=True, winograd_tile=max(tile, 0), winograd_min_cin=0xFFFFFFFF if tile < 0 else 0)
+    m = Model(c).control(ModelCmd.LoadBlob(blob50))
+    out = []
+    m.advance(fr, out)
+    worst, wname = 0.0, ""
+    for i, spec in enumerate(W.graph(50)):
+        ref = taps[spec.name].numpy()
+        buf = np.empty(ref.shape, np.float32)
+        cc, hh, ww = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        c.check(c.L.infur_debug_read_activation(c.h, i, buf.ctypes.data, buf.size, C.byref(cc), C.byref(hh), C.byref(ww)))
+        assert (cc.value, hh.value, ww.value) == ref.shape
+        e = rel_err(buf, ref)
+        if e > worst:
+            worst, wname = e, spec.name
+        assert e < HL_LAYER_TOL, (spec.name, e)
+    print(f"f16hl tile {tile}: worst layer {worst:.2e} ({wname})")
+    c.close()
+
+
+def test_hl_direct_convs(oracle, blob50):
+    """no Winograd: the error of the products and of the tensor format alone"""
+    from oracle.infur_oracle import TorchModel
+
+    fr = W.synth_frame(240, 320, index=3)
+    tl, ta = TorchModel(blob50).forward_lowres(oracle.pack_normalize(fr))
+    c = Context(device=0, dtype="f16hl", winograd_min_cin=0xFFFFFFFF)
+    m = Model(c).control(ModelCmd.LoadBlob(blob50))
+    FramePath(c).advance(fr, 1.0)
+    lo, la = m.lowres()
+    e = max(rel_err(lo, tl.numpy()), rel_err(la, ta.numpy()))
+    print(f"f16hl direct convs 320x240: {e:.2e}")
+    assert e < HL_TOL_DIRECT
+    c.close()
+
+
+@pytest.mark.parametrize("wh", [(1, 1), (7, 5), (33, 17), (130, 66), (257, 129)])
+def test_hl_tiny_and_ragged_frames(oracle, blob50, wh):
+    """Degenerate sizes: 1-pixel feature maps, ragged GEMM tiles (rows past M land zeros by the DMA's bounds check), partial
+    Winograd tiles, the two-source form on ragged tiles."""
+    from oracle.infur_oracle import TorchModel
+
+    w, h = wh
+    fr = W.synth_frame(h, w, index=w + h)
+    c = Context(device=0, dtype="f16hl")
+    m = Model(c).control(ModelCmd.LoadBlob(blob50))
+    rgba, _ = FramePath(c).advance(fr, 1.0)
+    lo, la = m.lowres()
+    tl, ta = TorchModel(blob50).forward_lowres(oracle.pack_normalize(fr))
+    assert lo.shape == tuple(tl.shape)
+    assert rel_err(lo, tl.numpy()) < HL_TOL and rel_err(la, ta.numpy()) < HL_TOL
+    assert (rgba == oracle.colorcode(oracle.upsample_bilinear(lo, h, w))).all()
+    c.close()
+
+
+def test_hl_fused_forms_match_unfused(blob50):
+    """conv3 + downsample as one two-source launch and the fused stem + pool against the separate launches: the same arithmetic in
+    another summation order (and, for the stem, the f16-rate stem against the exact f32 one) -- inside the mode's own noise"""
+    fr = W.synth_frame(135, 240, index=2)
+    outs = []
+    for kw in (dict(), dict(fuse_downsample=False), dict(fuse_stem_pool=False)):
+        c = Context(device=0, dtype="f16hl", **kw)
+        m = Model(c).control(ModelCmd.LoadBlob(blob50))
+        FramePath(c).advance(fr, 1.0)
+        outs.append(m.lowres()[0].copy())
+        c.close()
+    for o in outs[1:]:
+        e = rel_err(o, outs[0].astype(np.float64))
+        print(f"f16hl fused vs unfused: {e:.2e}")
+        assert e < HL_TOL
+
+
+def test_hl_large_and_small_values(oracle):
+    """activations scaled by 100 and by 10^4 through the stem (tests/test_gpu_split.py::test_split_activation_range): the format has
+    f16's exponent range and no tensor-level scale -- x100 keeps the mode's accuracy; x10^4 puts activations beyond f16's 65504, where
+    MODE.FP16_OVFL clamps the conversions: finite logits, no inf / NaN poisoning.  And a model scaled DOWN by 2^-8 keeps it too."""
+    from oracle.infur_oracle import TorchModel
+
+    fr = W.synth_frame(64, 96, index=2)
+    for gain, accurate in ((2.0 ** -8, True), (100.0, True), (1.0e4, False)):
+        tensors = [(s, w * np.float32(gain), b * np.float32(gain)) if s.name == "backbone.conv1" else (s, w, b)
+                   for s, w, b in W.synth_tensors(depth=50)]
+        blob = W.pack_blob(tensors, 50, W.NUM_CLASSES, True)
+        c = Context(device=0, dtype="f16hl")
+        m = Model(c).control(ModelCmd.LoadBlob(blob))
+        FramePath(c).advance(fr, 1.0)
+        lo, _ = m.lowres()
+        assert np.isfinite(lo).all()
+        if accurate:
+            tl, _ = TorchModel(blob).forward_lowres(oracle.pack_normalize(fr))
+            e = rel_err(lo, tl.numpy())
+            print(f"f16hl activations x{gain:g}: rel err {e:.2e}")
+            assert e < HL_TOL
+        c.close()
+
+
+SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from infur_amd import weights as W
+from infur_amd.processors import Context, FramePath, Model, ModelCmd
+blob = W.synth_blob()
+out = {}
+c = Context(device=0, dtype="f16hl")
+m = Model(c).control(ModelCmd.LoadBlob(blob))
+for i, (h, w) in enumerate(((135, 241), (97, 61))):
+    fr = W.synth_frame(h, w, index=4 + i)
+    rgba, _ = FramePath(c).advance(fr, 1.0)
+    lo, la = m.lowres()
+    out[f"lo{i}"] = lo; out[f"la{i}"] = la; out[f"rgba{i}"] = rgba
+c.close()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_hl_tile_configurations_are_bit_identical(tmp_path):
+    """the seven forms of conv_hl_kernel (tile shape, wave layout, ring depth, with / without residual prefetch) walk K in the same
+    order: forced one by one (INFUR_CONV_CFG) and autotuned they must give the same bits"""
+    def run(cfg, path):
+        env = dict(os.environ)
+        env.pop("INFUR_CONV_CFG", None)
+        if cfg is not None:
+            env["INFUR_CONV_CFG"] = str(cfg)
+        subprocess.run([sys.executable, "-c", SCRIPT, ROOT, path], check=True, env=env, timeout=300)
+        return np.load(path)
+
+    ref = run(0, str(tmp_path / "cfg0.npz"))
+    for cfg in (5, 6, 11, 12, 13, 14, None):
+        got = run(cfg, str(tmp_path / f"cfg{cfg}.npz"))
+        for k in ref.files:
+            assert (ref[k].view(np.uint8) == got[k].view(np.uint8)).all(), (cfg, k)
+
+
+def test_hl_resnet101_batch_and_stream(oracle):
+    """FCN-ResNet101 in the three-byte mode through the batch call and the streaming ring"""
+    from oracle.infur_oracle import TorchModel
+
+    from infur_amd.app import StreamPath
+
+    blob = W.synth_blob(depth=101)
+    tm = TorchModel(blob)
+    c = Context(device=0, dtype="f16hl")
+    m = Model(c).control(ModelCmd.LoadBlob(blob))
+    frames = [W.synth_frame(96, 160, index=i) for i in range(3)]
+    masks = FramePath(c).advance_batch(frames, 1.0)
+    lo, _ = m.lowres()
+    assert rel_err(lo, tm.forward_lowres(oracle.pack_normalize(frames[-1]))[0].numpy()) < 1e-3
+    sp = StreamPath(c, depth=2)
+    outs = list(sp.run(enumerate(frames), 1.0))
+    assert [fid for fid, _ in outs] == [0, 1, 2]
+    for (_, rgba), got in zip(outs, masks):
+        assert (rgba == got).all()
+    sp.close()
+    c.close()

@@ -35,11 +35,17 @@ pytestmark = pytest.mark.gpu
 # The logits bar is north_star's 1e-3 for every f32-grade mode.  VERDICT r3 asked for <= 1e-2 per element from a mode at f16-MFMA
 # rate: f32s has it with 10x room; f32x sits AT it (7e-3 .. 1.03e-2 depending on the Winograd tile -- test_f32x_tiles below holds
 # F(4x4) to 1e-2 and the F(6x6) default to 1.5e-2, and says so).  Per-layer bars: the measured values with ~3x head-room.
-LOGIT_BAR = {"f32": 1e-3, "f32s": 1e-3, "f32x": 1e-3, "f16": 5e-3}
-LAYER_BAR = {"f32": 3e-5, "f32s": 1e-4, "f32x": 1e-3, "f16": 1.5e-2}
-ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 1.5e-2, "f16": 0.5}  # worst per-element relative error over |ref| > 1e-2 max |ref|
+#   f16hl  1.5e-04 | 9.6e-03 (F(6x6) default; F(4x4) 1.2e-04 | 9.5e-03; per-layer path, direct convs 1.1e-04 | 8.2e-03)
+#                                                          5.1e-04      round 5: three-byte tensors (f16 hi + e5m2 lo planes), two MFMA units per
+#                                                                      product, every operand staged by LDS-DMA: VERDICT r4's bars -- logits 1e-3
+#                                                                      AND 1e-2 per element on this set -- at 1.2x the f32x rate.  The per-element
+#                                                                      figure is the format's: the simulation with EXACT products on three-byte
+#                                                                      tensors reads 4.6e-3 at 320x240 (scripts/sim_hl_assign.py), this mode 6.7e-3
+LOGIT_BAR = {"f32": 1e-3, "f32s": 1e-3, "f32x": 1e-3, "f16": 5e-3, "f16hl": 1e-3}
+LAYER_BAR = {"f32": 3e-5, "f32s": 1e-4, "f32x": 1e-3, "f16": 1.5e-2, "f16hl": 1.5e-3}
+ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 1.5e-2, "f16": 0.5, "f16hl": 1e-2}  # worst per-element relative error over |ref| > 1e-2 max |ref|
 # the per-layer read-back sees every conv output, incl. branch-internal tensors with few large elements: its per-element bar is wider
-LAYER_ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 3e-2, "f16": 0.6}
+LAYER_ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 3e-2, "f16": 0.6, "f16hl": 4e-2}
 
 
 @pytest.fixture(scope="module")
@@ -54,7 +60,7 @@ def ref64(hostile_blob):
     return TorchModel(hostile_blob, float64=True)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f32s", "f32x", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32s", "f32x", "f16", "f16hl"])
 def test_per_layer_on_hostile_parameters(hostile_blob, ref64, oracle, dtype):
     fr = H.saturated_frame(240, 320)
     taps = {}
@@ -88,7 +94,7 @@ def test_whole_frame_1080p_on_hostile_parameters(hostile_blob, ref64, oracle):
     fr = H.saturated_frame(1080, 1920, index=2)
     ref, ref_aux = ref64.forward_lowres(oracle.pack_normalize(fr))
     ref, ref_aux = ref.numpy(), ref_aux.numpy()
-    for dtype in ("f32", "f32s", "f32x", "f16"):
+    for dtype in ("f32", "f32s", "f32x", "f16", "f16hl"):
         c = Context(device=0, dtype=dtype)
         m = Model(c).control(ModelCmd.LoadBlob(hostile_blob))
         rgba, _ = FramePath(c).advance(fr, 1.0)

@@ -108,3 +108,52 @@ def test_epilogue_staging_reads():
     assert staging_read_conflicts(4 * 128 + 16, 16) == 0
     assert staging_read_conflicts(2 * 128 + 16, 8) == 32
     assert min(staging_read_conflicts(256 + pad, 8) for pad in range(0, 272, 16)) == 32
+
+
+# ---- conv_hl.hip (INFUR_DTYPE_F16_HL): 64-byte hi rows and 32-byte lo rows of a 32-channel K step, DMA pieces lane-linear ----
+def hl_swz64(row):
+    return (row >> 2) & 3
+
+
+def hl_swz32(row):
+    return (row >> 3) & 1
+
+
+@pytest.mark.parametrize("blocks", [1, 2, 4])
+def test_conv_hl_fragment_reads_are_conflict_free(blocks):
+    """lane (row r = lane & 31, half h = lane >> 5) reads hi chunk 2 h + kk (kk = 0, 1) and lo chunk h of its row; a wave's row blocks are
+    32 rows apart, which leaves both swizzles unchanged"""
+    for blk in range(blocks):
+        for kk in range(2):
+            assert extra_cycles_b128(lambda l: ((blk * 32 + (l & 31)) * 64 + (((2 * (l >> 5) + kk) ^ hl_swz64(l & 31)) * 16))) == 0
+        assert extra_cycles_b128(lambda l: ((blk * 32 + (l & 31)) * 32 + (((l >> 5) ^ hl_swz32(l & 31)) * 16))) == 0
+    # negative controls: the same reads without the swizzles collide (4-way on the 64-byte rows, 2-way on the 32-byte rows)
+    assert extra_cycles_b128(lambda l: (l & 31) * 64 + (2 * (l >> 5)) * 16) > 0
+    assert extra_cycles_b128(lambda l: (l & 31) * 32 + (l >> 5) * 16) > 0
+
+
+def test_conv_hl_dma_pieces_cover_the_image_exactly_once():
+    """a hi piece = rows 16 p .. 16 p + 15 (lane l: row l >> 2 at position l & 3 = data chunk (l & 3) ^ swz64(row)), a lo piece = rows 32 p ..
+    32 p + 31 (lane l: row l >> 1 at position l & 1): every (row, data chunk) of the image is written once, at the address the fragment
+    reads look for it"""
+    for rows in (128, 256):
+        where = {}
+        for p in range(rows // 16):
+            for l in range(64):
+                row = 16 * p + (l >> 2)
+                chunk = (l & 3) ^ hl_swz64(row)
+                addr = p * 1024 + l * 16
+                assert (row, chunk) not in where
+                where[(row, chunk)] = addr
+        for row in range(rows):
+            for q in range(4):
+                assert where[(row, q)] == row * 64 + ((q ^ hl_swz64(row)) * 16)
+        where = {}
+        for p in range(rows // 32):
+            for l in range(64):
+                row = 32 * p + (l >> 1)
+                chunk = (l & 1) ^ hl_swz32(row)
+                where[(row, chunk)] = p * 1024 + l * 16
+        for row in range(rows):
+            for q in range(2):
+                assert where[(row, q)] == row * 32 + ((q ^ hl_swz32(row)) * 16)

@@ -24,14 +24,14 @@ struct Args {
     int device = 0;
     float scale = 1.0f;
     uint64_t synthetic = 0;
-    bool app = false, quiet = false;
+    bool app = false, quiet = false, copy = false;
     std::string model, input = "-", output = "-";
 };
 
 int usage(const char* msg) {
     std::fprintf(stderr,
-                 "%s\nusage: infur_pipeline --width W --height H --model PATH [--scale F] [--bilinear] [--dtype f32|f32s|f32x|f16]\n"
-                 "       [--depth N] [--lanes N] [--device D] [--input FILE|-] [--output FILE|-|none] [--synthetic N] [--app] [--quiet]\n",
+                 "%s\nusage: infur_pipeline --width W --height H --model PATH [--scale F] [--bilinear] [--dtype f32|f32s|f32x|f16|f16hl]\n"
+                 "       [--depth N] [--lanes N] [--device D] [--input FILE|-] [--output FILE|-|none] [--synthetic N] [--app] [--copy] [--quiet]\n",
                  msg);
     return 2;
 }
@@ -55,6 +55,7 @@ int main(int argc, char** argv) {
         else if (k == "--output") a.output = val();
         else if (k == "--synthetic") a.synthetic = std::strtoull(val(), nullptr, 10);
         else if (k == "--app") a.app = true;
+        else if (k == "--copy") a.copy = true;
         else if (k == "--quiet") a.quiet = true;
         else if (k == "--dtype") {
             const std::string d = val();
@@ -62,6 +63,7 @@ int main(int argc, char** argv) {
             else if (d == "f32s") a.dtype = INFUR_DTYPE_F32_SPLIT;
             else if (d == "f32x") a.dtype = INFUR_DTYPE_F32_SPLIT_FP8;
             else if (d == "f16") a.dtype = INFUR_DTYPE_F16;
+            else if (d == "f16hl") a.dtype = INFUR_DTYPE_F16_HL;
             else return usage("unknown --dtype");
         } else return usage(("unknown argument " + k).c_str());
     }
@@ -163,8 +165,11 @@ int main(int argc, char** argv) {
                     return 1;
                 }
         t0 = std::chrono::steady_clock::now();
-        const infur::Status s = sp.run(
-            *src, a.scale, [&](uint64_t, const infur::ColorImage& m) { if (fout) std::fwrite(m.rgba.data(), 1, m.rgba.size(), fout); }, &n);
+        // default: the pipe is read straight into the ring's pinned slots and the masks are written out of them (--copy: the copying
+        // submit / collect calls, one pageable <-> pinned memcpy per frame and direction)
+        const infur::Status s =
+            a.copy ? sp.run(*src, a.scale, [&](uint64_t, const infur::ColorImage& m) { if (fout) std::fwrite(m.rgba.data(), 1, m.rgba.size(), fout); }, &n)
+                   : sp.run_zero_copy(*src, a.scale, [&](const infur::StreamPath::View& v) { if (fout) std::fwrite(v.rgba, 1, (size_t)v.width * v.height * 4, fout); }, &n);
         if (s != INFUR_OK) {
             std::fprintf(stderr, "infur_pipeline: after %llu frames: %s\n", (unsigned long long)n,
                          s == INFUR_E_IO ? "short read on the frame stream" : ctx.last_error().c_str());
