@@ -15,7 +15,9 @@ rm -rf $OUT; mkdir -p $OUT
 ( while true; do rocm-smi --showpower --showclocks --csv 2>/dev/null | tail -n +2 | sed "s/^/$(date +%s.%N),/"; sleep 0.2; done ) > $OUT/smi.csv &
 SMI=$!
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --dtype $DT --no-split --no-side --no-cpu-baseline $EXTRA > $OUT/bench_trace.json 2> $OUT/trace.err
+# frames in flight of the "default" trace: what bench.py itself uses for this arithmetic (3; F16_CONTEXTS = 2 for the f16 mode's side object)
+CTX=3; [ $DT = f16 ] && CTX=2
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --dtype $DT --contexts-per-gpu $CTX --no-split --no-side --no-cpu-baseline $EXTRA > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"
 kill $SMI 2>/dev/null
 # The default command keeps several frames in flight (--contexts-per-gpu, default 3): kernels of the streams time-share the chip, so the

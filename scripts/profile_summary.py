@@ -63,7 +63,12 @@ def main():
     ks = find(os.path.join(d, "trace"), "*kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(out, f"{tag}_kernel_stats.csv"))
-        md += ["## kernel trace (`rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline`)", "",
+        nctx = 3
+        try:
+            nctx = int(json.loads(open(os.path.join(d, "bench_trace.json")).read().strip().splitlines()[-1])["config"].get("contexts_per_gpu", 3))
+        except Exception:  # noqa: BLE001
+            pass
+        md += [f"## kernel trace (`rocprofv3 --kernel-trace --stats -- python bench.py --contexts-per-gpu {nctx} --no-cpu-baseline`: {nctx} frames in flight)", "",
                "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
         for r in csv.DictReader(open(ks)):
             md.append(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
@@ -77,7 +82,7 @@ def main():
         shutil.copy(ks2, os.path.join(out, f"{tag}_solo_kernel_stats.csv"))
         md += ["## kernel trace, one context (`… bench.py --contexts-per-gpu 1`): one kernel at a time -- these average durations are the ones",
                "that must agree with the HIP-event durations of bench.py's roofline frame (which runs alone); the table above is the",
-               "default command with three frames in flight (--contexts-per-gpu 3), where kernels of the streams time-share the chip", "",
+               "command the bench line is measured with (several frames in flight, see its caption), where kernels of the streams time-share the chip", "",
                "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
         for r in csv.DictReader(open(ks2)):
             md.append(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
@@ -110,13 +115,15 @@ def main():
     if gr:
         md += ["## MFMA utilisation (`--pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES`)", "",
                "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
-               "clock = GRBM_GUI_ACTIVE / 8 / duration.", "", "| kernel | launches | MfmaUtil % (time-weighted) | clock GHz |", "|---|---|---|---|"]
+               "clock = GRBM_GUI_ACTIVE / 8 / duration.  A clock ABOVE 2.4 GHz (the part's maximum) is an artefact of short kernels: GRBM_GUI_ACTIVE",
+               "keeps counting through launch / drain time that the kernel's own duration does not contain; read such rows' MfmaUtil as a lower bound.",
+               "", "| kernel | launches | MfmaUtil % (time-weighted) | clock GHz |", "|---|---|---|---|"]
         for k, disp in sorted(gr.items()):
             num = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for v in disp.values())
             den = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in disp.values()) / 8.0 * 1024.0
             clk = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in disp.values()) / 8.0 / max(sum(v["_dur"] for v in disp.values()), 1)
             if den > 0 and num > 0:
-                md.append(f"| `{k}` | {len(disp)} | {100.0 * num / den:.1f} | {clk:.2f} |")
+                md.append(f"| `{k}` | {len(disp)} | {100.0 * num / den:.1f} | {clk:.2f}{' (artefact)' if clk > 2.45 else ''} |")
         md.append("")
     if sq:
         md += ["## SQ wave states (`--pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT`)", "",
