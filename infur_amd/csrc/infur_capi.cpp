@@ -33,12 +33,13 @@
 
 #include "blob_dir.h"
 #include "infur_ctx.h"
+#include "infur_rt.h"
 #include "kernels.h"
 #include "onnx_reader.h"
 
 using namespace infur;
 
-namespace {
+namespace infur {
 
 int32_t fail(infur_ctx* c, int32_t code, const char* fmt, ...) {
     if (c) {
@@ -51,20 +52,6 @@ int32_t fail(infur_ctx* c, int32_t code, const char* fmt, ...) {
     }
     return code;
 }
-
-#define HIPCHK(c, expr)                                                                         \
-    do {                                                                                        \
-        hipError_t e__ = (expr);                                                                \
-        if (e__ != hipSuccess)                                                                  \
-            return fail((c), INFUR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
-                        __FILE__, __LINE__);                                                    \
-    } while (0)
-
-#define RETIF(expr)                 \
-    do {                            \
-        int32_t rc__ = (expr);      \
-        if (rc__ != INFUR_OK) return rc__; \
-    } while (0)
 
 int32_t ensure(infur_ctx* c, Buf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return INFUR_OK;
@@ -121,7 +108,6 @@ void pool_free(infur_ctx* c) {
 // A long-lived context that has seen several frame sizes (the GUI's scale slider) would otherwise keep the
 // largest arena forever: once kPoolTrimAfter consecutive frames had the same size, buffers no frame of that
 // run has used are returned to the device.  hipFree synchronises, so nothing in flight can still touch them.
-constexpr uint32_t kPoolTrimAfter = 4;
 void pool_trim(infur_ctx* c) {
     size_t kept = 0;
     for (auto& b : c->pool) {
@@ -149,27 +135,12 @@ int32_t talloc(infur_ctx* c, int h, int w, int ch, int es, Tensor* t) {
     return INFUR_OK;
 }
 
-inline bool ctx_f16(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F16; }
-// GEMM arithmetic of launch_conv_igemm: 0 f32 MFMA, 1 f16, 2 f32 tensors split into f16 pairs
-// (INFUR_DTYPE_F32_SPLIT_FP8 is the split mode everywhere except inside the GEMM: conv_mode() = 3 selects its MFMA sequence,
-//  its weight rows and its own tuning entries)
-inline bool ctx_fp8x(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F32_SPLIT_FP8; }
-inline int ctx_mode(const infur_ctx* c) { return ctx_fp8x(c) ? (int)INFUR_DTYPE_F32_SPLIT : (int)c->opt.compute_dtype; }
-inline int conv_mode(const infur_ctx* c) { return ctx_fp8x(c) ? 3 : ctx_mode(c); }
-// INFUR_DTYPE_F16_HL (= conv mode 5): three-byte tensors (f16 hi + e5m2 lo planes), conv_hl.hip
-inline bool ctx_hl(const infur_ctx* c) { return c->opt.compute_dtype == INFUR_DTYPE_F16_HL; }
-inline int act_es(const infur_ctx* c) { return ctx_f16(c) ? 2 : (ctx_hl(c) ? 3 : 4); }
-
 // ---- roctx ranges ----
 // The reference wraps its stages in `tracing` spans / events (infur/src/main.rs:18-24, RUST_LOG); here INFUR_ROCTX=1 makes every
 // stage and layer launch a named roctx range ("<layer> [<kernel>]", inside "infur frame"), so that
 // `rocprofv3 --marker-trace --kernel-trace` shows which layer a kernel belongs to.  The library is taken by dlopen at the first
 // use (no link-time dependency; without it, or without the variable, a range costs one predictable branch).  Ranges are host
 // side: they bracket the ENQUEUE of a launch, so look at them with graph replay off (the default).
-struct Roctx {
-    int (*push)(const char*) = nullptr;
-    int (*pop)() = nullptr;
-};
 const Roctx* roctx() {
     static Roctx r;
     static std::once_flag once;
@@ -191,52 +162,33 @@ const Roctx* roctx() {
     });
     return ok ? &r : nullptr;
 }
-struct RoctxRange {
-    const Roctx* rx;
-    explicit RoctxRange(const char* name) : rx(roctx()) {
-        if (rx) rx->push(name);
-    }
-    ~RoctxRange() {
-        if (rx) rx->pop();
-    }
-    RoctxRange(const RoctxRange&) = delete;
-    RoctxRange& operator=(const RoctxRange&) = delete;
-};
-
 // ---- profiling ----
-struct ProfScope {
-    infur_ctx* c;
-    bool on;
-    const Roctx* rx;
-    ProfRec r;
-    ProfScope(infur_ctx* c_, const std::string& name, const char* kernel, double flops, double bytes,
-              double algo_flops = -1.0)
-        : c(c_), on(c_->opt.profile != 0), rx(roctx()) {
-        if (rx) rx->push((name + " [" + kernel + "]").c_str());
-        if (!on) return;
-        r.name = name;
-        r.kernel = kernel;
-        r.flops = flops;
-        r.bytes = bytes;
-        r.algo_flops = algo_flops < 0.0 ? flops : algo_flops;
-        for (hipEvent_t* e : {&r.e0, &r.e1}) {
-            if (!c->ev_free.empty()) {
-                *e = c->ev_free.back();
-                c->ev_free.pop_back();
-            } else {
-                (void)hipEventCreate(e);
-            }
+ProfScope::ProfScope(infur_ctx* c_, const std::string& name, const char* kernel, double flops, double bytes, double algo_flops)
+    : c(c_), on(c_->opt.profile != 0), rx(roctx()) {
+    if (rx) rx->push((name + " [" + kernel + "]").c_str());
+    if (!on) return;
+    r.name = name;
+    r.kernel = kernel;
+    r.flops = flops;
+    r.bytes = bytes;
+    r.algo_flops = algo_flops < 0.0 ? flops : algo_flops;
+    for (hipEvent_t* e : {&r.e0, &r.e1}) {
+        if (!c->ev_free.empty()) {
+            *e = c->ev_free.back();
+            c->ev_free.pop_back();
+        } else {
+            (void)hipEventCreate(e);
         }
-        (void)hipEventRecord(r.e0, c->stream);
     }
-    ~ProfScope() {
-        if (on) {
-            (void)hipEventRecord(r.e1, c->stream);
-            c->prof.push_back(r);
-        }
-        if (rx) rx->pop();
+    (void)hipEventRecord(r.e0, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (on) {
+        (void)hipEventRecord(r.e1, c->stream);
+        c->prof.push_back(r);
     }
-};
+    if (rx) rx->pop();
+}
 
 void prof_reset(infur_ctx* c) {
     for (auto& r : c->prof) {
@@ -250,7 +202,6 @@ void prof_reset(infur_ctx* c) {
 // predict_onnx.rs:128 `f32::from(v) * 1f32 / 255f32`, :131-136 `(x - mean) * (1/std)`;
 // ColorNorm::new_torchvision_rgb :175-180.  volatile keeps every rounding step.
 // the table the stem kernels index with a pixel's bytes: the Float pre-proc, or the identity for Uint8-input models
-inline const float* stem_lut(const infur_ctx* c) { return c->input_u8 ? c->d_u8_lut : c->d_pre_lut; }
 
 void build_pre_lut(float* lut) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
@@ -316,7 +267,6 @@ uint32_t f32_as_u32(float v) {  // Rust `as u32`: saturating, NaN -> 0
     return (uint32_t)v;
 }
 
-int conv_out(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
 
 // output tile of the Winograd convs: the caller's choice, else F(6x6): 5.06x fewer MFMA FLOPs than the direct 3x3 (F(4x4):
 // 4x) and 1.9x instead of 2.27x the tensor in transform traffic.  Measured against the f32 CPU oracle (scripts/
@@ -377,10 +327,9 @@ void model_free(infur_ctx* c) {
     pool_release_all(c);
 }
 
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // the post stage's view of head k (0 = out, 1 = aux): plain logits, or u8 codes to be dequantised after the interpolation
-static UpQuant head_quant(const infur_ctx* c, int k) {
+UpQuant head_quant(const infur_ctx* c, int k) {
     UpQuant q;
     if (c->quant && c->q_resize_u8) {
         q.on = 1;
@@ -604,87 +553,7 @@ int32_t model_load_dev(infur_ctx* c, const void* d_blob, size_t len) {
     return INFUR_OK;
 }
 
-// ---- tile configuration of the conv kernel for one problem shape ----
-// The first time a shape is seen (a new frame size), every candidate configuration is launched
-// for real on the actual operands and timed with HIP events; the fastest is remembered for the
-// context's lifetime.  All configurations give bit-identical outputs, so the trial launches are
-// simply redundant evaluations of the layer.
-struct EventPair {  // the tuner's two events, released on every return path
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t create() {
-        hipError_t e = hipEventCreate(&e0);
-        return e != hipSuccess ? e : hipEventCreate(&e1);
-    }
-    ~EventPair() {
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    }
-};
-
-int32_t pick_cfg(infur_ctx* c, const ConvArgs& a, int mode, int out_f32, int* cfg) {
-    *cfg = conv_igemm_default_config(a);
-    if (mode == 5 && !conv_igemm_config_valid(a, *cfg, mode, out_f32)) *cfg = 0;  // (128 x 128: valid for every mode-5 shape)
-    // test hook: INFUR_CONV_CFG=<k> forces configuration k wherever it is a candidate
-    static const int forced = getenv("INFUR_CONV_CFG") ? atoi(getenv("INFUR_CONV_CFG")) : -1;
-    if (forced >= 0) {
-        if (conv_igemm_config_valid(a, forced, mode, out_f32)) *cfg = forced;
-        return INFUR_OK;
-    }
-    if (c->opt.no_autotune) return INFUR_OK;
-    const std::array<int, 13> key = {a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.stride, a.dil, a.batch,
-                                     a.res ? 1 : (a.in2 ? 2 : 0), mode, out_f32};
-    auto it = c->tuned.find(key);
-    if (it != c->tuned.end() && conv_igemm_config_valid(a, it->second, mode, out_f32)) {
-        *cfg = it->second;
-        return INFUR_OK;
-    }
-    EventPair ev;
-    HIPCHK(c, ev.create());
-    if (!c->tune_warm) {  // bring clocks and caches to their steady state before the first measurement
-        for (int r = 0; r < 12; r++) HIPCHK(c, launch_conv_igemm(a, mode, out_f32, *cfg, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->tune_warm = true;
-    }
-    float best = 1e30f;
-    std::vector<std::pair<int, float>> timed;
-    // (configuration 20 -- the BN = 256 form of conv3x3_halo.hip -- is not a tuning candidate: timed in isolation, with its operands
-    //  warm in the Infinity Cache, it beats the tiled `dmai` form on the long-K head convs by 2-4 %; inside a frame, where its
-    //  one-patch-image chunk boundaries meet HBM latency, it is 5-12 % slower (classifier.0 at 1080p 535 against 477 us).  It stays
-    //  selectable -- INFUR_CONV_CFG=20, INFUR_TUNE_HALO256=1 -- and bit-identical: tests/test_gpu_halo.py.)
-    static const bool tune_halo256 = getenv("INFUR_TUNE_HALO256") != nullptr;
-    for (int k = 0; k < conv_igemm_num_configs(); k++) {
-        if (!conv_igemm_config_valid(a, k, mode, out_f32)) continue;
-        if (k == 20 && !tune_halo256) continue;
-        // a candidate that cannot launch on this shape after all (invalid value) is skipped, not fatal: the layer still
-        // has the other configurations; anything else (a fault, a lost device) is an error of the frame
-        const hipError_t le = launch_conv_igemm(a, mode, out_f32, k, c->stream);  // warm-up (attributes, caches)
-        if (le == hipErrorInvalidValue) continue;
-        HIPCHK(c, le);
-        float fastest = 1e30f;
-        for (int r = 0; r < 4; r++) {  // minimum of 4 single-launch timings
-            HIPCHK(c, hipEventRecord(ev.e0, c->stream));
-            HIPCHK(c, launch_conv_igemm(a, mode, out_f32, k, c->stream));
-            HIPCHK(c, hipEventRecord(ev.e1, c->stream));
-            HIPCHK(c, hipEventSynchronize(ev.e1));
-            float ms = 0;
-            HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
-            if (ms < fastest) fastest = ms;
-        }
-        timed.emplace_back(k, fastest);
-        if (fastest < best) {
-            best = fastest;
-            *cfg = k;
-        }
-    }
-    // Tie-break towards the larger tile: among the configurations within 2 % of the fastest, the one with the largest
-    // BM x BN re-reads its operands least (A once per N tile, B once per M tile) -- the same speed for less L2 / Infinity
-    // Cache / HBM traffic, which is also what leaves room for a second frame in flight
-    for (const auto& kt : timed)
-        if (kt.second <= best * 1.02f && conv_igemm_config_tile_area(kt.first) > conv_igemm_config_tile_area(*cfg)) *cfg = kt.first;
-    c->tuned[key] = *cfg;
-    c->mem_gen++;  // (a new decision: frames captured as graphs before it are stale)
-    return INFUR_OK;
-}
+// ---- tile configuration of the conv kernel for one problem shape: infur_tuner.cpp (pick_cfg) ----
 
 // INFUR_DTYPE_F32_SPLIT: activations are multiplied by 2^2 while they are staged: |x| >= 2^-5 keeps a normal
 // f16 lo part (all 22 bits), smaller values an absolute error <= 2^-27 (f16 subnormals), and the f16 pair
@@ -950,367 +819,7 @@ int32_t stem16_image(infur_ctx* c, const float* wt, float w_scale, int split, co
     return INFUR_OK;
 }
 
-// ---- quantised models (INFURQ01) ----
-// d_blob resident on the device.  Header and directory are checked by blob_dir.h (host-only); weights are repacked to
-// OHWI with the channel axes padded to the K step of the i8 GEMM (128 bytes: the 64-channel tensors of the stem and layer1
-// travel as 128 channels, the upper half zero), the operator bias is folded with the (128 - x_zp) * sum w term of the kernel's
-// signed operands, and the requantisation multipliers are computed as ONNX Runtime computes them (f32: x_s * w_s[o] / y_s).
-inline int q_cpad(int c, bool padded) { return padded && c < 128 ? 128 : c; }
-// bytes of a layer's repacked weights: s8 OHWI (padded); the stem: one dword (r, g, b, 0) per tap and channel
-// layer1's convs (64-channel tensors on one side or both) also get the pixel-pair arrangement of their weights
-inline bool q_pair_layer(const ConvLayer& L) {
-    return L.name.compare(0, 16, "backbone.layer1.") == 0 && L.stride == 1 && L.dil == 1 && (L.k == 1 || (L.k == 3 && L.pad == 1)) &&
-           (L.cin == 64 || L.cout == 64) && (L.cin % 64) == 0 && (L.cout % 64) == 0;
-}
-inline size_t q_wbytes(const ConvLayer& L) {
-    return L.role == 's' ? (size_t)L.cout * L.k * L.k * 4 : (size_t)L.cout_p * L.k * L.k * L.cin_p + 64;
-}
-
-int32_t model_load_q_dev(infur_ctx* c, const void* d_blob, size_t len) {
-    if (len < kBlobHdr) return fail(c, INFUR_E_MODEL_FORMAT, "weight blob too short (%zu bytes)", len);
-    uint8_t hdr[kBlobHdr];
-    HIPCHK(c, hipMemcpyAsync(hdr, d_blob, kBlobHdr, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    BlobHeader bh;
-    uint32_t n_adds = 0;
-    std::vector<ConvSpec> spec;
-    std::string perr;
-    if (!qblob_parse_header(hdr, len, &bh, &n_adds, &spec, &perr)) return fail(c, INFUR_E_MODEL_FORMAT, "%s", perr.c_str());
-    const uint32_t n = bh.n_convs;
-    std::vector<uint8_t> table((size_t)n * kQEntry + (size_t)n_adds * kQAdd);
-    HIPCHK(c, hipMemcpyAsync(table.data(), (const uint8_t*)d_blob + kBlobHdr, table.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<QBlobConv> qc;
-    std::vector<QBlobAdd> qa;
-    if (!qblob_parse_directory(table.data(), len, spec, n_adds, &qc, &qa, &perr)) return fail(c, INFUR_E_MODEL_FORMAT, "%s", perr.c_str());
-    std::vector<ConvLayer> g = build_graph(bh.depth, bh.num_classes, bh.aux);
-    // a block's QLinearAdd takes conv3's output as A: the kernel requantises with conv3's own (y_scale, y_zp) and adds in place
-    {
-        uint32_t blk = 0;
-        for (uint32_t i = 0; i < n; i++)
-            if (g[i].role == '3') {
-                if (blk >= n_adds || qa[blk].a_zp != qc[i].y_zp || qa[blk].a_scale != qc[i].y_scale)
-                    return fail(c, INFUR_E_MODEL_FORMAT, "residual sum %u does not take '%s' as its first input (scale / zero point differ)", blk, g[i].name.c_str());
-                blk++;
-            }
-    }
-    size_t total = 1024;  // the quantisation table of the image
-    constexpr size_t kQStemW = 147 * 64 * 4, kQStemLut = 768 * 4, kQStemBias = 64 * 4;  // operands of the fused stem (launch_stem_pool_q)
-    total += align_up(kQStemW, 256) + align_up(kQStemLut, 256) + align_up(kQStemBias, 256);
-    for (uint32_t i = 0; i < n; i++) {
-        ConvLayer& L = g[i];
-        const bool logits = L.role == 'c';
-        L.cin_p = L.role == 's' ? L.cin : q_cpad(L.cin, true);
-        L.cout_p = L.role == 's' ? L.cout : q_cpad(L.cout, !logits);
-        total += align_up(q_wbytes(L), 256) + 2 * align_up((size_t)L.cout_p * 4, 256);
-        if (q_pair_layer(L)) {  // the pixel-pair form of layer1 (forward_q), beside the padded one (odd widths, kept activations)
-            L.cin2 = 2 * L.cin;
-            L.cout2 = 2 * L.cout;
-            total += align_up((size_t)L.cout2 * L.k * L.k * L.cin2 + 64, 256) + 2 * align_up((size_t)L.cout2 * 4, 256);
-        }
-    }
-    struct DevMem {
-        void* p = nullptr;
-        ~DevMem() { if (p) (void)hipFree(p); }
-    } arena, tmp;
-    HIPCHK(c, hipMalloc(&arena.p, total));
-    HIPCHK(c, hipMemsetAsync(arena.p, 0, total, c->stream));
-    size_t max_c = 0;
-    for (const ConvLayer& L : g) max_c = std::max(max_c, (size_t)L.cout_p);
-    HIPCHK(c, hipMalloc(&tmp.p, max_c * 4));  // row sums of the layer being repacked
-    uint8_t* const base = (uint8_t*)arena.p;
-    size_t off = 0;
-    // image quantisation table: QuantizeLinear of the reference's normalised value of every byte (predict_onnx.rs:126-137)
-    std::vector<uint8_t> ql(768);
-    {
-        std::vector<float> pre(768);
-        build_pre_lut(pre.data());
-        const volatile float xs = qc[0].x_scale;
-        for (int i = 0; i < 768; i++) {
-            volatile float t = pre[i] / xs;  // (one f32 division, then round half to even)
-            float r = std::nearbyintf(t) + (float)qc[0].x_zp;
-            r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
-            ql[i] = (uint8_t)r;
-        }
-        HIPCHK(c, hipMemcpyAsync(base + off, ql.data(), 768, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    uint8_t* const d_qlut = base + off;
-    off += 1024;
-    float* const d_qstem_w = (float*)(base + off);
-    off += align_up(kQStemW, 256);
-    float* const d_qstem_lut = (float*)(base + off);
-    off += align_up(kQStemLut, 256);
-    int32_t* const d_qstem_bias = (int32_t*)(base + off);
-    off += align_up(kQStemBias, 256);
-    std::vector<int32_t> h_sum, h_bias;
-    std::vector<float> h_ws, h_mult;
-    for (uint32_t i = 0; i < n; i++) {
-        ConvLayer& L = g[i];
-        L.x_scale = qc[i].x_scale; L.x_zp = qc[i].x_zp; L.y_scale = qc[i].y_scale; L.y_zp = qc[i].y_zp;
-        L.d_w = base + off;
-        off += align_up(q_wbytes(L), 256);
-        L.d_qbias = (int32_t*)(base + off);
-        off += align_up((size_t)L.cout_p * 4, 256);
-        L.d_qmult = (float*)(base + off);
-        off += align_up((size_t)L.cout_p * 4, 256);
-        const int8_t* src_w = (const int8_t*)d_blob + qc[i].w_off;
-        h_sum.assign(L.cout_p, 0);
-        h_bias.assign(L.cout, 0);
-        h_ws.assign(L.cout, 0.f);
-        if (L.role == 's') {
-            // stem: one dword (r, g, b, 0) per tap and channel, built on the host (9.4 KB)
-            std::vector<int8_t> w((size_t)L.cout * 3 * 49);
-            HIPCHK(c, hipMemcpyAsync(w.data(), src_w, w.size(), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            std::vector<int32_t> wq((size_t)L.cout * 49);
-            for (int o = 0; o < L.cout; o++)
-                for (int t = 0; t < 49; t++) {
-                    uint32_t d = 0;
-                    for (int ch = 0; ch < 3; ch++) {
-                        const int8_t v = w[((size_t)o * 3 + ch) * 49 + t];
-                        d |= (uint32_t)(uint8_t)v << (8 * ch);
-                        h_sum[o] += v;
-                    }
-                    wq[(size_t)o * 49 + t] = (int32_t)d;
-                }
-            HIPCHK(c, hipMemcpyAsync(L.d_w, wq.data(), wq.size() * 4, hipMemcpyHostToDevice, c->stream));
-            // the fused form's operands: weights as f32 [k][o] with k = (ky * 7 + kx) * 3 + channel, the table as q - x_zp
-            if (L.cout != 64) return fail(c, INFUR_E_MODEL_FORMAT, "stem has %d output channels, expected 64", L.cout);
-            std::vector<float> wf(147 * 64), lf(768);
-            for (int o = 0; o < 64; o++)
-                for (int ch = 0; ch < 3; ch++)
-                    for (int t = 0; t < 49; t++) wf[(size_t)(t * 3 + ch) * 64 + o] = (float)w[((size_t)o * 3 + ch) * 49 + t];
-            for (int i = 0; i < 768; i++) lf[i] = (float)((int)ql[i] - qc[0].x_zp);
-            HIPCHK(c, hipMemcpyAsync(d_qstem_w, wf.data(), kQStemW, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(d_qstem_lut, lf.data(), kQStemLut, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(d_qstem_bias, (const uint8_t*)d_blob + qc[i].b_off, kQStemBias, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        } else {
-            HIPCHK(c, launch_repack_q(src_w, (int8_t*)L.d_w, (int32_t*)tmp.p, L.cout, L.cin, L.k, L.k, L.cout_p, L.cin_p, c->stream));
-            HIPCHK(c, hipMemcpyAsync(h_sum.data(), tmp.p, (size_t)L.cout_p * 4, hipMemcpyDeviceToHost, c->stream));
-        }
-        HIPCHK(c, hipMemcpyAsync(h_bias.data(), (const uint8_t*)d_blob + qc[i].b_off, (size_t)L.cout * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(h_ws.data(), (const uint8_t*)d_blob + qc[i].ws_off, (size_t)L.cout * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        std::vector<int32_t> qb(L.cout_p, 0);
-        h_mult.assign(L.cout_p, 0.f);
-        for (int o = 0; o < L.cout; o++) {
-            if (!qscale_ok(h_ws[o])) return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s': weight scale of channel %d is not positive and finite", L.name.c_str(), o);
-            const int64_t b = (int64_t)h_bias[o] + (int64_t)(128 - L.x_zp) * (int64_t)h_sum[o];
-            if (b > INT32_MAX || b < INT32_MIN) return fail(c, INFUR_E_MODEL_FORMAT, "conv '%s': bias of channel %d overflows int32", L.name.c_str(), o);
-            qb[o] = (int32_t)b;
-            volatile float xw = L.x_scale * h_ws[o];  // f32 product, then f32 division: ONNX Runtime's output scale
-            h_mult[o] = xw / L.y_scale;
-        }
-        HIPCHK(c, hipMemcpyAsync(L.d_qbias, qb.data(), (size_t)L.cout_p * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(L.d_qmult, h_mult.data(), (size_t)L.cout_p * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (L.cin2) {
-            // Pixel-pair weights, OHWI over pairs: output row p * cout + o (p = which pixel of the output pair), input column
-            // q * cin + i.  1x1: W where p == q.  3x3 (pad 1, in pair units too): pair-column kx' in {0, 1, 2} holds input pixel
-            // x_in = 2 (X + kx' - 1) + q for output pixel x_out = 2 X + p, i.e. the tap kx = 2 (kx' - 1) + q - p + 1 where that is
-            // a tap of the 3x3, zero elsewhere.  A structural zero multiplies whatever the other pixel holds by 0; the row sums,
-            // hence the folded bias, and the multipliers are the channel's own, once per pixel of the pair.
-            const int taps = L.k * L.k;
-            std::vector<int8_t> w((size_t)L.cout * L.cin * taps), w2((size_t)L.cout2 * taps * L.cin2, 0);
-            HIPCHK(c, hipMemcpyAsync(w.data(), src_w, w.size(), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (int pp = 0; pp < 2; pp++)
-                for (int o = 0; o < L.cout; o++)
-                    for (int ky = 0; ky < L.k; ky++)
-                        for (int kxp = 0; kxp < L.k; kxp++)
-                            for (int qq = 0; qq < 2; qq++) {
-                                const int kx = L.k == 1 ? (pp == qq ? 0 : -1) : 2 * (kxp - 1) + qq - pp + 1;
-                                if (kx < 0 || kx >= L.k) continue;
-                                int8_t* dst = &w2[(((size_t)(pp * L.cout + o) * L.k + ky) * L.k + kxp) * L.cin2 + (size_t)qq * L.cin];
-                                for (int i = 0; i < L.cin; i++) dst[i] = w[((size_t)o * L.cin + i) * taps + ky * L.k + kx];
-                            }
-            std::vector<int32_t> qb2(L.cout2);
-            std::vector<float> qm2(L.cout2);
-            for (int pp = 0; pp < 2; pp++)
-                for (int o = 0; o < L.cout; o++) {
-                    qb2[pp * L.cout + o] = qb[o];
-                    qm2[pp * L.cout + o] = h_mult[o];
-                }
-            L.d_w2 = base + off;
-            off += align_up(w2.size() + 64, 256);
-            L.d_qbias2 = (int32_t*)(base + off);
-            off += align_up((size_t)L.cout2 * 4, 256);
-            L.d_qmult2 = (float*)(base + off);
-            off += align_up((size_t)L.cout2 * 4, 256);
-            HIPCHK(c, hipMemcpyAsync(L.d_w2, w2.data(), w2.size(), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(L.d_qbias2, qb2.data(), (size_t)L.cout2 * 4, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(L.d_qmult2, qm2.data(), (size_t)L.cout2 * 4, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
-    }
-    model_free(c);  // the old model goes only now
-    c->d_weights = arena.p;
-    arena.p = nullptr;
-    c->convs.swap(g);
-    c->qadds.clear();
-    for (const QBlobAdd& a : qa) c->qadds.push_back(QAddParams{a.a_scale, a.b_scale, a.c_scale, a.a_zp, a.b_zp, a.c_zp});
-    c->d_qlut = d_qlut;
-    c->d_qstem_w = d_qstem_w;
-    c->d_qstem_lut = d_qstem_lut;
-    c->d_qstem_bias = d_qstem_bias;
-    c->q_resize_u8 = bh.resize_u8;
-    for (const ConvLayer& L : c->convs)
-        if (L.role == 'c') {
-            const int k = L.name.rfind("aux_", 0) == 0 ? 1 : 0;
-            c->q_head_zp[k] = (float)L.y_zp;
-            c->q_head_scale[k] = L.y_scale;
-        }
-    c->quant = true;
-    c->depth = bh.depth;
-    c->num_classes = bh.num_classes;
-    c->has_aux = bh.aux;
-    c->input_u8 = false;
-    c->weight_bytes = total;
-    c->loaded = true;
-    infur_model_info& mi = c->info;
-    memset(&mi, 0, sizeof mi);
-    snprintf(mi.input_name, sizeof mi.input_name, "input");
-    snprintf(mi.input0_dtype, sizeof mi.input0_dtype, "Float");  // the int8 zoo model keeps float I/O (QuantizeLinear is its first node)
-    snprintf(mi.output_names[0], 32, "out");
-    mi.n_outputs = 1 + ((bh.aux && c->opt.compute_aux) ? 1 : 0);
-    if (mi.n_outputs == 2) snprintf(mi.output_names[1], 32, "aux");
-    mi.num_classes = (uint32_t)bh.num_classes;
-    mi.depth = (uint32_t)bh.depth;
-    mi.n_convs = n;
-    mi.weight_bytes = total;
-    mi.quantised = 1;
-    mi.resize_u8_heads = bh.resize_u8 ? 1 : 0;
-    return INFUR_OK;
-}
-
-// one QLinearConv (+ the block's QLinearAdd when `res` is given; f32 output = + DequantizeLinear) on the i8 MFMA
-// (pair: `in` / `res` / `out` are pixel-pair views -- (H, W/2, 2C) -- and the layer's pair weights are used: forward_q)
-int32_t run_qconv(infur_ctx* c, const ConvLayer& L, const Tensor& in, const Tensor* res, const QAddParams* add, Tensor* out, bool pair = false) {
-    const int oh = conv_out(in.h, L.k, L.stride, L.pad, L.dil), ow = conv_out(in.w, L.k, L.stride, L.pad, L.dil);
-    const int out_f32 = L.role == 'c' ? 1 : 0;
-    if (pair && !L.d_w2) return fail(c, INFUR_E_SHAPE, "'%s' has no pixel-pair weights", L.name.c_str());
-    const int cin_k = pair ? L.cin2 : L.cin_p, cout_k = pair ? L.cout2 : L.cout_p;
-    if (in.c != cin_k || in.es != 1) return fail(c, INFUR_E_SHAPE, "'%s' expects %d u8 channels, got %d", L.name.c_str(), cin_k, in.c);
-    RETIF(talloc(c, oh, ow, cout_k, out_f32 ? 4 : 1, out));
-    ConvArgs a;
-    a.in = in.p; a.wt = pair ? L.d_w2 : L.d_w; a.bias = nullptr; a.res = res ? res->p : nullptr; a.out = out->p;
-    a.H = in.h; a.W = in.w; a.Cin = in.c; a.OH = oh; a.OW = ow; a.Cout = cout_k;
-    a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.dil = L.dil; a.relu = 0;
-    a.q_mult = pair ? L.d_qmult2 : L.d_qmult; a.q_bias = pair ? L.d_qbias2 : L.d_qbias; a.q_yzp = L.y_zp; a.q_dq = L.y_scale;
-    if (out_f32 && c->q_resize_u8) {  // the file resizes the codes: leave them (as floats) for the post kernels to interpolate
-        a.q_dq = 1.0f;
-        a.q_dq_off = (float)L.y_zp;
-    }
-    if (res) {
-        if (!add || res->c != cout_k || res->h != oh || res->w != ow) return fail(c, INFUR_E_SHAPE, "residual of '%s' has the wrong shape", L.name.c_str());
-        volatile float ra = add->a_scale / add->c_scale, rb = add->b_scale / add->c_scale;  // f32 divisions, as MLAS' QLinearAdd
-        a.q_ra = ra; a.q_rb = rb; a.q_bzp = add->b_zp; a.q_czp = add->c_zp;
-    }
-    const double flops = 2.0 * oh * ow * (double)L.cout * L.cin * L.k * L.k;
-    const double bytes = (double)in.bytes() + (double)out->bytes() + (res ? (double)res->bytes() : 0.0) + (double)cout_k * cin_k * L.k * L.k;
-    int cfg = -1;
-    RETIF(pick_cfg(c, a, 4, out_f32, &cfg));
-    {
-        ProfScope ps(c, L.name, conv_igemm_config_name(cfg, 4), flops, bytes);
-        HIPCHK(c, launch_conv_igemm(a, 4, out_f32, cfg, c->stream));
-    }
-    if (c->opt.keep_activations) c->kept.push_back(*out);
-    return INFUR_OK;
-}
-
-// the forward of a quantised model: u8 NHWC activations end to end, dequantised f32 logits in c->out_low / c->aux_low
-int32_t forward_q(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
-    size_t ci = 0;
-    const ConvLayer& stem = c->convs[ci++];
-    const int sh = conv_out(h, 7, 2, 3, 1), sw = conv_out(w, 7, 2, 3, 1);
-    const int ph = conv_out(sh, 3, 2, 1, 1), pw = conv_out(sw, 3, 2, 1, 1);
-    Tensor s, x;
-    // layer1 on PIXEL PAIRS (an even pooled width; not with kept activations, whose per-layer read-back is the padded layout): its
-    // 64-channel tensors are stored compact, two neighbouring pixels = one 128-byte GEMM row of a (H, W/2) image, and the convs use
-    // the pair arrangement of their weights (model_load_q_dev) -- no channel padding in HBM, half the rows (hence half the MFMA
-    // work) for conv2 and layer1.0.conv1; the 256-channel tensors are unchanged: (H, W/2, 512) IS (H, W, 256).  Same integer sums,
-    // same epilogue per channel: bit-identical to the padded form (INFUR_Q_NOPAIR=1 keeps that one: tests/test_gpu_quant.py).
-    static const bool no_pair_env = getenv("INFUR_Q_NOPAIR") && atoi(getenv("INFUR_Q_NOPAIR")) != 0;
-    bool pair = !no_pair_env && !c->opt.keep_activations && !c->opt.no_fuse_stem_pool && (pw % 2) == 0;
-    for (const ConvLayer& L : c->convs)
-        if (L.name.compare(0, 16, "backbone.layer1.") == 0 && !L.d_w2) pair = false;
-    if (!c->opt.keep_activations && !c->opt.no_fuse_stem_pool) {
-        // QuantizeLinear + QLinearConv + MaxPool in one launch, exact on the f16 MFMA; the 64-channel stem tensor is never written
-        RETIF(talloc(c, ph, pw, pair ? 64 : 128, 1, &x));
-        const void* wimg = nullptr;
-        RETIF(stem16_image(c, c->d_qstem_w, 1.0f, 0, &wimg));
-        ProfScope ps(c, "backbone.conv1+maxpool", "stem_pool_q", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)x.bytes());
-        HIPCHK(c, launch_stem_pool_q(d_bgr, h, w, wimg, c->d_qstem_lut, c->d_qstem_bias, stem.d_qmult, stem.y_zp, (uint8_t*)x.p, pair ? 64 : 128,
-                                     sh, sw, ph, pw, c->stream));
-    } else {
-    {
-        RETIF(talloc(c, sh, sw, 64, 1, &s));
-        ProfScope ps(c, stem.name, "stem_q", 2.0 * sh * sw * 64 * 147, (double)h * w * 3 + (double)s.bytes());
-        HIPCHK(c, launch_stem_q(d_bgr, h, w, c->d_qlut, stem.x_zp, (const int32_t*)stem.d_w, stem.d_qbias, stem.d_qmult, stem.y_zp, (uint8_t*)s.p, sh, sw, c->stream));
-    }
-    if (c->opt.keep_activations) c->kept.push_back(s);
-    {
-        RETIF(talloc(c, ph, pw, 128, 1, &x));
-        ProfScope ps(c, "backbone.maxpool", "maxpool_q", 0, (double)s.bytes() + (double)x.bytes());
-        HIPCHK(c, launch_maxpool_q((const uint8_t*)s.p, sh, sw, 64, (uint8_t*)x.p, ph, pw, 128, c->stream));
-    }
-    pool_release(c, s);
-    }
-    Tensor l3;
-    size_t blk = 0;
-    while (c->convs[ci].role == '1') {
-        const ConvLayer& c1 = c->convs[ci];
-        const ConvLayer& c2 = c->convs[ci + 1];
-        const ConvLayer& c3 = c->convs[ci + 2];
-        const bool has_ds = c->convs[ci + 3].role == 'd';
-        if (blk >= c->qadds.size()) return fail(c, INFUR_E_SHAPE, "quantised model has fewer residual sums than blocks");
-        Tensor t1, t2, idt, y;
-        const bool pv = pair && c1.name.compare(0, 16, "backbone.layer1.") == 0;
-        Tensor xv = x;  // the block's input as the convs see it
-        if (pv) {
-            xv.w = x.w / 2;
-            xv.c = x.c * 2;
-        }
-        RETIF(run_qconv(c, c1, xv, nullptr, nullptr, &t1, pv));
-        RETIF(run_qconv(c, c2, t1, nullptr, nullptr, &t2, pv));
-        pool_release(c, t1);
-        if (has_ds) RETIF(run_qconv(c, c->convs[ci + 3], xv, nullptr, nullptr, &idt, pv));
-        RETIF(run_qconv(c, c3, t2, has_ds ? &idt : &xv, &c->qadds[blk], &y, pv));
-        if (pv) {  // (H, W/2, 512) is (H, W, 256)
-            y.w *= 2;
-            y.c /= 2;
-        }
-        if (has_ds && c->opt.keep_activations) std::swap(c->kept[c->kept.size() - 1], c->kept[c->kept.size() - 2]);  // blob order: conv3, downsample
-        pool_release(c, t2);
-        if (has_ds) pool_release(c, idt);
-        blk++;
-        ci += has_ds ? 4 : 3;
-        const bool end_l3 = c1.name.compare(0, 16, "backbone.layer3.") == 0 && c->convs[ci].name.compare(0, 16, "backbone.layer4.") == 0;
-        if (!(l3.p && x.p == l3.p)) pool_release(c, x);
-        x = y;
-        if (end_l3 && c->has_aux && c->opt.compute_aux) l3 = y;
-    }
-    {
-        Tensor h1;
-        RETIF(run_qconv(c, c->convs[ci], x, nullptr, nullptr, &h1));
-        pool_release(c, x);
-        RETIF(run_qconv(c, c->convs[ci + 1], h1, nullptr, nullptr, &c->out_low));
-        pool_release(c, h1);
-        ci += 2;
-    }
-    if (c->has_aux && c->opt.compute_aux) {
-        Tensor a1;
-        RETIF(run_qconv(c, c->convs[ci], l3, nullptr, nullptr, &a1));
-        pool_release(c, l3);
-        RETIF(run_qconv(c, c->convs[ci + 1], a1, nullptr, nullptr, &c->aux_low));
-        pool_release(c, a1);
-    }
-    c->last_h = h;
-    c->last_w = w;
-    return INFUR_OK;
-}
+// ---- quantised models (INFURQ01): infur_quant_model.cpp (model_load_q_dev, forward_q) ----
 
 // FCN-ResNet forward from a packed BGR frame resident on the device.
 // Leaves the output-stride-8 logits in c->out_low / c->aux_low (NHWC).
@@ -1433,7 +942,7 @@ int32_t forward(infur_ctx* c, const uint8_t* d_bgr, int w, int h) {
 // =====================================================================================
 // Every entry point runs on its context's device: a process may hold contexts on several GPUs, and
 // hipMalloc / kernel launches follow the calling thread's current device, not the stream's.
-static void stream_orphan(infur_stream* st);  // releases a stream's resources and detaches it from its context
+// (infur::stream_orphan -- infur_stream.cpp -- releases a stream's resources and detaches it from its context)
 
 static inline void enter(const infur_ctx* c) {
     int cur = -1;
@@ -2310,463 +1819,7 @@ int32_t infur_frame_advance(infur_ctx* c, const uint8_t* bgr, uint32_t w, uint32
     }
 }
 
-// ---- streaming ----
-}  // extern "C" (the struct below needs C++ members)
-
-struct infur_stream {
-    struct Slot {
-        uint8_t* h_in = nullptr;   // pinned
-        uint8_t* h_out = nullptr;  // pinned: [rgba | scaled bgr]
-        void* d_in = nullptr;
-        void* d_out = nullptr;  // [rgba | scaled bgr]
-        size_t in_cap = 0, out_cap = 0;
-        uint32_t small_in = 0, small_out = 0;  // consecutive requests below a quarter of the capacity (slot_reserve's hysteresis)
-        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_done = nullptr;
-        uint64_t id = 0;
-        uint32_t ow = 0, oh = 0;
-        int32_t status = INFUR_OK;
-        bool busy = false;
-        // zero-copy egress: the mask goes by DMA straight into a pinned buffer of the caller (infur_batch_advance with buffers from
-        // infur_host_alloc); nullptr: into h_out
-        uint8_t* direct_out = nullptr;
-    };
-    infur_ctx* ctx = nullptr;  // owner: holds the copy streams' device, receives the error messages
-    // compute lanes: frame i runs on lanes[i % n] (lanes[0] == ctx).  Frames are independent, so a second context of
-    // the same device (infur_stream_add_lane) lets the kernels of consecutive frames overlap
-    std::vector<infur_ctx*> lanes;
-    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
-    std::vector<Slot> slots;
-    uint64_t head = 0, tail = 0;  // tail = next to collect, head = next to submit
-    // zero-copy ingest / egress (infur_stream_acquire / _commit, _collect_view / _release): the slot at `head` is lent to the producer
-    // (acq_*: what it was sized for), the slot at `tail` is lent to the consumer (viewing)
-    bool acquired = false, viewing = false;
-    uint32_t acq_w = 0, acq_h = 0, acq_ow = 0, acq_oh = 0;
-    uint32_t acq_factor_bits = 0;
-};
-
-namespace {
-// buffers grow on demand and are given back when requests have needed less than a quarter of them for a while (a ring that lives
-// as long as its context -- infur_batch_advance's -- would otherwise keep the largest frame it ever saw).  "For a while" = 8
-// consecutive small requests of that slot: a batch that ALTERNATES large and small frames (4K and 480p) would otherwise free and
-// reallocate pinned + device memory on every frame -- each a device-wide synchronisation, and new pointers that no cached
-// graph of the fused frame path can match.
-constexpr uint32_t kSlotShrinkAfter = 8;
-int32_t slot_reserve(infur_ctx* c, infur_stream::Slot& sl, size_t in_bytes, size_t out_bytes) {
-    sl.small_in = sl.in_cap / 4 > in_bytes ? sl.small_in + 1 : 0;
-    sl.small_out = sl.out_cap / 4 > out_bytes ? sl.small_out + 1 : 0;
-    if (sl.in_cap < in_bytes || sl.small_in >= kSlotShrinkAfter) {
-        if (sl.h_in) HIPCHK(c, hipHostFree(sl.h_in));
-        if (sl.d_in) HIPCHK(c, hipFree(sl.d_in));
-        sl.h_in = nullptr; sl.d_in = nullptr; sl.in_cap = 0;
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_in, in_bytes, hipHostMallocDefault));
-        HIPCHK(c, hipMalloc(&sl.d_in, in_bytes));
-        sl.in_cap = in_bytes;
-        sl.small_in = 0;
-    }
-    if (sl.out_cap < out_bytes || sl.small_out >= kSlotShrinkAfter) {
-        if (sl.h_out) HIPCHK(c, hipHostFree(sl.h_out));
-        if (sl.d_out) HIPCHK(c, hipFree(sl.d_out));
-        sl.h_out = nullptr; sl.d_out = nullptr; sl.out_cap = 0;
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_out, out_bytes, hipHostMallocDefault));
-        HIPCHK(c, hipMalloc(&sl.d_out, out_bytes));
-        sl.out_cap = out_bytes;
-        sl.small_out = 0;
-    }
-    return INFUR_OK;
-}
-}  // namespace
-
-static void stream_orphan(infur_stream* st) {
-    infur_ctx* c = st->ctx;
-    if (!c) return;
-    enter(c);
-    for (infur_ctx* l : st->lanes)
-        if (l->stream) (void)hipStreamSynchronize(l->stream);
-    if (st->s_h2d) (void)hipStreamSynchronize(st->s_h2d);
-    if (st->s_d2h) (void)hipStreamSynchronize(st->s_d2h);
-    for (auto& sl : st->slots) {
-        if (sl.h_in) (void)hipHostFree(sl.h_in);
-        if (sl.h_out) (void)hipHostFree(sl.h_out);
-        if (sl.d_in) (void)hipFree(sl.d_in);
-        if (sl.d_out) (void)hipFree(sl.d_out);
-        for (hipEvent_t e : {sl.ev_h2d, sl.ev_comp, sl.ev_done})
-            if (e) (void)hipEventDestroy(e);
-    }
-    st->slots.clear();
-    if (st->s_h2d) (void)hipStreamDestroy(st->s_h2d);
-    if (st->s_d2h) (void)hipStreamDestroy(st->s_d2h);
-    st->s_h2d = st->s_d2h = nullptr;
-    st->head = st->tail = 0;
-    st->acquired = st->viewing = false;
-    for (infur_ctx* l : st->lanes)  // the stream is registered with every lane's context: any of them may go first
-        for (size_t i = 0; i < l->streams.size(); i++)
-            if (l->streams[i] == st) {
-                l->streams.erase(l->streams.begin() + (long)i);
-                break;
-            }
-    st->lanes.clear();
-    st->ctx = nullptr;
-}
-
-extern "C" {
-
-int32_t infur_stream_create(infur_ctx* c, uint32_t depth, infur_stream** out) {
-    try {
-        enter(c);
-        if (!c || !out || depth == 0 || depth > 64) return INFUR_E_INVALID_ARG;
-        *out = nullptr;
-        infur_stream* st = new infur_stream();
-        st->ctx = c;
-        st->lanes.push_back(c);
-        c->streams.push_back(st);
-        st->slots.resize(depth);
-        bool ok = hipStreamCreateWithFlags(&st->s_h2d, hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&st->s_d2h, hipStreamNonBlocking) == hipSuccess;
-        for (auto& sl : st->slots)
-            ok = ok && hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            infur_stream_destroy(st);
-            return fail(c, INFUR_E_HIP, "could not create the streaming ring");
-        }
-        *out = st;
-        return INFUR_OK;
-    } catch (const std::bad_alloc&) {
-        return fail(c, INFUR_E_CAPACITY, "out of host memory");
-    } catch (const std::exception& e) {
-        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
-    }
-}
-
-void infur_stream_destroy(infur_stream* st) {
-    if (!st) return;
-    stream_orphan(st);  // no-op when the context went first
-    delete st;
-}
-
-uint32_t infur_stream_pending(const infur_stream* st) { return st ? (uint32_t)(st->head - st->tail) : 0; }
-
-int32_t infur_stream_add_lane(infur_stream* st, infur_ctx* other) {
-    if (!st || !st->ctx || !other) return INFUR_E_INVALID_ARG;
-    infur_ctx* c = st->ctx;
-    if (other->device != c->device) return fail(c, INFUR_E_INVALID_ARG, "a lane must be a context of the stream's device (%d), got device %d", c->device, other->device);
-    for (infur_ctx* l : st->lanes)
-        if (l == other) return fail(c, INFUR_E_INVALID_ARG, "that context already is a lane of this stream");
-    if (st->head != st->tail) return fail(c, INFUR_E_INVALID_ARG, "add lanes while no frame is pending");
-    // odd and even frames must run the SAME arithmetic: the option set infur_group_weights_broadcast checks (the fusion
-    // switches are bit-identical forms and may differ; F(4x4) and F(6x6) logits differ by ~1e-6, enough to flip a tie)
-    if (other->opt.compute_dtype != c->opt.compute_dtype || other->opt.winograd_tile != c->opt.winograd_tile ||
-        other->opt.winograd_min_cin != c->opt.winograd_min_cin || other->opt.compute_aux != c->opt.compute_aux)
-        return fail(c, INFUR_E_INVALID_ARG, "a lane must share the stream's compute_dtype / winograd_tile / winograd_min_cin / compute_aux: its frames would otherwise differ");
-    if (!other->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "the lane's context has no model loaded (replicate it first: infur_group_weights_broadcast)");
-    if (c->loaded && other->quant != c->quant)
-        return fail(c, INFUR_E_INVALID_ARG, "a lane must hold the stream's model: one of the two contexts has a quantised model, the other a float one");
-    st->lanes.push_back(other);
-    other->streams.push_back(st);
-    return INFUR_OK;
-}
-
-namespace {
-inline uint32_t f32_bits(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    return u;
-}
-
-// pinned host memory (hipHostMalloc / hipHostRegister): DMA can read and write it directly
-bool host_is_pinned(const void* p) {
-    if (!p) return false;
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the runtime: not an error of ours)
-        return false;
-    }
-    return at.type == hipMemoryTypeHost;
-}
-
-// checks + slot reservation shared by submit and acquire: the slot at `head`, sized for a w x h frame scaled by `factor`
-int32_t stream_prepare(infur_stream* st, uint32_t w, uint32_t h, float factor, infur_stream::Slot** slot, uint32_t* ow_out, uint32_t* oh_out) {
-    infur_ctx* c = st->ctx;
-    int32_t rc = infur_scale_validate(factor);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    uint32_t ow = 0, oh = 0;
-    rc = infur_scale_out_dims(w, h, factor, &ow, &oh);
-    if (rc) return fail(c, rc, "%s", infur_status_string(rc));
-    infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
-    if (!lane->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");
-    // (a model may have been (re)loaded on one context after the lane was added: both kinds of arithmetic in one stream would
-    //  alternate frame by frame)
-    if (lane->quant != st->lanes[0]->quant || lane->depth != st->lanes[0]->depth)
-        return fail(c, INFUR_E_INVALID_ARG, "the stream's lanes hold different models (quantised / float, or different depths): replicate one model to all of them");
-    const size_t depth = st->slots.size();
-    if (st->head - st->tail >= depth)
-        return fail(c, INFUR_E_CAPACITY, "all %zu slots are in flight: collect before submitting more", depth);
-    infur_stream::Slot& sl = st->slots[st->head % depth];
-    const size_t in_bytes = (size_t)w * h * 3, rgba_bytes = (size_t)ow * oh * 4, sc_bytes = (size_t)ow * oh * 3;
-    if (in_bytes == 0 || rgba_bytes == 0) return fail(c, INFUR_E_SHAPE, "couldn't transform image: %ux%u", w, h);
-    RETIF(slot_reserve(c, sl, in_bytes, rgba_bytes + sc_bytes));
-    *slot = &sl;
-    *ow_out = ow;
-    *oh_out = oh;
-    return INFUR_OK;
-}
-
-// enqueues H2D -> scale / model / decode -> D2H for the slot at `head`.  src: pinned host memory holding the frame (the slot's own
-// h_in, or a pinned buffer of the caller); direct_out: pinned destination of the mask instead of the slot's h_out (or nullptr)
-int32_t stream_enqueue(infur_stream* st, infur_stream::Slot& sl, const uint8_t* src, uint32_t w, uint32_t h, float factor, uint32_t mode,
-                       uint64_t frame_id, uint32_t ow, uint32_t oh, uint8_t* direct_out) {
-    infur_ctx* c = st->ctx;
-    infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
-    const size_t in_bytes = (size_t)w * h * 3, rgba_bytes = (size_t)ow * oh * 4, sc_bytes = (size_t)ow * oh * 3;
-    sl.id = frame_id;
-    sl.ow = ow;
-    sl.oh = oh;
-    sl.direct_out = direct_out;
-    // From here on work that reads / writes this slot's buffers is in flight.  The slot is handed out again by the next
-    // submit (head does not advance on failure) and slot_reserve may free its buffers, so every failing return below
-    // first waits for whatever was enqueued (quiesce).
-    auto quiesce = [&]() {
-        (void)hipStreamSynchronize(st->s_h2d);
-        (void)hipStreamSynchronize(lane->stream);
-        (void)hipStreamSynchronize(st->s_d2h);
-    };
-#define SUBMIT_CHK(expr)                                                                                                     \
-    do {                                                                                                                     \
-        hipError_t e__ = (expr);                                                                                             \
-        if (e__ != hipSuccess) {                                                                                             \
-            quiesce();                                                                                                       \
-            return fail(c, INFUR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__);        \
-        }                                                                                                                    \
-    } while (0)
-    SUBMIT_CHK(hipMemcpyAsync(sl.d_in, src, in_bytes, hipMemcpyHostToDevice, st->s_h2d));
-    SUBMIT_CHK(hipEventRecord(sl.ev_h2d, st->s_h2d));
-    SUBMIT_CHK(hipStreamWaitEvent(lane->stream, sl.ev_h2d, 0));
-    uint8_t* d_rgba = (uint8_t*)sl.d_out;
-    uint8_t* d_sc = d_rgba + rgba_bytes;
-    uint32_t a = 0, b = 0;
-    sl.status = infur_frame_advance_dev(lane, sl.d_in, w, h, factor, mode, d_rgba, rgba_bytes, d_sc, &a, &b);
-    if (sl.status != INFUR_OK) {
-        const std::string msg = lane->err;  // (quiesce must not lose the message)
-        quiesce();
-        c->err = msg;
-        return sl.status;
-    }
-    SUBMIT_CHK(hipEventRecord(sl.ev_comp, lane->stream));
-    SUBMIT_CHK(hipStreamWaitEvent(st->s_d2h, sl.ev_comp, 0));
-    if (direct_out)  // (the mask alone: a caller-owned destination has no room for the scaled frame)
-        SUBMIT_CHK(hipMemcpyAsync(direct_out, sl.d_out, rgba_bytes, hipMemcpyDeviceToHost, st->s_d2h));
-    else
-        SUBMIT_CHK(hipMemcpyAsync(sl.h_out, sl.d_out, rgba_bytes + sc_bytes, hipMemcpyDeviceToHost, st->s_d2h));
-    SUBMIT_CHK(hipEventRecord(sl.ev_done, st->s_d2h));
-#undef SUBMIT_CHK
-    sl.busy = true;
-    st->head++;
-    st->acquired = false;
-    return INFUR_OK;
-}
-
-// submit with optional zero-copy: pinned_src -- `bgr` is pinned and stays untouched until the frame is collected (the batch calls:
-// they return only when everything is done); direct_out -- pinned destination for the mask
-int32_t stream_submit_impl(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode, uint64_t frame_id,
-                           bool pinned_src, uint8_t* direct_out) {
-    if (!st || !st->ctx || !bgr) return INFUR_E_INVALID_ARG;  // (a stream whose context was destroyed is dead)
-    enter(st->ctx);
-    if (st->acquired) return fail(st->ctx, INFUR_E_INVALID_ARG, "a slot is acquired: commit it before submitting another frame");
-    infur_stream::Slot* sl = nullptr;
-    uint32_t ow = 0, oh = 0;
-    RETIF(stream_prepare(st, w, h, factor, &sl, &ow, &oh));
-    if (!pinned_src) memcpy(sl->h_in, bgr, (size_t)w * h * 3);  // the caller's buffer is free again when submit returns
-    return stream_enqueue(st, *sl, pinned_src ? bgr : sl->h_in, w, h, factor, mode, frame_id, ow, oh, direct_out);
-}
-}  // namespace
-
-int32_t infur_stream_submit(infur_stream* st, const uint8_t* bgr, uint32_t w, uint32_t h, float factor, uint32_t mode,
-                            uint64_t frame_id) {
-    try {
-        return stream_submit_impl(st, bgr, w, h, factor, mode, frame_id, false, nullptr);
-    } catch (const std::bad_alloc&) {
-        return fail(st ? st->ctx : nullptr, INFUR_E_CAPACITY, "out of host memory");
-    } catch (const std::exception& e) {
-        return fail(st ? st->ctx : nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
-    }
-}
-
-// ---- zero-copy ingest: the producer fills the ring's own pinned slot (ff-video/src/decoder.rs:156-165 reads into a reused BgrImage) ----
-int32_t infur_stream_acquire(infur_stream* st, uint32_t w, uint32_t h, float factor, uint8_t** bgr_slot) {
-    try {
-        if (!st || !st->ctx || !bgr_slot) return INFUR_E_INVALID_ARG;
-        enter(st->ctx);
-        *bgr_slot = nullptr;
-        infur_stream::Slot* sl = nullptr;
-        uint32_t ow = 0, oh = 0;
-        RETIF(stream_prepare(st, w, h, factor, &sl, &ow, &oh));  // (acquiring again re-sizes the same slot: nothing is in flight on it)
-        st->acquired = true;
-        st->acq_w = w;
-        st->acq_h = h;
-        st->acq_ow = ow;
-        st->acq_oh = oh;
-        st->acq_factor_bits = f32_bits(factor);
-        *bgr_slot = sl->h_in;
-        return INFUR_OK;
-    } catch (const std::bad_alloc&) {
-        return fail(st ? st->ctx : nullptr, INFUR_E_CAPACITY, "out of host memory");
-    } catch (const std::exception& e) {
-        return fail(st ? st->ctx : nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
-    }
-}
-
-int32_t infur_stream_commit(infur_stream* st, uint32_t w, uint32_t h, float factor, uint32_t mode, uint64_t frame_id) {
-    try {
-        if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
-        enter(st->ctx);
-        infur_ctx* c = st->ctx;
-        if (!st->acquired) return fail(c, INFUR_E_INVALID_ARG, "no slot is acquired");
-        if (w != st->acq_w || h != st->acq_h || f32_bits(factor) != st->acq_factor_bits)
-            return fail(c, INFUR_E_INVALID_ARG, "commit of a %ux%u frame (factor %g) into a slot acquired for %ux%u", w, h, (double)factor, st->acq_w, st->acq_h);
-        infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
-        if (!lane->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");  // (unloaded between acquire and commit)
-        infur_stream::Slot& sl = st->slots[st->head % st->slots.size()];
-        return stream_enqueue(st, sl, sl.h_in, w, h, factor, mode, frame_id, st->acq_ow, st->acq_oh, nullptr);
-    } catch (const std::bad_alloc&) {
-        return fail(st ? st->ctx : nullptr, INFUR_E_CAPACITY, "out of host memory");
-    } catch (const std::exception& e) {
-        return fail(st ? st->ctx : nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
-    }
-}
-
-int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint32_t* ow, uint32_t* oh) {
-    if (!st || !st->ctx || st->head == st->tail) return INFUR_E_INVALID_ARG;
-    const infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
-    if (frame_id) *frame_id = sl.id;
-    if (ow) *ow = sl.ow;
-    if (oh) *oh = sl.oh;
-    return INFUR_OK;
-}
-
-int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t cap, uint8_t* scaled, uint64_t* frame_id,
-                             uint32_t* ow, uint32_t* oh) {
-    if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
-    enter(st->ctx);
-    infur_ctx* c = st->ctx;
-    if (st->head == st->tail) return fail(c, INFUR_E_INVALID_ARG, "no frame is pending");
-    infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
-    const size_t rgba_bytes = (size_t)sl.ow * sl.oh * 4, sc_bytes = (size_t)sl.ow * sl.oh * 3;
-    if (rgba && cap < rgba_bytes) return fail(c, INFUR_E_CAPACITY, "mask needs %zu bytes, buffer has %zu", rgba_bytes, cap);
-    if (scaled && sl.direct_out) return fail(c, INFUR_E_INVALID_ARG, "this frame's mask went straight to a caller-owned buffer: the scaled frame was not kept");
-    HIPCHK(c, hipEventSynchronize(sl.ev_done));
-    if (rgba && rgba != sl.direct_out) memcpy(rgba, sl.direct_out ? sl.direct_out : sl.h_out, rgba_bytes);
-    if (scaled) memcpy(scaled, sl.h_out + rgba_bytes, sc_bytes);
-    if (frame_id) *frame_id = sl.id;
-    if (ow) *ow = sl.ow;
-    if (oh) *oh = sl.oh;
-    sl.busy = false;
-    sl.direct_out = nullptr;
-    st->viewing = false;
-    st->tail++;
-    return INFUR_OK;
-}
-
-// ---- zero-copy egress: the oldest finished frame's mask (and scaled frame) in place, in the ring's pinned slot ----
-int32_t infur_stream_collect_view(infur_stream* st, const uint8_t** rgba, const uint8_t** scaled, uint64_t* frame_id, uint32_t* ow, uint32_t* oh) {
-    if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
-    enter(st->ctx);
-    infur_ctx* c = st->ctx;
-    if (st->head == st->tail) return fail(c, INFUR_E_INVALID_ARG, "no frame is pending");
-    infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
-    HIPCHK(c, hipEventSynchronize(sl.ev_done));
-    const size_t rgba_bytes = (size_t)sl.ow * sl.oh * 4;
-    if (rgba) *rgba = sl.direct_out ? sl.direct_out : sl.h_out;
-    if (scaled) *scaled = sl.direct_out ? nullptr : sl.h_out + rgba_bytes;
-    if (frame_id) *frame_id = sl.id;
-    if (ow) *ow = sl.ow;
-    if (oh) *oh = sl.oh;
-    st->viewing = true;  // the slot stays the consumer's until infur_stream_release (or a copying collect of the same frame)
-    return INFUR_OK;
-}
-
-int32_t infur_stream_release(infur_stream* st) {
-    if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
-    infur_ctx* c = st->ctx;
-    if (!st->viewing || st->head == st->tail) return fail(c, INFUR_E_INVALID_ARG, "no frame is being viewed");
-    infur_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
-    sl.busy = false;
-    sl.direct_out = nullptr;
-    st->viewing = false;
-    st->tail++;
-    return INFUR_OK;
-}
-
-// ---- pinned host memory for the caller's own frame / mask buffers: the batch calls move such buffers by DMA, without the
-//      pageable -> pinned staging copy (and back) they otherwise make ----
-int32_t infur_host_alloc(size_t bytes, void** p) {
-    if (!p || bytes == 0) return INFUR_E_INVALID_ARG;
-    *p = nullptr;
-    // portable: every device of the process may DMA it (a group's workers each move their own slice of one batch)
-    return hipHostMalloc(p, bytes, hipHostMallocPortable) == hipSuccess ? INFUR_OK : INFUR_E_CAPACITY;
-}
-
-int32_t infur_host_free(void* p) {
-    if (!p) return INFUR_OK;
-    return hipHostFree(p) == hipSuccess ? INFUR_OK : INFUR_E_INVALID_ARG;
-}
-
-uint32_t infur_host_is_pinned(const void* p) { return host_is_pinned(p) ? 1u : 0u; }
-
-// ---- frame batch ----
-int32_t infur_batch_advance(infur_ctx* c, const uint8_t* const* frames, const uint32_t* ws, const uint32_t* hs, uint32_t n,
-                            float factor, uint32_t mode, uint8_t* const* rgba, const size_t* caps, uint32_t* ows,
-                            uint32_t* ohs) {
-    try {
-        enter(c);
-        if (!c || (n && (!frames || !ws || !hs || !rgba || !caps))) return INFUR_E_INVALID_ARG;
-        if (n == 0) return INFUR_OK;
-        // The depth-3 ring lives as long as the context (6 pinned + device buffer pairs, 2 streams, 9 events: building it
-        // per call is a visible fixed cost when a batch is 8 frames per GPU -- BASELINE configs[3] at N = 8).  It is created
-        // on the first batch, shrinks with the frames (slot_reserve) and goes with infur_ctx_destroy.
-        if (!c->batch_ring) RETIF(infur_stream_create(c, 3, &c->batch_ring));
-        infur_stream* st = c->batch_ring;
-        int32_t rc = INFUR_OK;
-        uint32_t done = 0;
-        auto collect_one = [&]() -> int32_t {
-            uint64_t id = 0;
-            uint32_t ow = 0, oh = 0;
-            int32_t r = infur_stream_next_dims(st, &id, &ow, &oh);
-            if (r != INFUR_OK) return r;
-            r = infur_stream_collect(st, rgba[id], caps[id], nullptr, &id, &ow, &oh);
-            if (r == INFUR_OK) {
-                if (ows) ows[id] = ow;
-                if (ohs) ohs[id] = oh;
-                done++;
-            }
-            return r;
-        };
-        for (uint32_t i = 0; i < n && rc == INFUR_OK; i++) {
-            if (infur_stream_pending(st) >= 3) rc = collect_one();
-            if (rc == INFUR_OK) {
-                // caller-owned PINNED buffers (infur_host_alloc) are moved by DMA directly -- this call returns only when every frame
-                // is done, so they are not touched behind the caller's back; pageable ones go through the ring's pinned slots
-                const bool pin_in = host_is_pinned(frames[i]);
-                uint32_t eow = 0, eoh = 0;
-                const bool dims_ok = infur_scale_out_dims(ws[i], hs[i], factor, &eow, &eoh) == INFUR_OK;
-                uint8_t* direct = (dims_ok && caps[i] >= (size_t)eow * eoh * 4 && host_is_pinned(rgba[i])) ? rgba[i] : nullptr;
-                rc = stream_submit_impl(st, frames[i], ws[i], hs[i], factor, mode, i, pin_in, direct);
-            }
-        }
-        while (rc == INFUR_OK && infur_stream_pending(st) > 0) rc = collect_one();
-        if (rc != INFUR_OK) {  // frames may still be in flight into the caller's view of the ring: drop it, the next call builds a new one
-            const std::string keep = c->err;  // destroy() synchronises and must not lose the message
-            infur_stream_destroy(st);
-            c->batch_ring = nullptr;
-            c->err = keep;
-        }
-        return rc;
-    } catch (const std::bad_alloc&) {
-        return fail(c, INFUR_E_CAPACITY, "out of host memory");
-    } catch (const std::exception& e) {
-        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
-    }
-}
+// ---- streaming ring, frame batch, pinned host buffers: infur_stream.cpp ----
 
 // ---- range monitor of the split mode ----
 int32_t infur_split_range(infur_ctx* c, float* act_amax, float* wino_amax, uint32_t* saturated) {
@@ -2784,62 +1837,7 @@ int32_t infur_split_range(infur_ctx* c, float* act_amax, float* wino_amax, uint3
     return INFUR_OK;
 }
 
-// ---- tuning database ----
-int32_t infur_tune_export(infur_ctx* c, char* buf, size_t cap, size_t* len) {
-    try {
-        enter(c);
-        if (!c || !len) return INFUR_E_INVALID_ARG;
-        std::string out;
-        char line[256];
-        for (const auto& kv : c->tuned) {
-            int n = 0;
-            for (int v : kv.first) n += snprintf(line + n, sizeof line - n, "%d ", v);
-            snprintf(line + n, sizeof line - n, "%d\n", kv.second);
-            out += line;
-        }
-        *len = out.size();
-        if (!buf) return INFUR_OK;
-        if (cap < out.size()) return fail(c, INFUR_E_CAPACITY, "tuning text needs %zu bytes", out.size());
-        memcpy(buf, out.data(), out.size());
-        return INFUR_OK;
-    } catch (const std::bad_alloc&) {
-        return fail(c, INFUR_E_CAPACITY, "out of host memory");
-    } catch (const std::exception& e) {
-        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
-    }
-}
-
-int32_t infur_tune_import(infur_ctx* c, const char* text, size_t len) {
-    try {
-        enter(c);
-        if (!c || (!text && len)) return INFUR_E_INVALID_ARG;
-        std::string t(text ? text : "", len);
-        size_t pos = 0;
-        while (pos < t.size()) {
-            size_t eol = t.find('\n', pos);
-            if (eol == std::string::npos) eol = t.size();
-            const std::string ln = t.substr(pos, eol - pos);
-            pos = eol + 1;
-            if (ln.empty() || ln[0] == '#') continue;
-            std::array<int, 13> key;
-            int cfg = -1, off = 0, n = 0;
-            bool ok = true;
-            for (int i = 0; i < 13 && ok; i++) {
-                ok = sscanf(ln.c_str() + off, "%d%n", &key[i], &n) == 1;
-                off += n;
-            }
-            ok = ok && sscanf(ln.c_str() + off, "%d", &cfg) == 1;
-            if (!ok || cfg < 0 || cfg >= conv_igemm_num_configs()) return fail(c, INFUR_E_INVALID_ARG, "bad tuning line: %s", ln.c_str());
-            c->tuned[key] = cfg;
-            c->mem_gen++;
-        }
-        return INFUR_OK;
-    } catch (const std::bad_alloc&) {
-        return fail(c, INFUR_E_CAPACITY, "out of host memory");
-    } catch (const std::exception& e) {
-        return fail(c, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
-    }
-}
+// ---- tuning database: infur_tuner.cpp ----
 
 // ---- profiling ----
 int32_t infur_profile_enable(infur_ctx* c, uint32_t on) {

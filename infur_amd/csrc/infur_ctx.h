@@ -190,4 +190,6 @@ int32_t ctx_fail(infur_ctx* c, int32_t code, const char* fmt, ...) __attribute__
 void ctx_enter(const infur_ctx* c);
 // releases the context's weights and marks it unloaded
 void ctx_model_free(infur_ctx* c);
+// infur_stream.cpp: releases a streaming ring's resources and detaches it from its context(s); the handle stays allocated
+void stream_orphan(infur_stream* st);
 }  // namespace infur

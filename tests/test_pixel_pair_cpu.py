@@ -1,4 +1,4 @@
-"""The pixel-pair arrangement of the quantised layer1 (infur_amd/csrc/infur_capi.cpp: model_load_q_dev / forward_q) as
+"""The pixel-pair arrangement of the quantised layer1 (infur_amd/csrc/infur_quant_model.cpp: model_load_q_dev / forward_q) as
 integer arithmetic in numpy: a 64-channel NHWC tensor viewed as (H, W/2, 128) and convolved with the pair-arranged weights gives,
 viewed back, exactly the plain convolution.  This is the index formula the loader implements -- the GPU tests check the bytes of the
 whole network against the oracle; this one pins the formula itself, 1x1 and 3x3, without a GPU."""
