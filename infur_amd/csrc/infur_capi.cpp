@@ -1012,12 +1012,27 @@ static hipStream_t pool_stream(int device, int* slot) {
             }
         g_pool_made[device] = true;
     }
-    for (int tries = 0; tries < kPool; tries++) {
-        const int k = (int)(g_pool_next[device]++ % kPool);
+    // the next FREE entry in round-robin order (contexts created one after the other get consecutive entries, and a context never
+    // shares a stream while an unused one exists -- sharing also costs the sharer its graph replay); when all eight are held, the
+    // least-used one that no capturing context has reserved
+    int pick = -1;
+    for (int tries = 0; tries < kPool && pick < 0; tries++) {
+        const int k = (int)((g_pool_next[device] + (unsigned)tries) % kPool);
+        if (!g_pool_excl[device][k] && g_pool_users[device][k] == 0) pick = k;
+    }
+    for (int tries = 0; tries < kPool && pick < 0; tries++) {
+        const int k = (int)((g_pool_next[device] + (unsigned)tries) % kPool);
         if (g_pool_excl[device][k]) continue;  // reserved by a capturing context
-        *slot = k;
-        g_pool_users[device][k]++;
-        return g_pool[device][k];
+        bool least = true;
+        for (int j = 0; j < kPool; j++)
+            if (!g_pool_excl[device][j] && g_pool_users[device][j] < g_pool_users[device][k]) least = false;
+        if (least) pick = k;
+    }
+    if (pick >= 0) {
+        g_pool_next[device] = (unsigned)pick + 1;
+        *slot = pick;
+        g_pool_users[device][pick]++;
+        return g_pool[device][pick];
     }
     // every pool stream is reserved: a private stream (slot stays -1, the caller owns and destroys it)
     hipStream_t own = nullptr;
