@@ -122,11 +122,15 @@ def test_capture_never_runs_on_a_stream_another_context_uses():
     ctxs = [Context(device=0, dtype="f16") for _ in range(9)]
     try:
         L = ctxs[0].L
-        before = L.infur_ctx_stream(ctxs[0].h)
-        assert before == L.infur_ctx_stream(ctxs[8].h)  # the ninth context shares the first one's pool stream
-        ctxs[0].check(L.infur_ctx_set_graph_replay(ctxs[0].h, 1))
-        assert L.infur_ctx_stream(ctxs[0].h) == before
-        _hammer_while_replaying(ctxs, ctxs[0], ctxs[8], blob, expect_capture=False)
+        handles = [L.infur_ctx_stream(c.h) for c in ctxs]
+        # nine live contexts on a pool of eight: at least two of them hold the same stream (a free entry is always preferred, so
+        # which two depends on what else is alive in the process)
+        pair = next((i, j) for i in range(9) for j in range(i + 1, 9) if handles[i] == handles[j])
+        first, other = ctxs[pair[0]], ctxs[pair[1]]
+        before = L.infur_ctx_stream(first.h)
+        first.check(L.infur_ctx_set_graph_replay(first.h, 1))
+        assert L.infur_ctx_stream(first.h) == before
+        _hammer_while_replaying(ctxs, first, other, blob, expect_capture=False)
     finally:
         for c in ctxs:
             c.close()
