@@ -560,11 +560,9 @@ static hipError_t launch_hl_t(const ConvArgs& a, int out_f32, hipStream_t s) {
 
 // configurations of mode 5 (indices of conv_igemm.hip's table whose tile dimensions they share): 11 = 256x256 (8 waves of
 // 128x64), 0 = 128x128 (4 waves of 64x64), 6 = 256x128 (8 waves of 64x64), 5 = 128x256 (8 waves of 64x64); 12 = 256x128 and
-// 14 = 128x256 as FOUR waves of 128x64 with a ring of two images: two workgroups per CU; 13 = 256x256 as 8 waves of 64x128;
-// narrow N tiles (four waves, ring of two) for the layers whose Cout is far below 128: 2 = 256x64 (layer1's 64-channel convs: half
-// the weight ingest and half the MFMAs of the 128-wide tile), 4 = 256x32 (the 21-class logit convs)
+// 14 = 128x256 as FOUR waves of 128x64 with a ring of two images: two workgroups per CU
 bool conv_hl_config_valid(const ConvArgs& a, int cfg, int out_f32) {
-    if (cfg != 11 && cfg != 0 && cfg != 6 && cfg != 5 && cfg != 12 && cfg != 14 && cfg != 13 && cfg != 2 && cfg != 4) return false;
+    if (cfg != 11 && cfg != 0 && cfg != 6 && cfg != 5 && cfg != 12 && cfg != 14 && cfg != 13) return false;
     if (!a.in_lo || !a.wt_lo) return false;
     if (a.in2 && (!a.in2_lo || out_f32 || a.res || a.KH != 1 || a.KW != 1 || a.pad != 0 || a.stride != 1 || a.Cin2 % HL_KC != 0 || a.batch > 1 ||
                   (size_t)a.H2 * a.W2 * a.Cin2 * 2 >= 0x80000000ull))
@@ -574,9 +572,7 @@ bool conv_hl_config_valid(const ConvArgs& a, int cfg, int out_f32) {
     if (out_f32 ? (a.res != nullptr) : (!a.out_lo || (a.res != nullptr) != (a.res_lo != nullptr) || (a.Cout & 7))) return false;
     if (a.batch > 1 && (a.in_bs & 1 || a.wt_bs & 1 || !out_f32)) return false;
     if ((size_t)a.Cout * (a.in2 ? a.Cin + a.Cin2 : a.KH * a.KW * a.Cin) * 2 >= 0x80000000ull) return false;
-    const int bn = (cfg == 11 || cfg == 5 || cfg == 14 || cfg == 13) ? 256 : (cfg == 2 ? 64 : (cfg == 4 ? 32 : 128));
-    if (bn == 64) return a.Cout <= 64;
-    if (bn == 32) return a.Cout <= 32;
+    const int bn = (cfg == 11 || cfg == 5 || cfg == 14 || cfg == 13) ? 256 : 128;
     return bn <= a.Cout || bn == 128;  // Cout < 128 (layer1, the logits): the 128-wide N tile with its surplus rows out of range
 }
 
@@ -591,8 +587,6 @@ hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s
         case 12: return launch_hl_t<256, 128, 2, 2, 2>(a, out_f32, s);
         case 14: return launch_hl_t<128, 256, 1, 4, 2>(a, out_f32, s);
         case 13: return launch_hl_t<256, 256, 4, 2>(a, out_f32, s);  // 8 waves of 64 x 128: a wave's epilogue rows are 128 channels wide
-        case 2: return launch_hl_t<256, 64, 4, 1, 2>(a, out_f32, s);
-        case 4: return launch_hl_t<256, 32, 4, 1, 2>(a, out_f32, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -120,8 +120,6 @@ const char* conv_igemm_config_name(int cfg, int mode) {
             case 12: return "conv_hl<256,128,4w>";
             case 14: return "conv_hl<128,256,4w>";
             case 13: return "conv_hl<256,256,wn2>";
-            case 2: return "conv_hl<256,64,4w>";
-            case 4: return "conv_hl<256,32,4w>";
             default: return "conv_hl<?>";
         }
     }
