@@ -17,8 +17,9 @@ JOBS = [  # (dtype, depth, (w, h), factor)
     ("f32s", 50, (1920, 1080), 1.0), ("f32s", 50, (1920, 1080), 0.5), ("f32s", 50, (640, 480), 1.0),
     ("f32x", 50, (1920, 1080), 1.0), ("f32x", 50, (1920, 1080), 0.5),
     ("i8", 50, (1920, 1080), 1.0), ("i8", 50, (1920, 1080), 0.5), ("i8", 50, (640, 480), 1.0),  # the quantised model (INFURQ01)
+    ("f16hl", 50, (1920, 1080), 1.0), ("f16hl", 50, (1920, 1080), 0.5), ("f16hl", 50, (640, 480), 1.0), ("f16hl", 101, (3840, 2160), 1.0),
 ]
-MODE = {"f32": "0", "f16": "1", "f32s": "2", "f32x": "3", "i8": "4"}  # the `mode` column of the database
+MODE = {"f32": "0", "f16": "1", "f32s": "2", "f32x": "3", "i8": "4", "f16hl": "5"}  # the `mode` column of the database
 
 
 def main():
