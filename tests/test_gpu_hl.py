@@ -220,3 +220,37 @@ def test_hl_resnet101_batch_and_stream(oracle):
         assert (rgba == got).all()
     sp.close()
     c.close()
+
+
+def test_hl_group_replicas_and_pinned_batch(blob50):
+    """the three-byte mode through the group calls: the weight arena (hi AND lo planes, the two-source matrices, the Winograd planes)
+    is replicated to the other contexts with every pointer re-based (infur_multi.cpp: adopt_model), the batch is sharded over them,
+    frames and masks in pinned caller buffers travel without staging copies -- same masks as one context, in frame order"""
+    from infur_amd.app import PinnedArray
+    from infur_amd.processors import Group
+
+    imgs = [W.synth_frame(64 + 16 * (i % 2), 96, index=i) for i in range(7)]
+    ctxs = [Context(device=0, dtype="f16hl") for _ in range(3)]
+    pins = []
+    try:
+        Model(ctxs[0]).control(ModelCmd.LoadBlob(blob50))
+        ref = FramePath(ctxs[0]).advance_batch(imgs, 0.5)
+        with Group(ctxs) as g:
+            g.weights_broadcast(root=0)
+            got = g.advance_batch(imgs, 0.5)
+            assert len(got) == 7 and all((a == b).all() for a, b in zip(got, ref))
+            for c in ctxs[1:]:  # every context really holds a working replica
+                solo, _ = FramePath(c).advance(imgs[0], 0.5)
+                assert (solo == ref[0]).all()
+            pin_in = [PinnedArray(im.shape) for im in imgs]
+            pin_out = [PinnedArray(r.shape) for r in ref]
+            pins = pin_in + pin_out
+            for p, im in zip(pin_in, imgs):
+                np.copyto(p.array, im)
+            got = g.advance_batch([p.array for p in pin_in], 0.5, outs=[p.array for p in pin_out])
+            assert all((a == b).all() for a, b in zip(got, ref))
+    finally:
+        for p in pins:
+            p.close()
+        for c in ctxs:
+            c.close()
