@@ -28,12 +28,15 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "qepilogue.h"
 
 namespace infur {
 
 typedef float f32x16h __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8h __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
+typedef int i32x4h __attribute__((ext_vector_type(4)));
+typedef int i32x16h __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_h;
 
 namespace {
@@ -106,8 +109,13 @@ __host__ __device__ constexpr int h_lds(int bn, int na, int th, int tw, int d) {
     return operands > staging ? operands : staging;
 }
 
-template <int BN, int NA>
+// I8 (round 5): the same kernel on the quantised model's tensors -- u8 activations x s8 weights on v_mfma_i32_32x32x32_i8, a 128-byte
+// pixel row holds 128 channels instead of 64, the requantisation of QLinearConv in the epilogue (qepilogue.h, the Q8 form of
+// conv_igemm_kernel.h: 16 channels per lane).  Every byte address, swizzle and DMA piece is the f16 form's; integer accumulation is
+// exact in any order, so the result is the tiled `dmai` form's, byte for byte (tests/test_gpu_quant.py).
+template <int BN, int NA, bool I8 = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, const HaloGeom g, const int ntiles) {
+    constexpr int ES = I8 ? 1 : 2;           // bytes per element
     constexpr int WN = BN / 64, WM = 8 / WN;  // waves along N (64 channels each) / along M
     constexpr int TM = 256 / WM / 32, TN = 2;
     constexpr int BKB = h_bkb(BN);           // bytes of k per weight step: a whole tap's 128, or half a tap
@@ -140,8 +148,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
     const int npiece = (P + 7) / 8, pimg = npiece * 1024;
     const int npix = th * tw;              // GEMM rows that are pixels of the tile (the rest of the 256 is padding)
     const float rtw = 1.0f / (float)tw;    // row -> (ty, tx): exact for these small integers
-    const int Kb = a.Cin * 2;      // bytes of a pixel's channels
-    const int cchunks = a.Cin / 64;
+    const int Kb = a.Cin * ES;     // bytes of a pixel's channels
+    const int cchunks = Kb / 128;
 
     char* const As = smem;              // [NA][npiece * 8 rows][128]
     char* const Bs = smem + NA * pimg;  // [NB][BN][BKB]
@@ -268,9 +276,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
                     if (kl == 0 && issue_a) dma_a(tap, cc + 1, aimg ^ 1);
                     if (kl == (SL > 1 ? 1 : 0) && issue_b) dma_b(q + NB - 1 >= SPC ? cc + 1 : cc, q + NB - 1 >= SPC ? q + NB - 1 - SPC : q + NB - 1, bnext);
 #pragma unroll
-                    for (int i = 0; i < TM; i++)
+                    for (int i = 0; i < TM; i++) {
+                        // (I8: activations are u8, the MFMA is signed: x ^ 0x80 = x - 128 as s8; the -128 * sum w is in q_bias, and an
+                        //  out-of-image halo pixel -- zeros from the DMA's bounds check -- is x = 0 = the zero point of a padded tensor)
+                        const i32x4h ax = __builtin_bit_cast(i32x4h, fa[kl & 1][i]) ^ (int)0x80808080;
 #pragma unroll
-                        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kl & 1][j], fa[kl & 1][i], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; j++) {
+                            if constexpr (I8)
+                                acc[i][j] = __builtin_bit_cast(f32x16h, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4h, fb[kl & 1][j]), ax,
+                                                                                                               __builtin_bit_cast(i32x16h, acc[i][j]), 0, 0, 0));
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kl & 1][j], fa[kl & 1][i], acc[i][j], 0, 0, 0);
+                        }
+                    }
                 }
                 // The NEXT step's weights must have landed (and, at a chunk's last step, the next chunk's whole patch); loads retire in
                 // order, so what may stay in flight is exactly what was issued after them: this step's weight pieces (for two steps
@@ -291,6 +309,68 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const ConvArgs a, 
     // ---- epilogue: + bias, ReLU, f16; each wave passes its 32-pixel blocks through its own LDS slice so that 8 lanes store the
     //      128 contiguous bytes of a pixel's 64 channels (the f16 -> f16 form of conv_igemm_kernel.h, same steps per value) ----
     char* stage = smem + wave * 32 * H_ROWB;
+    if constexpr (I8) {
+        // QLinearConv's requantisation, 16 channels per lane (four lanes on the 64 bytes of a pixel's channels of this wave): the Q8
+        // epilogue of conv_igemm_kernel.h without the residual sum (a 3x3 conv has none)
+        const int q_row = lane >> 2, q_col = lane & 3;
+        const int nq = n0 + wn * 64 + q_col * 16;
+        const bool nq_ok = nq < a.Cout;
+        int qb[16];
+        float qm[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            qb[t] = 0;
+            qm[t] = 0.f;
+        }
+        if (nq_ok) {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) {
+                const qi4 b4 = *reinterpret_cast<const qi4*>(a.q_bias + nq + 4 * t4);
+                const qf4 m4 = *reinterpret_cast<const qf4*>(a.q_mult + nq + 4 * t4);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    qb[4 * t4 + t] = b4[t];
+                    qm[4 * t4 + t] = m4[t];
+                }
+            }
+        }
+        const float q_yzpf = (float)a.q_yzp;
+        const QEpi qe = {q_yzpf, -q_yzpf, 255.f - q_yzpf, a.q_ra, a.q_rb, (float)a.q_bzp, (float)a.q_czp};
+        unsigned char* outq = static_cast<unsigned char*>(a.out);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int jj = 0; jj < TN; jj++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const float4 v = make_float4(acc[i][jj][4 * g4 + 0], acc[i][jj][4 * g4 + 1], acc[i][jj][4 * g4 + 2], acc[i][jj][4 * g4 + 3]);
+                    *reinterpret_cast<float4*>(stage + h_pix(r, tw) * H_ROWB + (jj * 32 + 8 * g4 + 4 * hh) * 4) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int row = it * 16 + q_row;
+                const int R = (wm * TM + i) * 32 + row;
+                const int ty = (int)(((float)R + 0.5f) * rtw), tx = R - ty * tw;
+                const int oy = y0 + ty, ox = x0 + tx;
+                if (R < npix && oy < a.OH && ox < a.OW && nq_ok) {
+                    u32x4h pk;
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; t4++) {
+                        const qi4 ai = *reinterpret_cast<const qi4*>(stage + row * H_ROWB + q_col * 64 + t4 * 16);
+                        const qi4 a4 = {ai[0] + qb[4 * t4], ai[1] + qb[4 * t4 + 1], ai[2] + qb[4 * t4 + 2], ai[3] + qb[4 * t4 + 3]};
+                        const qf4 m4 = {qm[4 * t4], qm[4 * t4 + 1], qm[4 * t4 + 2], qm[4 * t4 + 3]};
+                        pk[t4] = q_word<false>(a4, m4, 0u, qe);
+                    }
+                    *reinterpret_cast<u32x4h*>(outq + ((size_t)oy * a.OW + ox) * a.Cout + nq) = pk;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     const int e_row = lane >> 3, e_col = lane & 7;
     const int n = n0 + wn * 64 + e_col * 8;
     const bool n_ok = n < a.Cout;
@@ -341,8 +421,9 @@ struct HaloPlan {
     HaloGeom g{};
     int na = 0, lds = 0;
 };
-HaloPlan halo_plan(const ConvArgs& a, int bn) {
+HaloPlan halo_plan(const ConvArgs& a, int bn, int es = 2) {
     HaloPlan best;
+    const int kchunks = a.Cin * es / 128;  // 128-byte channel chunks per pixel (f16: 64 channels each, i8: 128)
     long best_cost[3] = {0, 0, 0};
     const int ntiles = a.Cout / bn, d = a.dil, H = a.OH, W = a.OW;
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
@@ -357,7 +438,7 @@ HaloPlan halo_plan(const ConvArgs& a, int bn) {
     for (int ci = 0; ci < nc; ci++)
         // (one channel chunk: there is no next patch to prefetch; BN = 64 exists in the single-patch-image form only -- launch_conv3x3_halo
         //  runs launch_halo<64, 1> -- so its plan, LDS size and workgroups-per-CU estimate must describe that form: ADVICE r4)
-        for (int na = ((a.Cin == 64 || bn == 64) ? 1 : 2); na >= 1; na--) {
+        for (int na = ((kchunks == 1 || bn == 64) ? 1 : 2); na >= 1; na--) {
             const HaloGeom& g = cands[ci];
             int lds = h_lds(bn, na, g.th1, g.tw1, d), pieces = h_pieces(g.th1, g.tw1, d);
             long patch = (long)(g.th1 + 2 * d) * (g.tw1 + 2 * d);
@@ -370,7 +451,7 @@ HaloPlan halo_plan(const ConvArgs& a, int bn) {
             const long per_cu = (bn <= 128 && na == 1 && lds <= 80 * 1024) ? 2 : 1;
             const long wgs = (long)g.mtiles * ntiles, slots = 256L * per_cu;
             // one patch image costs a barrier + an exposed patch load per channel chunk: ~10 % of a round
-            const long cost[3] = {(wgs + slots - 1) / slots * ((na == 1 && a.Cin > 64) ? 11 : 10), g.mtiles, patch};
+            const long cost[3] = {(wgs + slots - 1) / slots * ((na == 1 && kchunks > 1) ? 11 : 10), g.mtiles, patch};
             bool better = best.na == 0;
             for (int k = 0; k < 3 && !better; k++) {
                 if (cost[k] < best_cost[k]) better = true;
@@ -744,10 +825,10 @@ HaloPlan halo4_plan(const ConvArgs& a) {
     return best;
 }
 
-template <int BN, int NA>
+template <int BN, int NA, bool I8 = false>
 hipError_t launch_halo(const ConvArgs& a, const HaloPlan& pl, hipStream_t s) {
     const int ntiles = a.Cout / BN;
-    auto k = conv3x3_halo_kernel<BN, NA>;
+    auto k = conv3x3_halo_kernel<BN, NA, I8>;
     // (the LDS size depends on the dilation and the tile shape: the attribute is raised to the largest footprint there is)
     static std::atomic<bool> attr_done[64];
     int dev = 0;
@@ -777,6 +858,14 @@ static int halo_bn(const ConvArgs& a, int bn) {
 }
 
 bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn) {
+    if (mode == 4) {  // the quantised model's 3x3 convs (u8 out): BN = 128 / 256, 128-byte rows = 128 channels
+        if (out_f32 || (bn != 128 && bn != 256) || !a.q_mult || !a.q_bias) return false;
+        if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != a.dil || (a.dil != 1 && a.dil != 2 && a.dil != 4)) return false;
+        if (a.res || a.in2 || a.batch > 1 || a.OH != a.H || a.OW != a.W) return false;
+        if (a.Cin % 128 != 0 || a.Cout % bn != 0) return false;
+        if (halo_plan(a, bn, 1).na == 0) return false;
+        return (size_t)a.H * a.W * a.Cin < 0x80000000ull && (size_t)a.Cout * 9 * a.Cin < 0x80000000ull;
+    }
     bn = halo_bn(a, bn);
     if (mode != 1 || out_f32 || (bn != 64 && bn != 128 && bn != 256)) return false;
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != a.dil || (a.dil != 1 && a.dil != 2 && a.dil != 4)) return false;
@@ -785,6 +874,13 @@ bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn) {
     if (halo_plan(a, bn).na == 0) return false;
     // 32-bit buffer offsets with 0x80000000 (+ the channel chunk's scalar offset) as the out-of-range marker
     return (size_t)a.H * a.W * a.Cin * 2 < 0x80000000ull && (size_t)a.Cout * 9 * a.Cin * 2 < 0x80000000ull;
+}
+
+hipError_t launch_conv3x3_halo_q(const ConvArgs& a, int bn, hipStream_t s) {
+    if (!conv3x3_halo_valid(a, 4, 0, bn)) return hipErrorInvalidValue;
+    const HaloPlan pl = halo_plan(a, bn, 1);
+    if (bn == 128) return pl.na == 2 ? launch_halo<128, 2, true>(a, pl, s) : launch_halo<128, 1, true>(a, pl, s);
+    return pl.na == 2 ? launch_halo<256, 2, true>(a, pl, s) : launch_halo<256, 1, true>(a, pl, s);
 }
 
 hipError_t launch_conv3x3_halo(const ConvArgs& a, int bn, hipStream_t s) {

@@ -1059,6 +1059,7 @@ static hipError_t launch_t(const ConvArgs& a, int cfg, hipStream_t s) {
         case 19:
         case 20:
             if constexpr (std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value && !SPLIT) return launch_conv3x3_halo(a, cfg == 19 ? 128 : 256, s);
+            if constexpr (std::is_same<T, signed char>::value && std::is_same<OutT, unsigned char>::value) return launch_conv3x3_halo_q(a, cfg == 19 ? 128 : 256, s);
             return hipErrorInvalidValue;
         case 21:
             if constexpr (std::is_same<T, _Float16>::value && std::is_same<OutT, _Float16>::value && !SPLIT) return launch_conv3x3_halo4(a, s);

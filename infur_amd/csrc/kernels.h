@@ -100,6 +100,8 @@ int conv1x1_q8_nsplit(const ConvArgs& a);  // configuration 18: N tiles shared o
 // tile stays in LDS for all nine taps (conv3x3_halo.hip).  Configurations 19 (bn = 128), 20 (bn = 256) and 21 (the 4-wave form) of mode 1.
 bool conv3x3_halo_valid(const ConvArgs& a, int mode, int out_f32, int bn);
 hipError_t launch_conv3x3_halo(const ConvArgs& a, int bn, hipStream_t s);
+// the same kernel on the quantised model's tensors (mode 4, u8 out): configurations 19 / 20 of that mode
+hipError_t launch_conv3x3_halo_q(const ConvArgs& a, int bn, hipStream_t s);
 // the 4-wave form (configuration 21): BN = 256, one wave per SIMD with a 128 x 128 wave tile, dilation 1 / 2
 bool conv3x3_halo4_valid(const ConvArgs& a, int mode, int out_f32);
 hipError_t launch_conv3x3_halo4(const ConvArgs& a, hipStream_t s);
