@@ -323,6 +323,22 @@ def test_conv1x1_q8_forced_on_every_1x1_is_bit_exact(cfg):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("cfg", ["19", "20"])
+def test_lds_patch_3x3_forced_on_every_3x3_is_bit_exact(cfg):
+    """conv3x3_halo.hip on the i8 MFMA (round 5: configurations 19 / 20 of the quantised mode -- the input patch of a 16 x 16 tile
+    resident in LDS for all nine taps, QLinearConv's requantisation in its epilogue) forced onto every stride-1 3x3 conv, dilation 1,
+    2 and 4, ragged tiles included: the layer-by-layer, hostile-parameter, ResNet-101 and 640x480 cases of this file run again in a
+    child process and must still give the integer oracle's bytes"""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, INFUR_CONV_CFG=cfg)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
+                        "every_layer or hostile or resnet101 or 640x480"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def test_layer1_padded_form_still_gives_the_oracles_bytes():
     """forward_q runs layer1 of a quantised model on PIXEL PAIRS when the pooled width is even (no channel padding, pair-arranged
     weights); INFUR_Q_NOPAIR=1 keeps the padded form (read once per process: a child process).  The whole-frame cases of this file
