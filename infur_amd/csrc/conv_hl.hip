@@ -36,37 +36,10 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "hl_format.h"
-#include "kernels.h"
+#include "conv_hl_dev.h"
 
 namespace infur {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-constexpr unsigned HL_OOB = 0x80000000u;  // out of range for every tensor accepted (< 2 GiB): the DMA lands zeros
-constexpr int HL_KC = 32;                 // channels per K step
-
-// LDS-DMA, 16 bytes per lane to (M0) + lane * 16 (conv_igemm_kernel.h: dma16 -- inline asm so that OUR vmcnt orders it)
-__device__ __forceinline__ void hl_dma16(const u32x4r rsrc, const unsigned lds, const unsigned voff, const unsigned soff) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(lds), "s"(rsrc), "s"(soff)
-        : "memory");
-}
-
-__host__ __device__ constexpr int hl_swz64(int row) { return (row >> 2) & 3; }
-__host__ __device__ constexpr int hl_swz32(int row) { return (row >> 3) & 1; }
 constexpr int hl_image_bytes(int bm, int bn) { return (bm + bn) * 96; }
 constexpr int hl_lds_bytes(int bm, int bn, int wm, int wn, int nimg) {
     const int operands = nimg * hl_image_bytes(bm, bn);
@@ -74,9 +47,6 @@ constexpr int hl_lds_bytes(int bm, int bn, int wm, int wn, int nimg) {
     return operands > staging ? operands : staging;
 }
 constexpr int hl_ceil_div(int a, int b) { return (a + b - 1) / b; }
-
-// top bytes of the four f16 in (d0, d1): [d0.b1, d0.b3, d1.b1, d1.b3]
-__device__ __forceinline__ int hl_top4(const unsigned d0, const unsigned d1) { return (int)__builtin_amdgcn_perm(d1, d0, 0x07050301u); }
 
 // DUAL (with G1): the K loop runs over two activation tensors in turn (ConvArgs.in, then ConvArgs.in2 sampled with stride2) against
 // one weight matrix whose rows are the two 1x1 kernels side by side -- a bottleneck's conv3 and the downsample branch of a stage's
@@ -562,6 +532,7 @@ static hipError_t launch_hl_t(const ConvArgs& a, int out_f32, hipStream_t s) {
 // 128x64), 0 = 128x128 (4 waves of 64x64), 6 = 256x128 (8 waves of 64x64), 5 = 128x256 (8 waves of 64x64); 12 = 256x128 and
 // 14 = 128x256 as FOUR waves of 128x64 with a ring of two images: two workgroups per CU
 bool conv_hl_config_valid(const ConvArgs& a, int cfg, int out_f32) {
+    if (cfg == 15) return conv_hl_areg_valid(a, out_f32);  // conv_hl_areg.hip: the activation fragment in registers (1x1 expansions)
     if (cfg != 11 && cfg != 0 && cfg != 6 && cfg != 5 && cfg != 12 && cfg != 14 && cfg != 13) return false;
     if (!a.in_lo || !a.wt_lo) return false;
     if (a.in2 && (!a.in2_lo || out_f32 || a.res || a.KH != 1 || a.KW != 1 || a.pad != 0 || a.stride != 1 || a.Cin2 % HL_KC != 0 || a.batch > 1 ||
@@ -580,6 +551,7 @@ hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s
     if (cfg < 0) cfg = a.Cout >= 256 && (size_t)a.OH * a.OW * (a.batch > 1 ? a.batch : 1) >= 256 * 200 ? 11 : 0;
     if (!conv_hl_config_valid(a, cfg, out_f32)) return hipErrorInvalidValue;
     switch (cfg) {
+        case 15: return launch_conv_hl_areg(a, s);
         case 11: return launch_hl_t<256, 256, 2, 4>(a, out_f32, s);
         case 0: return launch_hl_t<128, 128, 2, 2>(a, out_f32, s);
         case 6: return launch_hl_t<256, 128, 4, 2>(a, out_f32, s);

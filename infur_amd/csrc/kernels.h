@@ -83,6 +83,10 @@ const char* conv_igemm_config_name(int cfg, int mode);
 // mode 5 (conv_hl.hip)
 bool conv_hl_config_valid(const ConvArgs& a, int cfg, int out_f32);
 hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s);
+// configuration 15 of mode 5 (conv_hl_areg.hip): 1x1 expansions (Cin 64 / 128 / 256, Cout a multiple of 128) with the activation
+// fragment in registers, weights and residual streamed by LDS-DMA; bit-identical to the tiled forms
+bool conv_hl_areg_valid(const ConvArgs& a, int out_f32);
+hipError_t launch_conv_hl_areg(const ConvArgs& a, hipStream_t s);
 // weights of mode 5, one-off at load: f32 [n] (kernel K order) * scale -> f16 hi [n], e5m2 lo [n] (n % 4 == 0)
 hipError_t launch_hl_pack_weights(const float* w, size_t n, float scale, void* hi, void* lo, hipStream_t s);
 

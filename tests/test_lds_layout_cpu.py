@@ -157,3 +157,56 @@ def test_conv_hl_dma_pieces_cover_the_image_exactly_once():
         for row in range(rows):
             for q in range(2):
                 assert where[(row, q)] == row * 32 + ((q ^ hl_swz32(row)) * 16)
+
+
+# ---- conv_hl_areg.hip: a wave's residual / output slot (32 rows of 2 W bytes hi and W bytes lo, W = 64 or 128 channels per wave),
+#      DMA pieces of 1 KB of whole rows, accumulator-layout accesses in place, and the row permutation of the weight tile ----
+def ah_swz8(row):
+    return (row >> 1) & 7
+
+
+def ah_pi(r):
+    return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+
+
+@pytest.mark.parametrize("wch", [64, 128])
+def test_conv_hl_areg_slot_pieces_and_accumulator_accesses_agree(wch):
+    """piece p, lane l lands at p * 1024 + l * 16; the kernel sends it the data chunk (l % chunks_per_row) ^ swz(row) of row
+    rows_per_piece * p + l // chunks_per_row.  The epilogue looks for channels 32 j + 16 s + 8 h .. + 7 of row r at hi chunk
+    (4 j + 2 s + h) ^ swz(r) and at lo chunk (2 j + s) ^ swz(r), half h: both must be where the DMA put them, and every chunk of the
+    slot must be written exactly once"""
+    for plane, row_bytes in (("hi", 2 * wch), ("lo", wch)):
+        chunks = row_bytes // 16
+        rows_pp = 1024 // row_bytes
+        swz = ah_swz8 if chunks >= 8 else hl_swz64
+        where = {}
+        for p in range(32 * row_bytes // 1024):
+            for l in range(64):
+                row = rows_pp * p + l // chunks
+                d = (l % chunks) ^ swz(row)
+                assert 0 <= d < chunks and (row, d) not in where
+                where[(row, d)] = p * 1024 + l * 16
+        assert len(where) == 32 * chunks
+        for r in range(32):
+            for j in range(wch // 32):
+                for s_ in range(2):
+                    for h in range(2):
+                        d = 4 * j + 2 * s_ + h if plane == "hi" else 2 * j + s_
+                        assert where[(r, d)] == r * row_bytes + ((d ^ swz(r)) * 16)
+
+
+def test_conv_hl_areg_slot_hi_accesses_are_conflict_free():
+    """the in-place b128 accesses of the 64-channel form: lane (r, h) at chunk (4 j + 2 s + h) ^ swz8(r) of its 128-byte row"""
+    for j in range(2):
+        for s_ in range(2):
+            assert extra_cycles_b128(lambda l: (l & 31) * 128 + (((4 * j + 2 * s_ + (l >> 5)) ^ ah_swz8(l & 31)) * 16)) == 0
+
+
+def test_conv_hl_areg_row_permutation_gives_eight_consecutive_channels():
+    """weight-tile row R holds output channel pi(R); in the MFMA's C/D layout lane (pixel, h) register 4 g + e is row 8 g + 4 h + e, so
+    registers 8 s .. 8 s + 7 must be the consecutive channels 16 s + 8 h .. + 7"""
+    assert sorted(ah_pi(r) for r in range(32)) == list(range(32))
+    for h in range(2):
+        for s_ in range(2):
+            chans = [ah_pi(8 * (reg // 4) + 4 * h + reg % 4) for reg in range(8 * s_, 8 * s_ + 8)]
+            assert chans == [16 * s_ + 8 * h + t for t in range(8)]
