@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         const int row = 16 * p + (lane >> 2);
         const int n = n0 + row;
         bh_dst[i] = (unsigned)(B_HI + p * 1024);
-        bh_off[i] = n < a.Cout ? (unsigned)n * (unsigned)(Ktot * 2) + (unsigned)(((lane & 3) ^ hl_swz64(row)) * 16) : HL_OOB;
+        bh_off[i] = n < a.Cout ? (unsigned)n * 64u + (unsigned)(((lane & 3) ^ hl_swz64(row)) * 16) : HL_OOB;  // (K-block-major weights)
     }
 #pragma unroll
     for (int i = 0; i < I_BL; i++) {
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         const int row = 32 * p + (lane >> 1);
         const int n = n0 + row;
         bl_dst[i] = (unsigned)(B_LO + p * 1024);
-        bl_off[i] = n < a.Cout ? (unsigned)n * (unsigned)Ktot + (unsigned)(((lane & 1) ^ hl_swz32(row)) * 16) : HL_OOB;
+        bl_off[i] = n < a.Cout ? (unsigned)n * 32u + (unsigned)(((lane & 1) ^ hl_swz32(row)) * 16) : HL_OOB;
     }
 
     // K step being LOADED: its index, its tap and channel chunk, the ring image it goes to
@@ -215,9 +215,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     };
     auto load_b = [&]() {
 #pragma unroll
-        for (int i = 0; i < I_BH; i++) hl_dma16(bh_v, sdst(bh_dst[i]), bh_off[i], (unsigned)kl * 64u);
+        for (int i = 0; i < I_BH; i++) hl_dma16(bh_v, sdst(bh_dst[i]), bh_off[i], (unsigned)kl * (unsigned)(a.Cout * 64));
 #pragma unroll
-        for (int i = 0; i < I_BL; i++) hl_dma16(bl_v, sdst(bl_dst[i]), bl_off[i], (unsigned)kl * 32u);
+        for (int i = 0; i < I_BL; i++) hl_dma16(bl_v, sdst(bl_dst[i]), bl_off[i], (unsigned)kl * (unsigned)(a.Cout * 32));
     };
     auto load_next = [&]() {  // advance the load cursor (all wave-uniform scalars)
         kl++;
@@ -563,9 +563,15 @@ hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s
     }
 }
 
-// ---- weights: f32 [n] (already in the kernel's K order) * scale -> hi f16 [n] at dst, lo e5m2 [n] at dst_lo ----
-__global__ void hl_pack_weights_kernel(const float* __restrict__ w, size_t n4, float scale, _Float16* __restrict__ hi, unsigned* __restrict__ lo) {
+// ---- weights: f32 [rows][cols] (already in the kernel's K order) * scale -> hi f16 at dst, lo e5m2 at dst_lo, both K-BLOCK-MAJOR:
+//      element (n, k) at ((k / 32) * rows + n) * 32 + k % 32.  The 32 channels of a K step of `BN` consecutive output channels -- one
+//      weight image of the kernels -- are then ONE contiguous block (BN x 64 bytes hi, BN x 32 bytes lo) and every 1-KB DMA piece
+//      is eight whole 128-byte lines instead of sixteen half lines 2 Ktot bytes apart: the weights are half of what a K step
+//      ingests, and the re-layout costs nothing (done once, at model load).  cols % 32 != 0 (no such GEMM layer): row-major. ----
+__global__ void hl_pack_weights_kernel(const float* __restrict__ w, size_t n4, unsigned rows, unsigned cols, float scale, _Float16* __restrict__ hi,
+                                       unsigned* __restrict__ lo) {
     __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+    const bool blocked = (cols & 31u) == 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(w)[i];
         const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
@@ -577,16 +583,23 @@ __global__ void hl_pack_weights_kernel(const float* __restrict__ w, size_t n4, f
             hv[t] = (_Float16)x[t];
             rem[t] = x[t] - (float)hv[t];
         }
-        reinterpret_cast<f16x4*>(hi)[i] = hv;
-        lo[i] = hl_pack_lo4(rem);
+        size_t o = i;  // in units of four elements
+        if (blocked) {
+            const size_t e = i * 4, n = e / cols, k = e - n * cols;
+            o = (((k >> 5) * rows + n) * 32 + (k & 31)) >> 2;
+        }
+        reinterpret_cast<f16x4*>(hi)[o] = hv;
+        lo[o] = hl_pack_lo4(rem);
     }
 }
 
-hipError_t launch_hl_pack_weights(const float* w, size_t n, float scale, void* hi, void* lo, hipStream_t s) {
-    if (n & 3) return hipErrorInvalidValue;
+hipError_t launch_hl_pack_weights(const float* w, size_t rows, size_t cols, float scale, void* hi, void* lo, hipStream_t s) {
+    const size_t n = rows * cols;
+    if (n & 3 || rows > 0xffffffffull || cols > 0xffffffffull) return hipErrorInvalidValue;
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(hl_pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, n / 4, scale, static_cast<_Float16*>(hi), static_cast<unsigned*>(lo));
+    hipLaunchKernelGGL(hl_pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, n / 4, (unsigned)rows, (unsigned)cols, scale, static_cast<_Float16*>(hi),
+                       static_cast<unsigned*>(lo));
     return hipGetLastError();
 }
 

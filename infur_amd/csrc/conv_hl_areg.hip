@@ -150,13 +150,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) conv_hl_areg_kernel(
 #pragma unroll
     for (int i = 0; i < PPI; i++) {
         const int row = 16 * (wave * PPI + i) + (lane >> 2);
-        bh_voff[i] = (unsigned)ah_pi(row) * (unsigned)(K * 2) + (unsigned)(((lane & 3) ^ hl_swz64(row)) * 16);
+        bh_voff[i] = (unsigned)ah_pi(row) * 64u + (unsigned)(((lane & 3) ^ hl_swz64(row)) * 16);  // (K-block-major weights: conv_hl.hip)
         // lo piece i of this wave: NW = 8: piece wave & 3 of K step wave >> 2; NW = 4: piece `wave` of K step i
         const int lp = NW == 8 ? (wave & 3) : wave, ls = NW == 8 ? (wave >> 2) : i;
         const int rowl = 32 * lp + (lane >> 1);
-        bl_voff[i] = (unsigned)ah_pi(rowl) * (unsigned)K + (unsigned)(((lane & 1) ^ hl_swz32(rowl)) * 16);
+        bl_voff[i] = (unsigned)ah_pi(rowl) * 32u + (unsigned)(((lane & 1) ^ hl_swz32(rowl)) * 16);
         bl_dst[i] = (unsigned)(ls * AH_SUB + AH_SUB_LO + lp * 1024);
-        bl_soff[i] = (unsigned)(ls * 32);
+        bl_soff[i] = (unsigned)(ls * a.Cout * 32);
     }
     const int Q = ntiles * NSTEP;  // linear (channel tile, image) counter
     // every workgroup walks the channel tiles cyclically from its own first tile (conv1x1_areg.hip: in lockstep all CUs would pull
@@ -169,13 +169,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) conv_hl_areg_kernel(
     auto dma_image = [&]() {
         const int nt = nt_of(ld_w);
         const unsigned img = lds0 + ld_slot;
-        const unsigned soh = (unsigned)(nt * AH_BN) * (unsigned)(K * 2) + (unsigned)(ld_st * 128);
-        const unsigned sol = (unsigned)(nt * AH_BN) * (unsigned)K + (unsigned)(ld_st * 64);
+        const unsigned soh = (unsigned)(2 * ld_st) * (unsigned)(a.Cout * 64) + (unsigned)(nt * AH_BN * 64);  // K step 2 ld_st, rows of tile nt
+        const unsigned sol = (unsigned)(2 * ld_st) * (unsigned)(a.Cout * 32) + (unsigned)(nt * AH_BN * 32);
 #pragma unroll
         for (int i = 0; i < PPI; i++) {
             const unsigned dst = (unsigned)((wave * PPI + i) * 1024);
             hl_dma16(bh_v, __builtin_amdgcn_readfirstlane(img + dst), bh_voff[i], __builtin_amdgcn_readfirstlane(soh));
-            hl_dma16(bh_v, __builtin_amdgcn_readfirstlane(img + AH_SUB + dst), bh_voff[i], __builtin_amdgcn_readfirstlane(soh + 64u));
+            hl_dma16(bh_v, __builtin_amdgcn_readfirstlane(img + AH_SUB + dst), bh_voff[i], __builtin_amdgcn_readfirstlane(soh + (unsigned)(a.Cout * 64)));
             hl_dma16(bl_v, __builtin_amdgcn_readfirstlane(img + bl_dst[i]), bl_voff[i], __builtin_amdgcn_readfirstlane(sol + bl_soff[i]));
         }
         ld_q++;

@@ -362,13 +362,14 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
             if (g[i].d_wcat) most = std::max(most, (size_t)g[i].cout * (g[i].cin + g[i + 1].cin));
         HIPCHK(c, hipMalloc(&scratch.p, hl_tensor_bytes(most)));
     }
-    // f32 [planes][per] at `w`, plane p scaled by sc[p] -> hi planes at w, lo planes at w + hl_lo_offset(planes * per); *lo_out = the lo base
-    auto hl_pack = [&](float* w, size_t planes, size_t per, const float* sc, void** lo_out) -> int32_t {
+    // f32 [planes][rows][per / rows] at `w`, plane p scaled by sc[p] -> hi planes at w, lo planes at w + hl_lo_offset(planes * per), each plane
+    // K-block-major (conv_hl.hip: hl_pack_weights_kernel); *lo_out = the lo base
+    auto hl_pack = [&](float* w, size_t planes, size_t rows, size_t per, const float* sc, void** lo_out) -> int32_t {
         const size_t tot = planes * per;
         uint8_t* t_hi = (uint8_t*)scratch.p;
         uint8_t* t_lo = t_hi + hl_lo_offset(tot);
         for (size_t pl = 0; pl < planes; pl++)
-            HIPCHK(c, launch_hl_pack_weights(w + pl * per, per, sc[pl], t_hi + pl * per * 2, t_lo + pl * per, c->stream));
+            HIPCHK(c, launch_hl_pack_weights(w + pl * per, rows, per / rows, sc[pl], t_hi + pl * per * 2, t_lo + pl * per, c->stream));
         HIPCHK(c, hipMemcpyAsync(w, t_hi, hl_tensor_bytes(tot), hipMemcpyDeviceToDevice, c->stream));
         *lo_out = (uint8_t*)w + hl_lo_offset(tot);
         return INFUR_OK;
@@ -402,7 +403,7 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         L.w_scale = pow2_for(mx[per * i]);
         if (L.role == 's') continue;
         if (hl)
-            RETIF(hl_pack((float*)L.d_w, 1, (size_t)L.cout * L.cin * L.k * L.k, &L.w_scale, &L.d_wl));
+            RETIF(hl_pack((float*)L.d_w, 1, L.cout, (size_t)L.cout * L.cin * L.k * L.k, &L.w_scale, &L.d_wl));
         else
             HIPCHK(c, launch_split_weights((float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, L.w_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         if (L.d_u) {
@@ -422,7 +423,7 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
                 if (pl == 0 || sc < smin) smin = sc;
                 if (!hl) HIPCHK(c, launch_split_weights(L.d_u + pl * (size_t)L.cout * L.cin, (size_t)L.cout * L.cin, sc, ctx_fp8x(c) ? 1 : 0, c->stream));
             }
-            if (hl) RETIF(hl_pack(L.d_u, P, (size_t)L.cout * L.cin, scs.data(), &L.d_ul));
+            if (hl) RETIF(hl_pack(L.d_u, P, L.cout, (size_t)L.cout * L.cin, scs.data(), &L.d_ul));
             L.u_scale = smin;
             HIPCHK(c, hipMemcpyAsync(L.d_uacc, acc.data(), P * sizeof(float), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));  // (acc goes out of scope)
@@ -430,7 +431,7 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         if (L.d_wcat) {
             L.wcat_scale = pow2_for(mx[per * i + 1]);
             if (hl)
-                RETIF(hl_pack((float*)L.d_wcat, 1, (size_t)L.cout * (L.cin + g[i + 1].cin), &L.wcat_scale, &L.d_wcatl));
+                RETIF(hl_pack((float*)L.d_wcat, 1, L.cout, (size_t)L.cout * (L.cin + g[i + 1].cin), &L.wcat_scale, &L.d_wcatl));
             else
                 HIPCHK(c, launch_split_weights((float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), L.wcat_scale, ctx_fp8x(c) ? 1 : 0, c->stream));
         }

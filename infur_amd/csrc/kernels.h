@@ -88,7 +88,7 @@ hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s
 bool conv_hl_areg_valid(const ConvArgs& a, int out_f32);
 hipError_t launch_conv_hl_areg(const ConvArgs& a, hipStream_t s);
 // weights of mode 5, one-off at load: f32 [n] (kernel K order) * scale -> f16 hi [n], e5m2 lo [n] (n % 4 == 0)
-hipError_t launch_hl_pack_weights(const float* w, size_t n, float scale, void* hi, void* lo, hipStream_t s);
+hipError_t launch_hl_pack_weights(const float* w, size_t rows, size_t cols, float scale, void* hi, void* lo, hipStream_t s);  // K-block-major planes
 
 // 1x1 convolution with Cin in {64, 128, 256}, f16 operands (mode 1), f16 output: the activation tile stays in registers
 // while the workgroup walks all N tiles (conv1x1_areg.hip).  Reached through launch_conv_igemm as one more configuration.
