@@ -18,7 +18,8 @@ from infur_amd import weights as W
 RUNS = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 JOBS = [("f16", 101, 3840, 2160), ("f16", 50, 1920, 1080), ("f16", 50, 961, 541), ("f32s", 50, 1920, 1080), ("f32x", 50, 1920, 1080), ("f32", 50, 1920, 1080),
         # round 5: conv_hl.hip -- a ring of three (two) LDS images filled by DMA under a counted vmcnt, residual loads kept in flight
-        # across the last K steps; INFUR_CONV_CFG = 11 / 0 / 6 / 5 / 12 / 13 / 14 forces each form onto every layer
+        # across the last K steps; INFUR_CONV_CFG = 11 / 0 / 6 / 5 / 12 / 13 / 14 forces each form onto every layer, 15 conv_hl_areg.hip (per-wave DMA bookkeeping,
+        # residual slot reused in place) onto every expansion
         ("f16hl", 50, 1920, 1080), ("f16hl", 50, 961, 541), ("f16hl", 101, 3840, 2160),
         # the quantised model: i8 `dma` / `dmai` tiles and conv1x1_q8 (hand-counted vmcnt over DMA pieces, residual loads and stores);
         # 2160p so that the tuner also takes conv1x1_q8 for the expansions, 1080p for the database's choices
