@@ -1,7 +1,7 @@
 // ingest_rate.hip -- how many bytes per clock a CU takes in through each path (L2-resident source, 256 workgroups of 8 waves,
 // one per CU):   0  buffer_load_dwordx4 ... lds   (LDS-DMA: the path conv_hl / the dmai forms / conv3x3_halo stage operands through)
 //                1  global_load_dwordx4 -> VGPR    (consumed by an xor chain)
-//                2  global_load_dwordx4 -> VGPR -> ds_write_b128
+//                2  global_load_dwordx4 -> VGPR -> ds_write_b128   (not run: hipcc hoists the loop-invariant store; the K-step kernels below cover it)
 //                3  buffer_load_dword ... lds      (4-byte DMA, for the per-instruction cost)
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/ingest_rate.hip -o gpurun_out/ingest_rate && gpurun_out/ingest_rate
 #include <hip/hip_runtime.h>
@@ -377,8 +377,6 @@ int main() {
         run<3, 12>("LDS-DMA b32", src, window, sink, cyc, 256);
         run<1, 6>("global_load b128 -> VGPR", src, window, sink, cyc, 256);
         run<1, 12>("global_load b128 -> VGPR", src, window, sink, cyc, 256);
-        run<2, 6>("global_load b128 -> VGPR -> ds_write_b128", src, window, sink, cyc, 256);
-        run<2, 12>("global_load b128 -> VGPR -> ds_write_b128", src, window, sink, cyc, 256);
     }
     // fewer CUs active: is the limit per CU or chip-wide?
     run<0, 6>("LDS-DMA b128, 64 workgroups", src, 1u << 20, sink, cyc, 64);
