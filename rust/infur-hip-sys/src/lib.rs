@@ -46,6 +46,17 @@ pub struct infur_model_info {
     pub resize_u8_heads: u32,
 }
 
+/// one profiled kernel launch of the last advance (`infur_profile_get`)
+#[repr(C)]
+pub struct infur_kernel_record {
+    pub name: [c_char; 48],
+    pub kernel: [c_char; 32],
+    pub ms: f32,
+    pub flops: f64,
+    pub bytes: f64,
+    pub algo_flops: f64,
+}
+
 pub const INFUR_OK: i32 = 0;
 pub const INFUR_E_INVALID_SCALE: i32 = 1;
 pub const INFUR_E_ZERO_SIZE_IN: i32 = 2;
@@ -146,4 +157,36 @@ extern "C" {
     /// INFUR_DTYPE_F32_SPLIT: largest |activation| fed to a GEMM and largest |Winograd-domain input| of the last
     /// forward, and whether either left the exact range of the f16 pairs
     pub fn infur_split_range(c: *mut infur_ctx, act_amax: *mut f32, wino_amax: *mut f32, saturated: *mut u32) -> i32;
+    // ---- the rest of the header (round 5): device-resident entry points, stage kernels on device buffers, the ONNX converter,
+    //      tuning database, per-kernel profile, device memory helpers -- for hosts that keep frames in HBM (a decoder writing into
+    //      device memory, a display reading from it) or want the library's measurements; none is needed by `impl Processor` ----
+    pub fn infur_ctx_stream(c: *mut infur_ctx) -> *mut c_void;
+    pub fn infur_scale_dev(c: *mut infur_ctx, d_bgr: *const c_void, w: u32, h: u32, factor: f32, mode: u32, d_out: *mut c_void,
+                           out_capacity: usize, ow: *mut u32, oh: *mut u32) -> i32;
+    pub fn infur_onnx_to_blob(onnx: *const c_void, len: usize, blob: *mut *mut c_void, blob_len: *mut usize, err: *mut c_char,
+                              errcap: usize) -> i32;
+    pub fn infur_buffer_free(p: *mut c_void);
+    pub fn infur_model_load_blob_dev(c: *mut infur_ctx, d_blob: *const c_void, len: usize) -> i32;
+    pub fn infur_model_advance_dev(c: *mut infur_ctx, d_bgr: *const c_void, w: u32, h: u32, d_out: *mut c_void, d_aux: *mut c_void,
+                                   n_outputs: *mut u32) -> i32;
+    pub fn infur_model_lowres_dims(h: u32, w: u32, lh: *mut u32, lw: *mut u32) -> i32;
+    pub fn infur_model_read_lowres(c: *mut infur_ctx, out_low: *mut f32, aux_low: *mut f32, lh: *mut u32, lw: *mut u32) -> i32;
+    pub fn infur_debug_read_activation(c: *mut infur_ctx, index: u32, host_chw: *mut f32, cap_floats: usize, ch: *mut u32,
+                                       h: *mut u32, w: *mut u32) -> i32;
+    pub fn infur_pack_normalize(c: *mut infur_ctx, bgr: *const u8, w: u32, h: u32, chw: *mut f32) -> i32;
+    pub fn infur_pack_normalize_dev(c: *mut infur_ctx, d_bgr: *const c_void, w: u32, h: u32, d_chw: *mut c_void) -> i32;
+    pub fn infur_colorcode_dev(c: *mut infur_ctx, d_khw: *const c_void, k: u32, h: u32, w: u32, d_rgba: *mut c_void) -> i32;
+    pub fn infur_bgr_to_rgba_dev(c: *mut infur_ctx, d_bgr: *const c_void, w: u32, h: u32, d_rgba: *mut c_void) -> i32;
+    pub fn infur_frame_advance_dev(c: *mut infur_ctx, d_bgr: *const c_void, w: u32, h: u32, factor: f32, scale_mode: u32,
+                                   d_rgba: *mut c_void, rgba_capacity: usize, d_scaled_bgr: *mut c_void, ow: *mut u32,
+                                   oh: *mut u32) -> i32;
+    pub fn infur_tune_export(c: *mut infur_ctx, buf: *mut c_char, cap: usize, len: *mut usize) -> i32;
+    pub fn infur_tune_import(c: *mut infur_ctx, text: *const c_char, len: usize) -> i32;
+    pub fn infur_profile_enable(c: *mut infur_ctx, on: u32) -> i32;
+    pub fn infur_profile_count(c: *mut infur_ctx, n: *mut u32) -> i32;
+    pub fn infur_profile_get(c: *mut infur_ctx, i: u32, rec: *mut infur_kernel_record) -> i32;
+    pub fn infur_dev_alloc(c: *mut infur_ctx, bytes: usize, d_ptr: *mut *mut c_void) -> i32;
+    pub fn infur_dev_free(c: *mut infur_ctx, d_ptr: *mut c_void) -> i32;
+    pub fn infur_memcpy_h2d(c: *mut infur_ctx, d_dst: *mut c_void, src: *const c_void, bytes: usize) -> i32;
+    pub fn infur_memcpy_d2h(c: *mut infur_ctx, dst: *mut c_void, d_src: *const c_void, bytes: usize) -> i32;
 }

@@ -61,12 +61,44 @@ impl Ctx {
         let msg = unsafe { CStr::from_ptr(sys::infur_last_error(self.0)) }.to_string_lossy().into_owned();
         HipError { code: rc, msg }
     }
-    /// the context's own message for `rc` (infur_last_error), falling back to the status string
-    fn from_ctx(ctx: &Ctx, rc: i32) -> Self {
-        let p = unsafe { sys::infur_last_error(ctx.0) };
-        if p.is_null() { return Self::status(rc); }
-        let msg = unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned();
-        if msg.is_empty() { Self::status(rc) } else { HipError { code: rc, msg } }
+    /// the decisions of the tile-configuration tuner so far, as text (`infur_tune_export`): feed it to `tuning_import` of a later
+    /// process and its first frame finds every conv shape's configuration already measured
+    pub fn tuning_text(&self) -> Result<String, HipError> {
+        let mut len = 0usize;
+        let rc = unsafe { sys::infur_tune_export(self.0, std::ptr::null_mut(), 0, &mut len) };
+        if rc != sys::INFUR_OK { return Err(self.err(rc)); }
+        let mut buf = vec![0u8; len + 1];
+        let rc = unsafe { sys::infur_tune_export(self.0, buf.as_mut_ptr() as *mut std::os::raw::c_char, buf.len(), &mut len) };
+        if rc != sys::INFUR_OK { return Err(self.err(rc)); }
+        buf.truncate(len);
+        Ok(String::from_utf8_lossy(&buf).into_owned())
+    }
+    pub fn tuning_import(&self, text: &str) -> Result<(), HipError> {
+        let rc = unsafe { sys::infur_tune_import(self.0, text.as_ptr() as *const std::os::raw::c_char, text.len()) };
+        if rc != sys::INFUR_OK { return Err(self.err(rc)); }
+        Ok(())
+    }
+    /// per-kernel HIP-event records of the last advance (after `set_profile(true)`): (layer, kernel family, milliseconds, FLOPs, bytes)
+    pub fn set_profile(&self, on: bool) -> Result<(), HipError> {
+        let rc = unsafe { sys::infur_profile_enable(self.0, on as u32) };
+        if rc != sys::INFUR_OK { return Err(self.err(rc)); }
+        Ok(())
+    }
+    pub fn profile(&self) -> Result<Vec<(String, String, f32, f64, f64)>, HipError> {
+        let mut n = 0u32;
+        let rc = unsafe { sys::infur_profile_count(self.0, &mut n) };
+        if rc != sys::INFUR_OK { return Err(self.err(rc)); }
+        let mut out = Vec::with_capacity(n as usize);
+        for i in 0..n {
+            let mut rec = std::mem::MaybeUninit::<sys::infur_kernel_record>::zeroed();
+            let rc = unsafe { sys::infur_profile_get(self.0, i, rec.as_mut_ptr()) };
+            if rc != sys::INFUR_OK { return Err(self.err(rc)); }
+            let rec = unsafe { rec.assume_init() };
+            let name = unsafe { CStr::from_ptr(rec.name.as_ptr()) }.to_string_lossy().into_owned();
+            let kernel = unsafe { CStr::from_ptr(rec.kernel.as_ptr()) }.to_string_lossy().into_owned();
+            out.push((name, kernel, rec.ms, rec.flops, rec.bytes));
+        }
+        Ok(out)
     }
 }
 impl Drop for Ctx {
@@ -80,6 +112,13 @@ impl HipError {
     fn status(rc: i32) -> Self {
         let msg = unsafe { CStr::from_ptr(sys::infur_status_string(rc)) }.to_string_lossy().into_owned();
         HipError { code: rc, msg }
+    }
+    /// the context's own message for `rc` (infur_last_error), falling back to the status string
+    fn from_ctx(ctx: &Ctx, rc: i32) -> Self {
+        let p = unsafe { sys::infur_last_error(ctx.0) };
+        if p.is_null() { return Self::status(rc); }
+        let msg = unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned();
+        if msg.is_empty() { Self::status(rc) } else { HipError { code: rc, msg } }
     }
 }
 

@@ -77,6 +77,7 @@ def rust_functions():
 def test_every_rust_extern_matches_the_header():
     hf, rf = header_functions(), rust_functions()
     assert len(rf) >= 38 and len(hf) >= len(rf)
+    assert set(hf) == set(rf), f"exports of the header the -sys crate does not bind: {sorted(set(hf) - set(rf))}"
     for name, (rret, rparams) in rf.items():
         assert name in hf, f"{name} is declared in the Rust crate but not in include/infur_hip.h"
         cret, cparams = hf[name]
@@ -105,7 +106,7 @@ def rust_struct_fields(name):
     return [(f.group(1), re.sub(r"\s+", " ", f.group(2).strip())) for f in re.finditer(r"pub (\w+)\s*:\s*([^,\n]+),", m.group(1))]
 
 
-@pytest.mark.parametrize("name", ["infur_options", "infur_model_info"])
+@pytest.mark.parametrize("name", ["infur_options", "infur_model_info", "infur_kernel_record"])
 def test_repr_c_structs_match_the_header(name):
     assert rust_struct_fields(name) == c_struct_fields(name)
 
