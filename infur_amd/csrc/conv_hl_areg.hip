@@ -402,15 +402,6 @@ bool conv_hl_areg_valid(const ConvArgs& a, int out_f32) {
 
 hipError_t launch_conv_hl_areg(const ConvArgs& a, hipStream_t s) {
     if (!conv_hl_areg_valid(a, 0)) return hipErrorInvalidValue;
-    static const bool w4 = getenv("INFUR_AH_W4") != nullptr;  // measurement hook: the one-wave-per-SIMD form for every Cin
-    if (w4) {
-        switch (a.Cin) {
-            case 64: return launch_ah<2, 4, 4>(a, s);
-            case 128: return launch_ah<4, 4, 4>(a, s);
-            case 256: return launch_ah<8, 4, 4>(a, s);
-            default: break;
-        }
-    }
     switch (a.Cin) {
         case 64: return launch_ah<2, 4, 8>(a, s);
         case 128: return launch_ah<4, 4, 8>(a, s);
