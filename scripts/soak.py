@@ -7,7 +7,8 @@ from infur_amd import weights as W
 from infur_amd.app import StreamPath
 from infur_amd.processors import Context, FramePath, Model, ModelCmd
 
-c = Context(device=0, profile=False)
+DT = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] not in ("i8",) else "f32"  # f32 | f32s | f32x | f16 | f16hl | i8
+c = Context(device=0, dtype=DT, profile=False)
 if len(sys.argv) > 1 and sys.argv[1] == "i8":  # the quantised model through the same soak
     from infur_amd import quantize
 
