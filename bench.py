@@ -263,6 +263,103 @@ def cpu_probe(spec):
     print(ts[-1], flush=True)
 
 
+LINE_LIMIT = 6000  # bytes: the driver recovers the JSON line from an 8 KB stdout tail (round 5's 20 KB line came back `parsed: null`)
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+SIDE_KEYS = ("f32_split_mode", "f32_split_fp8_mode", "f16hl_mode_1080p", "f16_mode_1080p", "int8_quantised_model", "configs2_stream_scale05",
+             "configs4_r101_f16_4k", "configs3_batch64_group", "configs3_batch64_group_f16hl")
+
+
+def _sig(x, digits=5):
+    """floats to `digits` significant figures, recursively (the line is a record, not a measurement instrument)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _clip(x, n=120):
+    """no string of the line longer than n characters (dict keys included: a kernel name as a key must not blow the budget)."""
+    if isinstance(x, str):
+        return x[:n]
+    if isinstance(x, dict):
+        return {str(k)[:n]: _clip(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clip(v, n) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out):
+    """The ONE stdout line: headline + `config` + `roofline` + `cpu_baseline` numbers only, <= LINE_LIMIT bytes.
+    Every note string, the per-kernel tables (`other_kernels`, `winograd`, `conv3x3`, tile-configuration times) and the side objects go to
+    bench_detail.json next to this file (and to stderr); `config.side_rates` keeps each side object's [frames/s, roofline fraction
+    (executed_frac where Winograd runs), PCIe-inclusive frames/s]."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data"))
+    cfg = out.get("config") or {}
+    c = _pick(cfg, ("workload", "frames_per_step_per_gpu", "contexts_per_gpu", "frames_per_s_one_context", "sharding", "backend", "weights_load_ms",
+                    "weights_bcast_ms", "ranks_agree_on_frame0_mask", "oversubscribed", "ms_per_frame_per_gpu", "conv_gflop_per_frame",
+                    "effective_conv_tflops", "pcie_inclusive_frames_per_s", "pcie_inclusive_zero_copy_frames_per_s"))
+    side = {}
+    for key in SIDE_KEYS:
+        o = out.get(key)
+        if isinstance(o, dict) and "value" in o:
+            r = o.get("roofline") or {}
+            frac = r.get("executed_frac", r.get("frac"))
+            side[key] = [round(o["value"], 1), None if frac is None else round(frac, 3), o.get("pcie_inclusive_frames_per_s")]
+        elif isinstance(o, dict) and "error" in o:
+            side[key] = str(o["error"])[:60]
+    if side:
+        c["side_rates"] = side
+    c["detail"] = "bench_detail.json (next to bench.py; also on stderr): notes, per-kernel tables, side objects"
+    line["config"] = c
+    r = out.get("roofline")
+    if isinstance(r, dict):
+        rr = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "flops_per_launch",
+                       "algorithmic_bytes_per_launch", "frame_kernel_ms"))
+        rr["kernel"] = str(r.get("kernel", "")).split(" (")[0][:80]
+        if isinstance(r.get("all_convs"), dict):
+            rr["all_convs"] = _pick(r["all_convs"], ("achieved", "frac", "ms"))
+        w = r.get("winograd")
+        if isinstance(w, dict):
+            rr["winograd"] = _pick(w, ("launches", "gemm_ms", "transform_ms", "executed_frac"))
+        if "executed_frac" in r:
+            rr["executed_frac"] = r["executed_frac"]
+        line["roofline"] = rr
+    b = out.get("cpu_baseline")
+    if isinstance(b, dict):
+        bb = _pick(b, ("value", "unit", "cores", "kind", "host_cpu", "host_logical_cores", "frames_per_s_by_threads"))
+        bb["sample"] = str(b.get("sample", ""))[:160]
+        c3 = b.get("c_oracle_3_threads")
+        if isinstance(c3, dict):
+            bb["c_oracle_3_threads"] = _pick(c3, ("frames_per_s", "threads", "error"))
+        if isinstance(b.get("reference_runtime"), dict):
+            bb["reference_runtime"] = _pick(b["reference_runtime"], ("frames_per_s", "threads", "model", "onnxruntime", "skipped"))
+        line["cpu_baseline"] = bb
+    text = json.dumps(_clip(_sig(line)), separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, f"bench line is {len(text)} bytes (limit {LINE_LIMIT}): move fields to bench_detail.json"
+    return text
+
+
+def emit(out):
+    """bench_detail.json + stderr get the full record; stdout gets the one compact line, last."""
+    detail = json.dumps(out, indent=1, default=str)
+    try:
+        with open(DETAIL_FILE, "w") as f:
+            f.write(detail + "\n")
+    except OSError as e:
+        sys.stderr.write(f"bench.py: cannot write {DETAIL_FILE}: {e}\n")
+    sys.stderr.write(json.dumps(out, default=str) + "\n")
+    sys.stderr.flush()
+    print(compact_line(out), flush=True)
+
+
 def main():
     a = parse()
     if a.cpu_probe:
@@ -585,19 +682,7 @@ def main():
                 out["configs3_batch64_group_f16hl"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, frames_np[0], a.cpu_seconds)
-        # every side object's rate in ONE compact map inside `config` (the driver keeps `config` in its parsed record; the side objects
-        # themselves sit behind the 8 KB tail of stdout): {mode: [frames/s, roofline frac (executed_frac where Winograd runs), PCIe-inclusive frames/s]}
-        side = {}
-        for key in ("f32_split_mode", "f32_split_fp8_mode", "f16hl_mode_1080p", "f16_mode_1080p", "int8_quantised_model", "configs2_stream_scale05",
-                    "configs4_r101_f16_4k", "configs3_batch64_group", "configs3_batch64_group_f16hl"):
-            o = out.get(key)
-            if isinstance(o, dict) and "value" in o:
-                r = o.get("roofline") or {}
-                frac = r.get("executed_frac", r.get("frac"))
-                side[key] = [round(o["value"], 1), None if frac is None else round(frac, 3), o.get("pcie_inclusive_frames_per_s")]
-        if side:
-            out["config"]["side_rates"] = side
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     for c in ctxs:
         c.close()
