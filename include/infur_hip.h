@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define INFUR_ABI_VERSION 5
+#define INFUR_ABI_VERSION 6
 
 /* status codes */
 enum {
@@ -310,12 +310,16 @@ int32_t infur_stream_collect(infur_stream* st, uint8_t* rgba, size_t rgba_capaci
  *             one first).  Acquiring again before commit returns the same slot, re-sized.
  *   commit    enqueues H2D -> scale / model / decode -> D2H for the acquired slot, exactly what submit() enqueues after its copy;
  *             w, h, factor must be the acquired ones.  submit() while a slot is acquired is INFUR_E_INVALID_ARG.
+ *   abandon   (ABI 6) gives an acquired slot back UNCOMMITTED -- the producer hit end of input or a read error after acquiring
+ *             (every pump acquires first and only then learns there is no frame).  Idempotent.  A failed acquire leaves nothing
+ *             acquired, whatever was acquired before it.
  *   collect_view  waits for the oldest pending frame and returns pointers INTO its pinned output slot (mask ow*oh*4 bytes, scaled
  *             frame ow*oh*3 bytes); they stay valid -- and the slot stays out of circulation -- until
  *   release   (or a copying collect() of the same frame) gives the slot back.
  * Copying and zero-copy calls may be mixed frame by frame; results and their order are the same. */
 int32_t infur_stream_acquire(infur_stream* st, uint32_t w, uint32_t h, float factor, uint8_t** bgr_slot);
 int32_t infur_stream_commit(infur_stream* st, uint32_t w, uint32_t h, float factor, uint32_t scale_mode, uint64_t frame_id);
+int32_t infur_stream_abandon(infur_stream* st);
 int32_t infur_stream_collect_view(infur_stream* st, const uint8_t** rgba, const uint8_t** scaled_bgr, uint64_t* frame_id,
                                   uint32_t* ow, uint32_t* oh);
 int32_t infur_stream_release(infur_stream* st);

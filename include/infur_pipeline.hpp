@@ -293,6 +293,7 @@ public:
     };
     Status acquire(uint32_t w, uint32_t h, float factor, uint8_t*& slot) { return infur_stream_acquire(st_, w, h, factor, &slot); }
     Status commit(uint32_t w, uint32_t h, float factor, uint64_t frame_id) { return infur_stream_commit(st_, w, h, factor, mode_, frame_id); }
+    Status abandon() { return infur_stream_abandon(st_); }
     Status collect_view(View& v) { return infur_stream_collect_view(st_, &v.rgba, &v.scaled_bgr, &v.frame_id, &v.width, &v.height); }
     Status release() { return infur_stream_release(st_); }
     /// as run(), without the two pageable <-> pinned copies per frame: the source reads each frame straight into the next pinned slot
@@ -316,7 +317,8 @@ public:
             const VideoStatus v = src.read_into(slot, id);
             if (v != VideoStatus::Ok) {
                 if (v != VideoStatus::FinishedNormally) err = INFUR_E_IO;
-                break;  // (the acquired slot is simply never committed: the next acquire re-uses it)
+                (void)abandon();  // the acquired slot goes back uncommitted: copying submits work again on this stream
+                break;
             }
             if ((err = commit(src.width(), src.height(), factor, id)) != INFUR_OK) break;
         }

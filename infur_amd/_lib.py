@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # INFUR_LIB_PATH: an instrumentation build of the same ABI (scripts/ktrace.py: `make ktrace` -> libinfur_hip_ktrace.so)
 LIB_PATH = os.environ.get("INFUR_LIB_PATH") or os.path.join(_HERE, "libinfur_hip.so")
 
-ABI_VERSION = 5  # INFUR_ABI_VERSION of include/infur_hip.h
+ABI_VERSION = 6  # INFUR_ABI_VERSION of include/infur_hip.h
 
 # status codes (include/infur_hip.h)
 OK = 0
@@ -136,6 +136,7 @@ SIGNATURES = {
     "infur_stream_commit": (C.c_int32, [_vp, _u32, _u32, _f, _u32, C.c_uint64]),
     "infur_stream_collect_view": (C.c_int32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), _u32p, _u32p]),
     "infur_stream_release": (C.c_int32, [_vp]),
+    "infur_stream_abandon": (C.c_int32, [_vp]),
     "infur_host_alloc": (C.c_int32, [_sz, C.POINTER(_vp)]),
     "infur_host_free": (C.c_int32, [_vp]),
     "infur_host_is_pinned": (C.c_uint32, [_vp]),

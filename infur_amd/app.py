@@ -345,6 +345,10 @@ class StreamPath:
     def commit(self, w: int, h: int, factor: float, frame_id: int) -> None:
         self.ctx.check(self.ctx.L.infur_stream_commit(self.h, w, h, float(np.float32(factor)), self.scale_mode, frame_id))
 
+    def abandon(self) -> None:
+        """Give an acquired slot back uncommitted (end of input / read error after ``acquire``); idempotent."""
+        self.ctx.check(self.ctx.L.infur_stream_abandon(self.h))
+
     def collect_view(self, want_scaled: bool = False):
         """-> (frame_id, rgba view [oh,ow,4], scaled view or None): arrays over the pinned output slot, valid until ``release``."""
         L = self.ctx.L
@@ -372,7 +376,12 @@ class StreamPath:
                 self.release()
                 yield i, out
             h, w = img.shape[:2]
-            fill(self.acquire(w, h, factor), img)
+            slot = self.acquire(w, h, factor)
+            try:
+                fill(slot, img)
+            except BaseException:
+                self.abandon()  # a producer that fails after acquire must not leave the ring unusable for submit()
+                raise
             self.commit(w, h, factor, fid)
         while self.pending():
             i, rgba, _ = self.collect_view()

@@ -319,6 +319,9 @@ int32_t infur_stream_acquire(infur_stream* st, uint32_t w, uint32_t h, float fac
         if (!st || !st->ctx || !bgr_slot) return INFUR_E_INVALID_ARG;
         enter(st->ctx);
         *bgr_slot = nullptr;
+        // an earlier acquire is void from here on: if the re-size below fails (slot_reserve frees before it allocates) the slot has
+        // no buffers, and a commit against the old dimensions must not find `acquired` still set
+        st->acquired = false;
         infur_stream::Slot* sl = nullptr;
         uint32_t ow = 0, oh = 0;
         RETIF(stream_prepare(st, w, h, factor, &sl, &ow, &oh));  // (acquiring again re-sizes the same slot: nothing is in flight on it)
@@ -347,13 +350,25 @@ int32_t infur_stream_commit(infur_stream* st, uint32_t w, uint32_t h, float fact
             return fail(c, INFUR_E_INVALID_ARG, "commit of a %ux%u frame (factor %g) into a slot acquired for %ux%u", w, h, (double)factor, st->acq_w, st->acq_h);
         infur_ctx* lane = st->lanes[st->head % st->lanes.size()];
         if (!lane->loaded) return fail(c, INFUR_E_MODEL_NOT_LOADED, "no model loaded");  // (unloaded between acquire and commit)
+        // (... or another model loaded on one lane between acquire and commit: the same rule stream_prepare enforces)
+        if (lane->quant != st->lanes[0]->quant || lane->depth != st->lanes[0]->depth)
+            return fail(c, INFUR_E_INVALID_ARG, "the stream's lanes hold different models (quantised / float, or different depths): replicate one model to all of them");
         infur_stream::Slot& sl = st->slots[st->head % st->slots.size()];
+        if (!sl.h_in || !sl.d_in) return fail(c, INFUR_E_INVALID_ARG, "the acquired slot has no buffers");
         return stream_enqueue(st, sl, sl.h_in, w, h, factor, mode, frame_id, st->acq_ow, st->acq_oh, nullptr);
     } catch (const std::bad_alloc&) {
         return fail(st ? st->ctx : nullptr, INFUR_E_CAPACITY, "out of host memory");
     } catch (const std::exception& e) {
         return fail(st ? st->ctx : nullptr, INFUR_E_INVALID_ARG, "internal error: %s", e.what());
     }
+}
+
+// the producer found no frame to put into the slot it acquired (end of input, read error): give it back uncommitted
+int32_t infur_stream_abandon(infur_stream* st) {
+    if (!st || !st->ctx) return INFUR_E_INVALID_ARG;
+    enter(st->ctx);
+    st->acquired = false;  // (idempotent: abandoning with nothing acquired is not an error -- EOF paths call it unconditionally)
+    return INFUR_OK;
 }
 
 int32_t infur_stream_next_dims(const infur_stream* st, uint64_t* frame_id, uint32_t* ow, uint32_t* oh) {

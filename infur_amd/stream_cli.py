@@ -87,6 +87,7 @@ def main(argv=None) -> int:
             try:
                 fid = src.read_frame(slot)
             except VideoProcError as e:
+                sp.abandon()  # the acquired slot goes back uncommitted
                 if e.kind == "FinishedNormally":
                     break
                 raise

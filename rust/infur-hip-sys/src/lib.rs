@@ -69,7 +69,7 @@ pub const INFUR_E_RCCL: i32 = 8;
 pub const INFUR_E_INVALID_ARG: i32 = 9;
 pub const INFUR_E_IO: i32 = 10;
 pub const INFUR_E_CAPACITY: i32 = 11;
-pub const INFUR_ABI_VERSION: u32 = 5;
+pub const INFUR_ABI_VERSION: u32 = 6;
 pub const INFUR_SCALE_NEAREST: u32 = 0;
 pub const INFUR_SCALE_BILINEAR: u32 = 1;
 pub const INFUR_DTYPE_F32: u32 = 0;
@@ -126,6 +126,7 @@ extern "C" {
     pub fn infur_stream_collect_view(s: *mut infur_stream, rgba: *mut *const u8, scaled_bgr: *mut *const u8,
                                      frame_id: *mut u64, ow: *mut u32, oh: *mut u32) -> i32;
     pub fn infur_stream_release(s: *mut infur_stream) -> i32;
+    pub fn infur_stream_abandon(s: *mut infur_stream) -> i32;
     // pinned host memory for caller-owned frame / mask buffers (moved by DMA by the batch calls)
     pub fn infur_host_alloc(bytes: usize, p: *mut *mut c_void) -> i32;
     pub fn infur_host_free(p: *mut c_void) -> i32;

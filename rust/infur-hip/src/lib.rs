@@ -357,7 +357,7 @@ impl Processor for HipColorCode {
 /// UNTESTED like the rest of the crate (no Rust toolchain in the build image).
 pub struct HipStream { raw: *mut sys::infur_stream, ctx: Rc<Ctx>, depth: u32, mode: u32 }
 /// A finished frame in place in the ring's pinned output slot; the slot returns to the ring when the view is dropped.
-pub struct MaskView<'a> { stream: &'a mut HipStream, pub frame_id: u64, pub size: [usize; 2], pub rgba: &'a [u8], pub scaled_bgr: &'a [u8] }
+pub struct MaskView<'a> { stream: &'a mut HipStream, pub frame_id: u64, pub size: [usize; 2], pub rgba: &'a [u8], pub scaled_bgr: Option<&'a [u8]> }
 impl<'a> Drop for MaskView<'a> {
     fn drop(&mut self) { unsafe { sys::infur_stream_release(self.stream.raw); } }
 }
@@ -382,6 +382,9 @@ impl HipStream {
         if rc != sys::INFUR_OK { return Err(HipError::from_ctx(&self.ctx, rc)); }
         Ok(())
     }
+    /// the decoder found no frame for the slot `next_slot` lent out (end of input, read error): give it back uncommitted, so that
+    /// copying `submit`s work again on this stream
+    pub fn abandon(&mut self) { unsafe { sys::infur_stream_abandon(self.raw); } }
     /// waits for the oldest pending frame
     pub fn view(&mut self) -> Result<MaskView<'_>, HipError> {
         let (mut rgba, mut sc): (*const u8, *const u8) = (std::ptr::null(), std::ptr::null());
@@ -389,7 +392,9 @@ impl HipStream {
         let rc = unsafe { sys::infur_stream_collect_view(self.raw, &mut rgba, &mut sc, &mut id, &mut ow, &mut oh) };
         if rc != sys::INFUR_OK { return Err(HipError::from_ctx(&self.ctx, rc)); }
         let n = (ow as usize) * (oh as usize);
-        let (r, s) = unsafe { (std::slice::from_raw_parts(rgba, n * 4), std::slice::from_raw_parts(sc, n * 3)) };
+        // (a frame whose mask went straight to a caller-owned pinned buffer keeps no scaled copy: collect_view hands back NULL for it)
+        let r = unsafe { std::slice::from_raw_parts(rgba, n * 4) };
+        let s = if sc.is_null() { None } else { Some(unsafe { std::slice::from_raw_parts(sc, n * 3) }) };
         Ok(MaskView { stream: self, frame_id: id, size: [ow as usize, oh as usize], rgba: r, scaled_bgr: s })
     }
 }

@@ -226,6 +226,33 @@ def test_zero_copy_streaming_equals_copying(ctx, model):
     with pytest.raises(InfurError) as e:
         sp.acquire(240, 135, -1.0)
     assert e.value.code == _lib.E_INVALID_SCALE
+    # ABI 6: a producer that acquires and then finds no frame (EOF, read error) abandons the slot -- copying submits work
+    # again; a FAILED acquire voids an earlier successful one (its commit must not pass against a slot that may have lost its buffers)
+    sp.acquire(240, 135, 0.5)
+    sp.abandon()
+    sp.abandon()  # idempotent
+    with pytest.raises(InfurError) as e:
+        sp.commit(240, 135, 0.5, 3)  # nothing acquired any more
+    assert e.value.code == _lib.E_INVALID_ARG
+    sp.submit(frames[0][1], 0.5, 90)  # the ring is usable for copying submits again
+    fid, rgba, _s = sp.collect()
+    assert fid == 90 and (rgba == ref[0][1]).all()
+    sp.acquire(240, 135, 0.5)
+    with pytest.raises(InfurError):
+        sp.acquire(240, 135, -1.0)  # fails ...
+    with pytest.raises(InfurError) as e:
+        sp.commit(240, 135, 0.5, 4)  # ... and leaves nothing acquired
+    assert e.value.code == _lib.E_INVALID_ARG
+    sp.submit(frames[1][1], 0.5, 91)
+    assert sp.collect()[0] == 91
+
+    def failing_fill(slot, img):
+        raise OSError("decoder died")
+
+    with pytest.raises(OSError):
+        list(sp.run_zero_copy(frames[:1], 0.5, fill=failing_fill))
+    sp.submit(frames[2][1], 0.5, 92)  # run_zero_copy abandoned the slot on its way out
+    assert sp.collect()[0] == 92
     sp.close()
 
 
