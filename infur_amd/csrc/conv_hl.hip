@@ -40,6 +40,19 @@
 
 namespace infur {
 
+// Instrumentation build (make EXTRA="-DHL_TRACE -DHLT_CIN=2048 -DHLT_COUT=512", scripts/hl_trace.py): workgroup HLT_WG of the launches with
+// that shape accumulates, per wave, the shader cycles (s_memtime) of each phase of the pipelined K loop.  Timestamps sit where no LDS
+// read is outstanding (s_memtime shares lgkmcnt with them).  Not compiled into the product library.
+#ifdef HL_TRACE
+#ifndef HLT_WG
+#define HLT_WG 100
+#endif
+__device__ unsigned long long g_hl_trace[8 * 8];
+#define HLT_T(k) do { if (tr_on) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); tr[k] += now__ - tlast; tlast = now__; } } while (0)
+#else
+#define HLT_T(k) do { } while (0)
+#endif
+
 constexpr int hl_image_bytes(int bm, int bn) { return (bm + bn) * 96; }
 constexpr int hl_lds_bytes(int bm, int bn, int wm, int wn, int nimg) {
     const int operands = nimg * hl_image_bytes(bm, bn);
@@ -55,7 +68,17 @@ constexpr int hl_ceil_div(int a, int b) { return (a + b - 1) / b; }
 // CU).  2 = one step ahead: half-size tiles of FOUR waves with 128 x 64 wave tiles fit TWO independent workgroups per CU (72 KB
 // each, one wave per SIMD each) -- the epilogue of one overlaps the K loop of the other, which is what the output-bound 1x1
 // expansions (conv3: K = 256 / 512, a tile's epilogue moves as many bytes as its K loop ingests) are short of.
-template <int BM, int BN, int WM, int WN, bool G1, bool OUTF32, bool DUAL = false, int NIMG = 3>
+// PIPE (round 6): the K loop software-pipelined ACROSS the barrier.  The plain loop (PIPE = false) opens every step with its 12
+// fragment reads and `s_waitcnt lgkmcnt(0)` -- all eight waves at once, right behind the barrier: ~96 KB through the LDS (~600 cycles)
+// during which no SIMD has an MFMA to issue, then 2 x 1024 cycles of MFMAs: the 3.1 k cycles per 2 k of scripts/micro/ingest_rate.hip.
+// The pipelined loop puts the step's one barrier in its MIDDLE, between the f16 MFMAs (hi x hi, two slices) and the bf8 MFMAs (cross
+// terms), and the first thing after it is the read of the NEXT step's slice-0 fragments: they land under the 512 cycles of bf8 MFMAs
+// the wave (and its SIMD partner) still has to issue; slice 1 and the lo planes are read under the slice-0 MFMAs.  After the barrier of
+// step k every wave has finished ALL reads of image k (slice 0 before, slice 1 + lo during the first half of the step, drained by the
+// lgkmcnt(0) in front of the barrier), so the DMA of step k + NIMG goes out there, into the image just freed -- the same two steps of
+// cover as before (ring of three), one image less idle.  Same MFMAs on the same operands in the same order per accumulator:
+// bit-identical to PIPE = false (tests/test_gpu_hl.py).
+template <int BM, int BN, int WM, int WN, bool G1, bool OUTF32, bool DUAL = false, int NIMG = 3, bool PIPE = false>
 __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs a, const int mtiles, const int ntiles) {
     static_assert(!DUAL || (G1 && !OUTF32), "DUAL is a form of the 1x1 GEMM addressing");
     constexpr int NW = WM * WN;
@@ -65,7 +88,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     // DMA pieces (1 KB each) per plane and per wave; a plane whose pieces do not divide among the waves lets the surplus waves
     // repeat a piece (same bytes to the same place: harmless) so that every wave issues the same number -- the counted vmcnt
     constexpr int P_AH = BM / 16, P_AL = BM / 32, P_BH = BN / 16, P_BL = BN / 32;
-    constexpr int I_AH = hl_ceil_div(P_AH, NW), I_AL = hl_ceil_div(P_AL, NW), I_BH = hl_ceil_div(P_BH, NW), I_BL = hl_ceil_div(P_BL, NW);
+    // LW: the waves that issue the DMA.  Pipelined loop with two waves per SIMD (eight waves): only the FIRST half -- waves w and w + 4 share a
+    // SIMD, the older one wins the issue arbitration, finishes both halves of a step early and idles ~1.2 k cycles per step at the barrier
+    // while the younger one, held at its DMA issues beside the other's MFMAs, is the step's critical path (s_memtime trace, LAB_NOTES
+    // round 6): the pieces go where the slack is.
+    constexpr int LW = (PIPE && NW == 8) ? 4 : NW;
+    constexpr int I_AH = hl_ceil_div(P_AH, LW), I_AL = hl_ceil_div(P_AL, LW), I_BH = hl_ceil_div(P_BH, LW), I_BL = hl_ceil_div(P_BL, LW);
     constexpr int NPW = I_AH + I_AL + I_BH + I_BL;  // pieces per wave per K step
     static_assert(NPW <= 16, "vmcnt immediates below are written for <= 16 pieces per step");
 
@@ -88,8 +116,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     const int mt = tile / ntiles, nt = tile - mt * ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: per-wave offsets live in SGPRs)
+#ifdef HL_TRACE
+    const bool tr_on = PIPE && a.Cin == HLT_CIN && a.Cout == HLT_COUT && blockIdx.x == HLT_WG;
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     const int wm = wave / WN, wn = wave % WN;
+    const bool loader = LW == NW || wave < LW;  // (wave-uniform)
     const int M = a.OH * a.OW;
     const int Ktot = DUAL ? a.Cin + a.Cin2 : a.KH * a.KW * a.Cin;
     const int cchunks = a.Cin / HL_KC;
@@ -249,20 +282,6 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     const int b_hi1 = B_HI + (wn * TN * 32 + r) * 64 + (((2 * h + 1) ^ hl_swz64(r)) * 16);
     const int b_lo = B_LO + (wn * TN * 32 + r) * 32 + ((h ^ hl_swz32(r)) * 16);
 
-    // prologue: steps 0 and 1 into images 0 and 1 (ring of two: step 0)
-    load_a();
-    load_b();
-    load_next();
-    if (NIMG == 3 && ksteps > 1) {
-        load_a();
-        load_b();
-        load_next();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-
     // Residual prefetch (tiles with <= 64 accumulators per lane: room for the whole residual tile in registers): the loads go out at
     // the start of the first K step that issues no DMA any more (ks = ksteps - 2) -- every DMA piece still in flight is then OLDER
     // than they are, so the step-end wait becomes vmcnt(NRES) and the residual's HBM latency hides behind the last two steps
@@ -276,92 +295,299 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     u32x2 prl[CANPF ? TM : 1][CANPF ? E_NIT : 1];
     const int pf_step = ksteps >= 2 ? ksteps - 2 : 0;  // (ring of two: the residual loads are then OLDER than the last step's DMA)
 
-    unsigned cur = 0;  // byte offset of the image being multiplied
-    for (int ks = 0; ks < ksteps; ks++) {
-        if constexpr (CANPF) {
-            if (pf && ks == pf_step) {
-                const int e_row = lane / E_LPR, e_col = lane % E_LPR;
-                const int n = n0 + wn * TN * 32 + e_col * E_CPL;
+
+    if constexpr (PIPE) {
+        // ---- software-pipelined K loop (see the comment on PIPE above), rotated: one iteration = [barrier of step ks | next step's
+        // slice-0 reads, the DMA pieces of step ks + NIMG one between every two MFMAs, bf8 MFMAs of step ks | slice-1 + lo reads and
+        // the f16 MFMAs of step ks + 1].  The prefetched slice-0 set is defined and consumed inside one iteration; what crosses the
+        // back edge is the bf8 operand set (a8 / b8), written unconditionally. ----
+        int nload = 0;
 #pragma unroll
-                for (int i = 0; i < TM; i++)
-#pragma unroll
-                    for (int it = 0; it < E_NIT; it++) {
-                        const int m = m0 + wm * TM * 32 + i * 32 + it * E_RPI + e_row;
-                        const size_t e = (m < M && n < a.Cout) ? (size_t)m * a.Cout + n : 0;
-                        prh[i][it] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(a.res) + e);
-                        prl[i][it] = *reinterpret_cast<const u32x2*>(static_cast<const unsigned char*>(a.res_lo) + e);
-                    }
+        for (int p = 0; p < NIMG; p++)
+            if (p < ksteps) {
+                if (loader) {
+                    load_a();
+                    load_b();
+                }
+                load_next();
+                nload++;
             }
-        }
-        const char* I = smem + cur;
-        const bool more = kl < ksteps;  // step ks + 2 (ring of two: ks + 1) exists: its pieces go out between the slices
-        uint4 fa[TM], fb[TN], fal[TM], fbl[TN];
+        if (NIMG == 3 && nload == 3)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+        else if (nload == 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int pf_mid = ksteps >= 3 ? ksteps - 3 : 0;  // the residual loads go out behind the barrier of this step: no DMA is issued at or after it
         i32x8 a8[TM], b8[TN];
-        // slice 0
+        // one DMA piece of the step being loaded (p = 0 .. NPW - 1: A hi, A lo, B hi, B lo), for the interleave below
+        auto load_piece = [&](const int p) {
+            if (p < I_AH + I_AL) {
+                const bool hi = p < I_AH;
+                const int i = hi ? p : p - I_AH;
+                if constexpr (G1) {
+                    if (DUAL && kl >= cchunks) {
+                        const unsigned k2 = (unsigned)(kl - cchunks);
+                        if (hi) hl_dma16(a2h_v, sdst(ah_dst[i < I_AH ? i : 0]), (unsigned)ah_x[i < I_AH ? i : 0], k2 * 64u);
+                        else hl_dma16(a2l_v, sdst(al_dst[i < I_AL ? i : 0]), (unsigned)al_x[i < I_AL ? i : 0], k2 * 32u);
+                    } else {
+                        if (hi) hl_dma16(ah_v, sdst(ah_dst[i < I_AH ? i : 0]), (unsigned)ah_y[i < I_AH ? i : 0], (unsigned)kl * 64u);
+                        else hl_dma16(al_v, sdst(al_dst[i < I_AL ? i : 0]), (unsigned)al_y[i < I_AL ? i : 0], (unsigned)kl * 32u);
+                    }
+                } else {
+                    const int dy = ky * a.dil, dx = kx * a.dil;
+                    if (hi) {
+                        const int q = i < I_AH ? i : 0;
+                        const int iy = ah_y[q] + dy, ix = ah_x[q] + dx;
+                        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                        const unsigned off = (unsigned)(iy * a.W + ix) * (unsigned)(a.Cin * 2) + (unsigned)(cc * 64) + ah_c[q];
+                        hl_dma16(ah_v, sdst(ah_dst[q]), ok ? off : HL_OOB, 0u);
+                    } else {
+                        const int q = i < I_AL ? i : 0;
+                        const int iy = al_y[q] + dy, ix = al_x[q] + dx;
+                        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                        const unsigned off = (unsigned)(iy * a.W + ix) * (unsigned)a.Cin + (unsigned)(cc * 32) + al_c[q];
+                        hl_dma16(al_v, sdst(al_dst[q]), ok ? off : HL_OOB, 0u);
+                    }
+                }
+            } else {
+                const int pb = p - I_AH - I_AL;
+                if (pb < I_BH) hl_dma16(bh_v, sdst(bh_dst[pb < I_BH ? pb : 0]), bh_off[pb < I_BH ? pb : 0], (unsigned)kl * (unsigned)(a.Cout * 64));
+                else {
+                    const int q = pb - I_BH < I_BL ? pb - I_BH : 0;
+                    hl_dma16(bl_v, sdst(bl_dst[q]), bl_off[q], (unsigned)kl * (unsigned)(a.Cout * 32));
+                }
+            }
+        };
+        // first half of step `img`: slice 1 and the lo planes are read under the slice-0 MFMAs; leaves the step's bf8 operands in a8 / b8
+        auto first_half = [&](const char* I, const uint4* f0a, const uint4* f0b) {
+            uint4 f1a[TM], f1b[TN];
 #pragma unroll
-        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const uint4*>(I + a_hi0 + i * 32 * 64);
+            for (int i = 0; i < TM; i++) f1a[i] = *reinterpret_cast<const uint4*>(I + a_hi1 + i * 32 * 64);
 #pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const uint4*>(I + b_hi0 + j * 32 * 64);
+            for (int j = 0; j < TN; j++) f1b[j] = *reinterpret_cast<const uint4*>(I + b_hi1 + j * 32 * 64);
 #pragma unroll
-        for (int i = 0; i < TM; i++) fal[i] = *reinterpret_cast<const uint4*>(I + a_lo + i * 32 * 32);
+            for (int i = 0; i < TM; i++) {
+                const uint4 t = *reinterpret_cast<const uint4*>(I + a_lo + i * 32 * 32);
+                a8[i][4] = (int)t.x; a8[i][5] = (int)t.y; a8[i][6] = (int)t.z; a8[i][7] = (int)t.w;
+            }
 #pragma unroll
-        for (int j = 0; j < TN; j++) fbl[j] = *reinterpret_cast<const uint4*>(I + b_lo + j * 32 * 32);
-        if (more) load_a();
+            for (int j = 0; j < TN; j++) {
+                const uint4 t = *reinterpret_cast<const uint4*>(I + b_lo + j * 32 * 32);
+                b8[j][0] = (int)t.x; b8[j][1] = (int)t.y; b8[j][2] = (int)t.z; b8[j][3] = (int)t.w;
+            }
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-            a8[i][0] = hl_top4(fa[i].x, fa[i].y);
-            a8[i][1] = hl_top4(fa[i].z, fa[i].w);
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f0b[j]), __builtin_bit_cast(f16x8, f0a[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                a8[i][0] = hl_top4(f0a[i].x, f0a[i].y);
+                a8[i][1] = hl_top4(f0a[i].z, f0a[i].w);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                b8[j][4] = hl_top4(f0b[j].x, f0b[j].y);
+                b8[j][5] = hl_top4(f0b[j].z, f0b[j].w);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f1b[j]), __builtin_bit_cast(f16x8, f1a[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                a8[i][2] = hl_top4(f1a[i].x, f1a[i].y);
+                a8[i][3] = hl_top4(f1a[i].z, f1a[i].w);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                b8[j][6] = hl_top4(f1b[j].x, f1b[j].y);
+                b8[j][7] = hl_top4(f1b[j].z, f1b[j].w);
+            }
+        };
+        // the wait in front of the barrier of step ks: step ks + 1 has landed (this wave's pieces), every read of image ks is back in
+        // registers; in flight behind it: the pieces of step ks + 2 (ring of three), the residual
+        auto wait_mid = [&](const int ks) {
+            const bool res_out = CANPF && pf && ks > pf_mid;
+            if (NIMG == 3 && ks + 2 < ksteps)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
+            else if (res_out)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRES) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        };
+        {
+            uint4 f0a[TM], f0b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) f0a[i] = *reinterpret_cast<const uint4*>(smem + a_hi0 + i * 32 * 64);
+#pragma unroll
+            for (int j = 0; j < TN; j++) f0b[j] = *reinterpret_cast<const uint4*>(smem + b_hi0 + j * 32 * 64);
+            first_half(smem, f0a, f0b);
+            wait_mid(0);
         }
+        HLT_T(0);  // prologue + the first step's f16 half
+        unsigned cur = 0;
+        for (int ks = 0;; ks++) {
+            __builtin_amdgcn_s_barrier();
+            HLT_T(1);  // at the barrier
+            const unsigned nxt = cur + IMG == NIMG * IMG ? 0u : cur + IMG;
+            // next step's slice 0 (unconditional: behind the last step it reads an image nobody uses any more)
+            uint4 f0a[TM], f0b[TN];
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            b8[j][4] = hl_top4(fb[j].x, fb[j].y);
-            b8[j][5] = hl_top4(fb[j].z, fb[j].w);
+            for (int i = 0; i < TM; i++) f0a[i] = *reinterpret_cast<const uint4*>(smem + nxt + a_hi0 + i * 32 * 64);
+#pragma unroll
+            for (int j = 0; j < TN; j++) f0b[j] = *reinterpret_cast<const uint4*>(smem + nxt + b_hi0 + j * 32 * 64);
+            const bool more = kl < ksteps;  // step ks + NIMG exists: its pieces go out between the bf8 MFMAs, into the image of step ks
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 1, 1, 0, 127 - kHlLoShift, 0, 127);
+                    constexpr int NMF = TM * TN;
+                    const int m = i * TN + j;
+                    // pieces m * NPW / NMF .. (m + 1) * NPW / NMF - 1 behind MFMA m
+                    if (more && loader) {
+#pragma unroll
+                        for (int p = 0; p < NPW; p++)
+                            if (p * NMF / NPW == m) load_piece(p);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if (more) load_next();
+            if constexpr (CANPF) {
+                if (pf && ks == pf_mid) {
+                    const int e_row = lane / E_LPR, e_col = lane % E_LPR;
+                    const int n = n0 + wn * TN * 32 + e_col * E_CPL;
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int it = 0; it < E_NIT; it++) {
+                            const int m = m0 + wm * TM * 32 + i * 32 + it * E_RPI + e_row;
+                            const size_t e = (m < M && n < a.Cout) ? (size_t)m * a.Cout + n : 0;
+                            prh[i][it] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(a.res) + e);
+                            prl[i][it] = *reinterpret_cast<const u32x2*>(static_cast<const unsigned char*>(a.res_lo) + e);
+                        }
+                }
+            }
+            if (ks + 1 == ksteps) break;
+            HLT_T(2);  // slice-0 reads of the next step, DMA issue, bf8 MFMAs
+            first_half(smem + nxt, f0a, f0b);
+            HLT_T(3);  // slice-1 + lo reads, f16 MFMAs
+            wait_mid(ks + 1);
+            HLT_T(4);  // counted vmcnt + lgkmcnt(0)
+            cur = nxt;
         }
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
-        // slice 1
-#pragma unroll
-        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const uint4*>(I + a_hi1 + i * 32 * 64);
-#pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const uint4*>(I + b_hi1 + j * 32 * 64);
-        if (more) {
+        // (the last step's barrier stands between every wave's last LDS read and the epilogue's staging stores -- but the unconditional
+        //  slice-0 read behind it is still outstanding: drain it before the staging stores reuse the registers' LDS region)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HLT_T(5);  // the last step's second half
+    } else {
+        // prologue: steps 0 and 1 into images 0 and 1 (ring of two: step 0)
+        load_a();
+        load_b();
+        load_next();
+        if (NIMG == 3 && ksteps > 1) {
+            load_a();
             load_b();
             load_next();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            a8[i][2] = hl_top4(fa[i].x, fa[i].y);
-            a8[i][3] = hl_top4(fa[i].z, fa[i].w);
-            a8[i][4] = (int)fal[i].x; a8[i][5] = (int)fal[i].y; a8[i][6] = (int)fal[i].z; a8[i][7] = (int)fal[i].w;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            b8[j][6] = hl_top4(fb[j].x, fb[j].y);
-            b8[j][7] = hl_top4(fb[j].z, fb[j].w);
-            b8[j][0] = (int)fbl[j].x; b8[j][1] = (int)fbl[j].y; b8[j][2] = (int)fbl[j].z; b8[j][3] = (int)fbl[j].w;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
-        // cross terms: [t(a_hi) | a_lo8] . [w_lo8 | t(w_hi)], 64 deep, e5m2 x e5m2, block scale 2^-11
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 1, 1, 0, 127 - kHlLoShift, 0, 127);
-        if (NIMG == 3 && more)
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
-        else if (pf && !more)
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRES) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        cur = cur + IMG == NIMG * IMG ? 0u : cur + IMG;
+
+        unsigned cur = 0;  // byte offset of the image being multiplied
+        for (int ks = 0; ks < ksteps; ks++) {
+            if constexpr (CANPF) {
+                if (pf && ks == pf_step) {
+                    const int e_row = lane / E_LPR, e_col = lane % E_LPR;
+                    const int n = n0 + wn * TN * 32 + e_col * E_CPL;
+    #pragma unroll
+                    for (int i = 0; i < TM; i++)
+    #pragma unroll
+                        for (int it = 0; it < E_NIT; it++) {
+                            const int m = m0 + wm * TM * 32 + i * 32 + it * E_RPI + e_row;
+                            const size_t e = (m < M && n < a.Cout) ? (size_t)m * a.Cout + n : 0;
+                            prh[i][it] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(a.res) + e);
+                            prl[i][it] = *reinterpret_cast<const u32x2*>(static_cast<const unsigned char*>(a.res_lo) + e);
+                        }
+                }
+            }
+            const char* I = smem + cur;
+            const bool more = kl < ksteps;  // step ks + 2 (ring of two: ks + 1) exists: its pieces go out between the slices
+            uint4 fa[TM], fb[TN], fal[TM], fbl[TN];
+            i32x8 a8[TM], b8[TN];
+            // slice 0
+    #pragma unroll
+            for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const uint4*>(I + a_hi0 + i * 32 * 64);
+    #pragma unroll
+            for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const uint4*>(I + b_hi0 + j * 32 * 64);
+    #pragma unroll
+            for (int i = 0; i < TM; i++) fal[i] = *reinterpret_cast<const uint4*>(I + a_lo + i * 32 * 32);
+    #pragma unroll
+            for (int j = 0; j < TN; j++) fbl[j] = *reinterpret_cast<const uint4*>(I + b_lo + j * 32 * 32);
+            if (more) load_a();
+    #pragma unroll
+            for (int i = 0; i < TM; i++) {
+                a8[i][0] = hl_top4(fa[i].x, fa[i].y);
+                a8[i][1] = hl_top4(fa[i].z, fa[i].w);
+            }
+    #pragma unroll
+            for (int j = 0; j < TN; j++) {
+                b8[j][4] = hl_top4(fb[j].x, fb[j].y);
+                b8[j][5] = hl_top4(fb[j].z, fb[j].w);
+            }
+    #pragma unroll
+            for (int i = 0; i < TM; i++)
+    #pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
+            // slice 1
+    #pragma unroll
+            for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const uint4*>(I + a_hi1 + i * 32 * 64);
+    #pragma unroll
+            for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const uint4*>(I + b_hi1 + j * 32 * 64);
+            if (more) {
+                load_b();
+                load_next();
+            }
+    #pragma unroll
+            for (int i = 0; i < TM; i++) {
+                a8[i][2] = hl_top4(fa[i].x, fa[i].y);
+                a8[i][3] = hl_top4(fa[i].z, fa[i].w);
+                a8[i][4] = (int)fal[i].x; a8[i][5] = (int)fal[i].y; a8[i][6] = (int)fal[i].z; a8[i][7] = (int)fal[i].w;
+            }
+    #pragma unroll
+            for (int j = 0; j < TN; j++) {
+                b8[j][6] = hl_top4(fb[j].x, fb[j].y);
+                b8[j][7] = hl_top4(fb[j].z, fb[j].w);
+                b8[j][0] = (int)fbl[j].x; b8[j][1] = (int)fbl[j].y; b8[j][2] = (int)fbl[j].z; b8[j][3] = (int)fbl[j].w;
+            }
+    #pragma unroll
+            for (int i = 0; i < TM; i++)
+    #pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
+            // cross terms: [t(a_hi) | a_lo8] . [w_lo8 | t(w_hi)], 64 deep, e5m2 x e5m2, block scale 2^-11
+    #pragma unroll
+            for (int i = 0; i < TM; i++)
+    #pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 1, 1, 0, 127 - kHlLoShift, 0, 127);
+            if (NIMG == 3 && more)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
+            else if (pf && !more)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRES) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = cur + IMG == NIMG * IMG ? 0u : cur + IMG;
+        }
+
     }
 
     // ---- epilogue: * acc_scale, + bias, + residual (HL), ReLU; HL planes or f32 out.  Each wave passes its 32-pixel row blocks
@@ -476,6 +702,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
+#ifdef HL_TRACE
+        if (tr_on) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            HLT_T(6);  // epilogue to the last store's completion
+            if (lane == 0)
+                for (int k = 0; k < 8; k++) g_hl_trace[wave * 8 + k] = tr[k];
+        }
+#endif
         return;
     }
     // Cout not a multiple of the vector width (the 21-class logits, f32 out): element-wise from the accumulator layout
@@ -502,12 +736,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool G1, bool OUTF32, bool DUAL = false, int NIMG = 3>
+template <int BM, int BN, int WM, int WN, bool G1, bool OUTF32, bool DUAL = false, int NIMG = 3, bool PIPE = false>
 static hipError_t launch_hl_g(const ConvArgs& a, hipStream_t s) {
     const int M = a.OH * a.OW;
     const int mtiles = (M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
     const size_t lds = (size_t)hl_lds_bytes(BM, BN, WM, WN, NIMG);
-    auto k = conv_hl_kernel<BM, BN, WM, WN, G1, OUTF32, DUAL, NIMG>;
+    auto k = conv_hl_kernel<BM, BN, WM, WN, G1, OUTF32, DUAL, NIMG, PIPE>;
     static std::atomic<bool> attr_done[64];
     int dev = 0;
     const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
@@ -520,12 +754,21 @@ static hipError_t launch_hl_g(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WM, int WN, int NIMG, bool PIPE>
+static hipError_t launch_hl_p(const ConvArgs& a, int out_f32, hipStream_t s) {
+    const bool g1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
+    if (a.in2) return launch_hl_g<BM, BN, WM, WN, true, false, true, NIMG, PIPE>(a, s);  // (conv_hl_config_valid: 1x1, stride 1, hi / lo out)
+    if (out_f32) return g1 ? launch_hl_g<BM, BN, WM, WN, true, true, false, NIMG, PIPE>(a, s) : launch_hl_g<BM, BN, WM, WN, false, true, false, NIMG, PIPE>(a, s);
+    return g1 ? launch_hl_g<BM, BN, WM, WN, true, false, false, NIMG, PIPE>(a, s) : launch_hl_g<BM, BN, WM, WN, false, false, false, NIMG, PIPE>(a, s);
+}
+// INFUR_HL_PIPE=0: the plain K loop (measurement / bisection hook; both loops are bit-identical)
+static bool hl_pipe_on() {
+    static const bool on = !(getenv("INFUR_HL_PIPE") && atoi(getenv("INFUR_HL_PIPE")) == 0);
+    return on;
+}
 template <int BM, int BN, int WM, int WN, int NIMG = 3>
 static hipError_t launch_hl_t(const ConvArgs& a, int out_f32, hipStream_t s) {
-    const bool g1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
-    if (a.in2) return launch_hl_g<BM, BN, WM, WN, true, false, true, NIMG>(a, s);  // (conv_hl_config_valid: 1x1, stride 1, hi / lo out)
-    if (out_f32) return g1 ? launch_hl_g<BM, BN, WM, WN, true, true, false, NIMG>(a, s) : launch_hl_g<BM, BN, WM, WN, false, true, false, NIMG>(a, s);
-    return g1 ? launch_hl_g<BM, BN, WM, WN, true, false, false, NIMG>(a, s) : launch_hl_g<BM, BN, WM, WN, false, false, false, NIMG>(a, s);
+    return hl_pipe_on() ? launch_hl_p<BM, BN, WM, WN, NIMG, true>(a, out_f32, s) : launch_hl_p<BM, BN, WM, WN, NIMG, false>(a, out_f32, s);
 }
 
 // configurations of mode 5 (indices of conv_igemm.hip's table whose tile dimensions they share): 11 = 256x256 (8 waves of
@@ -602,5 +845,11 @@ hipError_t launch_hl_pack_weights(const float* w, size_t rows, size_t cols, floa
                        static_cast<unsigned*>(lo));
     return hipGetLastError();
 }
+
+#ifdef HL_TRACE
+extern "C" int infur_debug_hltrace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hl_trace), sizeof(unsigned long long) * 64);
+}
+#endif
 
 }  // namespace infur

@@ -370,7 +370,9 @@ int main() {
     hipMemset(src, 1, cap);
     hipMalloc(&sink, 64);
     hipMalloc(&cyc, 1024 * 8);
+    const bool rows_only = getenv("ROWS_ONLY") != nullptr;
     for (unsigned window : {1u << 20, 32u << 20}) {
+        if (rows_only) break;
         run<0, 3>("LDS-DMA b128", src, window, sink, cyc, 256);
         run<0, 6>("LDS-DMA b128", src, window, sink, cyc, 256);
         run<0, 12>("LDS-DMA b128", src, window, sink, cyc, 256);
@@ -379,6 +381,7 @@ int main() {
         run<1, 12>("global_load b128 -> VGPR", src, window, sink, cyc, 256);
     }
     // fewer CUs active: is the limit per CU or chip-wide?
+    if (!rows_only) {
     run<0, 6>("LDS-DMA b128, 64 workgroups", src, 1u << 20, sink, cyc, 64);
     run<1, 12>("global_load b128 -> VGPR, 64 workgroups", src, 1u << 20, sink, cyc, 64);
     {
@@ -409,11 +412,26 @@ int main() {
     run_lds<32, false, 16>(src, sink, cyc);
     run_lds<32, true, 16>(src, sink, cyc);
     run_lds<32, false, 8>(src, sink, cyc);
+    }
     // the activation operand's pattern (rows of a [pixels][C] tensor, one K step = one segment of every row), 256 MB source
     char* big;
     const unsigned big_bytes = 256u << 20;
     hipMalloc(&big, big_bytes);
     hipMemset(big, 1, big_bytes);
+    if (getenv("ROWS_ONLY")) {
+        // round 6: the same row-segment pattern with the rows L2-RESIDENT (every workgroup walks the same few MB) -- is it the
+        // pattern (partial lines per request) or HBM that holds the activation operand at 11-12 B/clk/CU?
+        for (unsigned window : {2u << 20, 8u << 20, 64u << 20, 256u << 20}) {
+            printf("-- window %u MB\n", window >> 20);
+            run_rows<32, 1>(big, window, 2048, cyc);
+            run_rows<64, 2>(big, window, 4096, cyc);
+            run_rows<128, 4>(big, window, 4096, cyc);
+            run_rows<128, 8>(big, window, 4096, cyc);
+            run_rows<64, 2>(big, window, 4096 + 128, cyc);   // pitch-padded rows
+            run_rows<128, 4>(big, window, 4096 + 128, cyc);
+        }
+        return 0;
+    }
     for (unsigned stride : {1024u, 2048u, 4096u}) {
         run_rows<32, 1>(big, big_bytes, stride / 2, cyc);   // lo plane of 256 rows: 8 KB per step
         run_rows<64, 2>(big, big_bytes, stride, cyc);       // hi plane of 256 rows: 16 KB per step
