@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int pf_mid = ksteps >= 3 ? ksteps - 3 : 0;  // the residual loads go out behind the barrier of this step: no DMA is issued at or after it
+        const int pf_mid = ksteps >= NIMG ? ksteps - NIMG : 0;  // the residual loads go out in the first iteration that issues no DMA any more (they must be the YOUNGEST loads)
         i32x8 a8[TM], b8[TN];
         // one DMA piece of the step being loaded (p = 0 .. NPW - 1: A hi, A lo, B hi, B lo), for the interleave below
         auto load_piece = [&](const int p) {
@@ -361,7 +361,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
             }
         };
         // first half of step `img`: slice 1 and the lo planes are read under the slice-0 MFMAs; leaves the step's bf8 operands in a8 / b8
-        auto first_half = [&](const char* I, const uint4* f0a, const uint4* f0b) {
+        constexpr int NMF = TM * TN;
+        constexpr int P1 = NPW / 2, P2 = NPW - P1;  // DMA pieces issued in the bf8 half / in the f16 half of an iteration
+        auto first_half = [&](const char* I, const uint4* f0a, const uint4* f0b, const bool issue) {
             uint4 f1a[TM], f1b[TN];
 #pragma unroll
             for (int i = 0; i < TM; i++) f1a[i] = *reinterpret_cast<const uint4*>(I + a_hi1 + i * 32 * 64);
@@ -377,11 +379,22 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
                 const uint4 t = *reinterpret_cast<const uint4*>(I + b_lo + j * 32 * 32);
                 b8[j][0] = (int)t.x; b8[j][1] = (int)t.y; b8[j][2] = (int)t.z; b8[j][3] = (int)t.w;
             }
+            // the second half of the step's DMA pieces goes out between these MFMAs (all of them behind one barrier crowd the CU's
+            // one texture path: 48 pieces x >= 16 cycles each inside the ~1 k cycles of the bf8 half)
+            auto pieces_behind = [&](const int m2) {
+                if (issue) {
+#pragma unroll
+                    for (int p = P1; p < NPW; p++)
+                        if ((p - P1) * (2 * NMF) / P2 == m2) load_piece(p);
+                }
+            };
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < TN; j++)
+                for (int j = 0; j < TN; j++) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f0b[j]), __builtin_bit_cast(f16x8, f0a[i]), acc[i][j], 0, 0, 0);
+                    pieces_behind(i * TN + j);
+                }
 #pragma unroll
             for (int i = 0; i < TM; i++) {
                 a8[i][0] = hl_top4(f0a[i].x, f0a[i].y);
@@ -395,8 +408,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < TN; j++)
+                for (int j = 0; j < TN; j++) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f1b[j]), __builtin_bit_cast(f16x8, f1a[i]), acc[i][j], 0, 0, 0);
+                    pieces_behind(NMF + i * TN + j);
+                }
 #pragma unroll
             for (int i = 0; i < TM; i++) {
                 a8[i][2] = hl_top4(f1a[i].x, f1a[i].y);
@@ -425,7 +440,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
             for (int i = 0; i < TM; i++) f0a[i] = *reinterpret_cast<const uint4*>(smem + a_hi0 + i * 32 * 64);
 #pragma unroll
             for (int j = 0; j < TN; j++) f0b[j] = *reinterpret_cast<const uint4*>(smem + b_hi0 + j * 32 * 64);
-            first_half(smem, f0a, f0b);
+            first_half(smem, f0a, f0b, false);
             wait_mid(0);
         }
         HLT_T(0);  // prologue + the first step's f16 half
@@ -447,17 +462,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 1, 1, 0, 127 - kHlLoShift, 0, 127);
-                    constexpr int NMF = TM * TN;
                     const int m = i * TN + j;
-                    // pieces m * NPW / NMF .. (m + 1) * NPW / NMF - 1 behind MFMA m
                     if (more && loader) {
 #pragma unroll
-                        for (int p = 0; p < NPW; p++)
-                            if (p * NMF / NPW == m) load_piece(p);
+                        for (int p = 0; p < P1; p++)
+                            if (p * NMF / P1 == m) load_piece(p);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            if (more) load_next();
             if constexpr (CANPF) {
                 if (pf && ks == pf_mid) {
                     const int e_row = lane / E_LPR, e_col = lane % E_LPR;
@@ -473,9 +485,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
                         }
                 }
             }
-            if (ks + 1 == ksteps) break;
+            if (ks + 1 == ksteps) break;  // (more is false here: nothing is left half-issued)
             HLT_T(2);  // slice-0 reads of the next step, DMA issue, bf8 MFMAs
-            first_half(smem + nxt, f0a, f0b);
+            first_half(smem + nxt, f0a, f0b, more && loader);
+            if (more) load_next();
             HLT_T(3);  // slice-1 + lo reads, f16 MFMAs
             wait_mid(ks + 1);
             HLT_T(4);  // counted vmcnt + lgkmcnt(0)
