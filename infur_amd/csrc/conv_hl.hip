@@ -363,22 +363,26 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         // first half of step `img`: slice 1 and the lo planes are read under the slice-0 MFMAs; leaves the step's bf8 operands in a8 / b8
         constexpr int NMF = TM * TN;
         constexpr int P1 = NPW / 2, P2 = NPW - P1;  // DMA pieces issued in the bf8 half / in the f16 half of an iteration
+        // With two waves per SIMD the ORDER still matters: a ds_read_b128 holds its wave ~16 cycles at issue, an LDS-DMA piece 50-60, an MFMA
+        // covers 32 (f16) / 64 (bf8): twelve reads in a row in front of the first MFMA of a half leave the pipe to the partner alone --
+        // which is in the same place of the same code behind the same barrier.  So every read and every piece sits behind an MFMA of
+        // its own (conv3x3_halo.hip's one-filler-per-MFMA rule), pinned with sched_barrier.
         auto first_half = [&](const char* I, const uint4* f0a, const uint4* f0b, const bool issue) {
             uint4 f1a[TM], f1b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) f1a[i] = *reinterpret_cast<const uint4*>(I + a_hi1 + i * 32 * 64);
-#pragma unroll
-            for (int j = 0; j < TN; j++) f1b[j] = *reinterpret_cast<const uint4*>(I + b_hi1 + j * 32 * 64);
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const uint4 t = *reinterpret_cast<const uint4*>(I + a_lo + i * 32 * 32);
-                a8[i][4] = (int)t.x; a8[i][5] = (int)t.y; a8[i][6] = (int)t.z; a8[i][7] = (int)t.w;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const uint4 t = *reinterpret_cast<const uint4*>(I + b_lo + j * 32 * 32);
-                b8[j][0] = (int)t.x; b8[j][1] = (int)t.y; b8[j][2] = (int)t.z; b8[j][3] = (int)t.w;
-            }
+            constexpr int NRD = 2 * (TM + TN);  // slice-1 hi fragments, then the lo planes
+            auto read_op = [&](const int k) {
+                if (k < TM) f1a[k] = *reinterpret_cast<const uint4*>(I + a_hi1 + k * 32 * 64);
+                else if (k < TM + TN) f1b[k - TM] = *reinterpret_cast<const uint4*>(I + b_hi1 + (k - TM) * 32 * 64);
+                else if (k < 2 * TM + TN) {
+                    const int i = k - TM - TN;
+                    const uint4 t = *reinterpret_cast<const uint4*>(I + a_lo + i * 32 * 32);
+                    a8[i][4] = (int)t.x; a8[i][5] = (int)t.y; a8[i][6] = (int)t.z; a8[i][7] = (int)t.w;
+                } else {
+                    const int j = k - 2 * TM - TN;
+                    const uint4 t = *reinterpret_cast<const uint4*>(I + b_lo + j * 32 * 32);
+                    b8[j][0] = (int)t.x; b8[j][1] = (int)t.y; b8[j][2] = (int)t.z; b8[j][3] = (int)t.w;
+                }
+            };
             // the second half of the step's DMA pieces goes out between these MFMAs (all of them behind one barrier crowd the CU's
             // one texture path: 48 pieces x >= 16 cycles each inside the ~1 k cycles of the bf8 half)
             auto pieces_behind = [&](const int m2) {
@@ -392,8 +396,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
+                    const int m = i * TN + j;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f0b[j]), __builtin_bit_cast(f16x8, f0a[i]), acc[i][j], 0, 0, 0);
-                    pieces_behind(i * TN + j);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < NRD; k++)
+                        if (k * NMF / NRD == m) read_op(k);
+                    pieces_behind(m);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
             for (int i = 0; i < TM; i++) {
@@ -449,13 +459,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
             __builtin_amdgcn_s_barrier();
             HLT_T(1);  // at the barrier
             const unsigned nxt = cur + IMG == NIMG * IMG ? 0u : cur + IMG;
-            // next step's slice 0 (unconditional: behind the last step it reads an image nobody uses any more)
+            // next step's slice 0 (unconditional: behind the last step it reads an image nobody uses any more), one read behind each of
+            // the first bf8 MFMAs; the first half of the DMA pieces of step ks + NIMG behind the MFMAs as well
             uint4 f0a[TM], f0b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) f0a[i] = *reinterpret_cast<const uint4*>(smem + nxt + a_hi0 + i * 32 * 64);
-#pragma unroll
-            for (int j = 0; j < TN; j++) f0b[j] = *reinterpret_cast<const uint4*>(smem + nxt + b_hi0 + j * 32 * 64);
-            const bool more = kl < ksteps;  // step ks + NIMG exists: its pieces go out between the bf8 MFMAs, into the image of step ks
+            const bool more = kl < ksteps;  // step ks + NIMG exists: its pieces go out between the MFMAs, into the image of step ks
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -463,6 +470,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
                 for (int j = 0; j < TN; j++) {
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 1, 1, 0, 127 - kHlLoShift, 0, 127);
                     const int m = i * TN + j;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < TM + TN; k++)
+                        if (k * NMF / (TM + TN) == m) {
+                            if (k < TM) f0a[k] = *reinterpret_cast<const uint4*>(smem + nxt + a_hi0 + k * 32 * 64);
+                            else f0b[k - TM] = *reinterpret_cast<const uint4*>(smem + nxt + b_hi0 + (k - TM) * 32 * 64);
+                        }
                     if (more && loader) {
 #pragma unroll
                         for (int p = 0; p < P1; p++)
@@ -824,10 +838,20 @@ hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s
 //      weight image of the kernels -- are then ONE contiguous block (BN x 64 bytes hi, BN x 32 bytes lo) and every 1-KB DMA piece
 //      is eight whole 128-byte lines instead of sixteen half lines 2 Ktot bytes apart: the weights are half of what a K step
 //      ingests, and the re-layout costs nothing (done once, at model load).  cols % 32 != 0 (no such GEMM layer): row-major. ----
-__global__ void hl_pack_weights_kernel(const float* __restrict__ w, size_t n4, unsigned rows, unsigned cols, float scale, _Float16* __restrict__ hi,
+// `planes` tensors back to back (blockIdx.y = plane, scale per plane in the argument block): one launch for a layer's 16 / 36 / 64 Winograd
+// planes (round 6: one launch per plane made model load ~950 launches of this kernel)
+struct HlPlaneScales {
+    float s[64];
+};
+__global__ void hl_pack_weights_kernel(const float* __restrict__ w, size_t n4, unsigned rows, unsigned cols, const HlPlaneScales sc, _Float16* __restrict__ hi,
                                        unsigned* __restrict__ lo) {
     __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
     const bool blocked = (cols & 31u) == 0;
+    const size_t pl = blockIdx.y;
+    const float scale = sc.s[pl];
+    w += pl * n4 * 4;
+    hi += pl * n4 * 4;
+    lo += pl * n4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(w)[i];
         const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
@@ -849,14 +873,23 @@ __global__ void hl_pack_weights_kernel(const float* __restrict__ w, size_t n4, u
     }
 }
 
-hipError_t launch_hl_pack_weights(const float* w, size_t rows, size_t cols, float scale, void* hi, void* lo, hipStream_t s) {
+// planes tensors [rows][cols] f32 back to back at w, plane p scaled by scales[p] -> hi planes back to back at hi (2 bytes / element), lo
+// planes back to back at lo (1 byte / element)
+hipError_t launch_hl_pack_weights_planes(const float* w, size_t rows, size_t cols, int planes, const float* scales, void* hi, void* lo, hipStream_t s) {
     const size_t n = rows * cols;
-    if (n & 3 || rows > 0xffffffffull || cols > 0xffffffffull) return hipErrorInvalidValue;
+    if (n & 3 || rows > 0xffffffffull || cols > 0xffffffffull || planes < 1 || planes > 64) return hipErrorInvalidValue;
     size_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(hl_pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, n / 4, (unsigned)rows, (unsigned)cols, scale, static_cast<_Float16*>(hi),
+    const size_t cap = planes > 1 ? 256 : 4096;
+    if (blocks > cap) blocks = cap;
+    HlPlaneScales sc;
+    for (int p = 0; p < 64; p++) sc.s[p] = p < planes ? scales[p] : 0.f;
+    hipLaunchKernelGGL(hl_pack_weights_kernel, dim3((unsigned)blocks, (unsigned)planes), dim3(256), 0, s, w, n / 4, (unsigned)rows, (unsigned)cols, sc, static_cast<_Float16*>(hi),
                        static_cast<unsigned*>(lo));
     return hipGetLastError();
+}
+
+hipError_t launch_hl_pack_weights(const float* w, size_t rows, size_t cols, float scale, void* hi, void* lo, hipStream_t s) {
+    return launch_hl_pack_weights_planes(w, rows, cols, 1, &scale, hi, lo, s);
 }
 
 #ifdef HL_TRACE

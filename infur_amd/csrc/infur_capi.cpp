@@ -368,8 +368,8 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         const size_t tot = planes * per;
         uint8_t* t_hi = (uint8_t*)scratch.p;
         uint8_t* t_lo = t_hi + hl_lo_offset(tot);
-        for (size_t pl = 0; pl < planes; pl++)
-            HIPCHK(c, launch_hl_pack_weights(w + pl * per, rows, per / rows, sc[pl], t_hi + pl * per * 2, t_lo + pl * per, c->stream));
+        // (all planes of the tensor in one launch: hi planes back to back at t_hi, lo planes back to back at t_lo)
+        HIPCHK(c, launch_hl_pack_weights_planes(w, rows, per / rows, (int)planes, sc, t_hi, t_lo, c->stream));
         HIPCHK(c, hipMemcpyAsync(w, t_hi, hl_tensor_bytes(tot), hipMemcpyDeviceToDevice, c->stream));
         *lo_out = (uint8_t*)w + hl_lo_offset(tot);
         return INFUR_OK;
@@ -384,8 +384,8 @@ int32_t split_weights(infur_ctx* c, std::vector<ConvLayer>& g) {
         const ConvLayer& L = g[i];
         e = launch_absmax((const float*)L.d_w, (size_t)L.cout * L.cin * L.k * L.k, d_max + per * i, c->stream);
         if (L.role == 's') continue;  // the stem keeps f32 weights (its kernel splits them while it stages them): scale only
-        for (size_t pl = 0; pl < P && e == hipSuccess && L.d_u; pl++)
-            e = launch_absmax(L.d_u + pl * (size_t)L.cout * L.cin, (size_t)L.cout * L.cin, d_max + per * i + 2 + pl, c->stream);
+        if (e == hipSuccess && L.d_u)  // every Winograd plane's maximum in one launch
+            e = launch_absmax_planes(L.d_u, (size_t)L.cout * L.cin, (int)P, d_max + per * i + 2, c->stream);
         if (e == hipSuccess && L.d_wcat)
             e = launch_absmax((const float*)L.d_wcat, (size_t)L.cout * (L.cin + g[i + 1].cin), d_max + per * i + 1, c->stream);
     }

@@ -89,6 +89,7 @@ bool conv_hl_areg_valid(const ConvArgs& a, int out_f32);
 hipError_t launch_conv_hl_areg(const ConvArgs& a, hipStream_t s);
 // weights of mode 5, one-off at load: f32 [n] (kernel K order) * scale -> f16 hi [n], e5m2 lo [n] (n % 4 == 0)
 hipError_t launch_hl_pack_weights(const float* w, size_t rows, size_t cols, float scale, void* hi, void* lo, hipStream_t s);  // K-block-major planes
+hipError_t launch_hl_pack_weights_planes(const float* w, size_t rows, size_t cols, int planes, const float* scales, void* hi, void* lo, hipStream_t s);  // <= 64 planes back to back, one launch
 
 // 1x1 convolution with Cin in {64, 128, 256}, f16 operands (mode 1), f16 output: the activation tile stays in registers
 // while the workgroup walks all N tiles (conv1x1_areg.hip).  Reached through launch_conv_igemm as one more configuration.
@@ -184,6 +185,8 @@ hipError_t launch_repack_oihw_to_ohwi(const float* src, void* dst, int f16, int 
 // split: in place, every 32 consecutive f32 (one 128-byte K-step row chunk) become
 // [32 x f16 hi][32 x f16 lo] of w * scale, hi = rne(w*scale), lo = rne(w*scale - hi).
 hipError_t launch_absmax(const float* w, size_t n, float* out, hipStream_t s);
+// out[p] = max |plane p| for `planes` tensors of `per` elements back to back, one launch (out must be zeroed)
+hipError_t launch_absmax_planes(const float* w, size_t per, int planes, float* out, hipStream_t s);
 // fp8_cross: the [f16 hi][e5m2 lo * 2^11][e5m2 hi] row form of conv_igemm mode 3 instead of [f16 hi][f16 lo]
 hipError_t launch_split_weights(float* w, size_t n, float scale, int fp8_cross, hipStream_t s);
 // two-source GEMM weights (one-off at load): out[r] = a[r] ++ b[r] for `rows` rows of a_bytes / b_bytes

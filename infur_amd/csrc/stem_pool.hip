@@ -415,6 +415,9 @@ __global__ void __launch_bounds__(256, 2)
                        float a_scale, float w_scale, float acc_scale, unsigned* __restrict__ amax, const u32x4s* __restrict__ wimg,
                        const StemQuant sq = StemQuant{}) {
     constexpr int NP = SPLIT ? 2 : 1;  // operand planes: hi (, lo)
+    // three-byte output (INFUR_DTYPE_F16_HL): hl_split4 requires MODE.FP16_OVFL = 1 -- a pooled value beyond 65504 clamps instead of
+    // becoming hi = inf, rem = -inf
+    if constexpr (sizeof(OutT) == 3) hl_set_fp16_ovfl();
     __shared__ __attribute__((aligned(16))) float smem[SP_LDS_FLOATS];
     _Float16* patch = reinterpret_cast<_Float16*>(smem);  // [NP][SP_IH][S16_PSTR]
     _Float16* wsm = patch + NP * S16_PATCH_H;              // [NP][64][S16_WSTR]
@@ -723,6 +726,24 @@ __global__ void absmax_kernel(const float* __restrict__ w, size_t n, float* __re
 hipError_t launch_absmax(const float* w, size_t n, float* out, hipStream_t s) {
     const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, w, n, out);
+    return hipGetLastError();
+}
+
+// `planes` tensors of `per` elements each, back to back: out[p] = max |w[p * per + i]| in ONE launch (blockIdx.y = plane) -- the 16 / 36 /
+// 64 Winograd planes of a layer (round 6: model load in the split / HL modes issued ~950 of the single-tensor launches above)
+__global__ void absmax_planes_kernel(const float* __restrict__ w, size_t per, float* __restrict__ out) {
+    const float* wp = w + (size_t)blockIdx.y * per;
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(wp[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out + blockIdx.y), __float_as_uint(m));
+}
+
+hipError_t launch_absmax_planes(const float* w, size_t per, int planes, float* out, hipStream_t s) {
+    if (planes < 1 || planes > 65535) return hipErrorInvalidValue;
+    const int blocks = (int)((per + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(absmax_planes_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks), planes), dim3(256), 0, s, w, per, out);
     return hipGetLastError();
 }
 
