@@ -803,7 +803,7 @@ static hipError_t launch_hl_t(const ConvArgs& a, int out_f32, hipStream_t s) {
 // 14 = 128x256 as FOUR waves of 128x64 with a ring of two images: two workgroups per CU
 bool conv_hl_config_valid(const ConvArgs& a, int cfg, int out_f32) {
     if (cfg == 15) return conv_hl_areg_valid(a, out_f32);  // conv_hl_areg.hip: the activation fragment in registers (1x1 expansions)
-    if (cfg != 11 && cfg != 0 && cfg != 6 && cfg != 5 && cfg != 12 && cfg != 14 && cfg != 13) return false;
+    if (cfg != 11 && cfg != 0 && cfg != 6 && cfg != 5 && cfg != 12 && cfg != 14 && cfg != 13 && cfg != 16 && cfg != 17) return false;
     if (!a.in_lo || !a.wt_lo) return false;
     if (a.in2 && (!a.in2_lo || out_f32 || a.res || a.KH != 1 || a.KW != 1 || a.pad != 0 || a.stride != 1 || a.Cin2 % HL_KC != 0 || a.batch > 1 ||
                   (size_t)a.H2 * a.W2 * a.Cin2 * 2 >= 0x80000000ull))
@@ -813,7 +813,7 @@ bool conv_hl_config_valid(const ConvArgs& a, int cfg, int out_f32) {
     if (out_f32 ? (a.res != nullptr) : (!a.out_lo || (a.res != nullptr) != (a.res_lo != nullptr) || (a.Cout & 7))) return false;
     if (a.batch > 1 && (a.in_bs & 1 || a.wt_bs & 1 || !out_f32)) return false;
     if ((size_t)a.Cout * (a.in2 ? a.Cin + a.Cin2 : a.KH * a.KW * a.Cin) * 2 >= 0x80000000ull) return false;
-    const int bn = (cfg == 11 || cfg == 5 || cfg == 14 || cfg == 13) ? 256 : 128;
+    const int bn = (cfg == 11 || cfg == 5 || cfg == 14 || cfg == 13 || cfg == 16) ? 256 : 128;
     return bn <= a.Cout || bn == 128;  // Cout < 128 (layer1, the logits): the 128-wide N tile with its surplus rows out of range
 }
 
@@ -829,6 +829,10 @@ hipError_t launch_conv_hl(const ConvArgs& a, int out_f32, int cfg, hipStream_t s
         case 12: return launch_hl_t<256, 128, 2, 2, 2>(a, out_f32, s);
         case 14: return launch_hl_t<128, 256, 1, 4, 2>(a, out_f32, s);
         case 13: return launch_hl_t<256, 256, 4, 2>(a, out_f32, s);  // 8 waves of 64 x 128: a wave's epilogue rows are 128 channels wide
+        // round 6: the two-workgroups-per-CU forms with 64 x 128 wave tiles (the expansions' epilogue moves whole 256 / 128-byte rows
+        // of the hi / lo planes per pixel instead of 128 / 64)
+        case 16: return launch_hl_t<128, 256, 2, 2, 2>(a, out_f32, s);
+        case 17: return launch_hl_t<256, 128, 4, 1, 2>(a, out_f32, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -120,6 +120,8 @@ const char* conv_igemm_config_name(int cfg, int mode) {
             case 12: return "conv_hl<256,128,4w>";
             case 14: return "conv_hl<128,256,4w>";
             case 13: return "conv_hl<256,256,wn2>";
+            case 16: return "conv_hl<128,256,4w,wn2>";
+            case 17: return "conv_hl<256,128,4w,wn2>";
             case 15: return "conv_hl<128,areg>";
             default: return "conv_hl<?>";
         }

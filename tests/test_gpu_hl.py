@@ -193,7 +193,7 @@ def test_hl_tile_configurations_are_bit_identical(tmp_path):
         return np.load(path)
 
     ref = run(0, str(tmp_path / "cfg0.npz"))
-    for cfg in (5, 6, 11, 12, 13, 14, 15, None):
+    for cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, None):
         got = run(cfg, str(tmp_path / f"cfg{cfg}.npz"))
         for k in ref.files:
             assert (ref[k].view(np.uint8) == got[k].view(np.uint8)).all(), (cfg, k)
