@@ -46,3 +46,28 @@ def test_f32_oracles_agree_with_float64_on_hostile_parameters(hostile_blob):
         e_max, e_rel = H.errors(got, want)
         print(f"{name}: max-abs/max-abs {e_max:.2e}, per-element (|ref| > 1e-2 max) {e_rel:.2e}")
         assert e_max < 2e-5 and e_rel < 1e-3
+
+
+def test_every_seed_of_the_distribution_is_hostile_finite_and_distinct():
+    """tests/hostile.py::SEEDS (round 6): the six parameter sets the fast modes' accuracy is stated over are six DIFFERENT sets, each a
+    finite O(1) function with channels three decades apart, and the torch f32 oracle agrees with float64 on each (so it can grade there)."""
+    import hashlib
+
+    from oracle.infur_oracle import COracle, TorchModel
+
+    co = COracle()
+    x = co.pack_normalize(H.saturated_frame(72, 104, index=2))
+    seen = set()
+    for seed, base in H.SEEDS:
+        blob = H.hostile_blob(seed=seed, base_seed=base)
+        seen.add(hashlib.sha256(blob).hexdigest())
+        taps = {}
+        ref, ref_aux = TorchModel(blob, float64=True).forward_lowres(x, taps=taps)
+        assert np.isfinite(ref.numpy()).all() and 0.5 < float(ref.abs().max()) < 50.0, hex(seed)
+        cm = taps["backbone.layer3.5.conv3"].abs().amax(dim=(1, 2)).numpy()
+        assert cm[cm > 0].max() / cm[cm > 0].min() > 1e3, hex(seed)
+        t32, t32_aux = TorchModel(blob).forward_lowres(x)
+        for got, want in ((t32.numpy(), ref.numpy()), (t32_aux.numpy(), ref_aux.numpy())):
+            e_max, e_rel = H.errors(got, want)
+            assert e_max < 2e-5 and e_rel < 1e-3, (hex(seed), e_max, e_rel)
+    assert len(seen) == len(H.SEEDS)
