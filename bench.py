@@ -968,9 +968,11 @@ def pcie_inclusive_rate(a, dev, blob, frames_np, dtype="f32", zero_copy=False, c
     """the headline workload with the frames in HOST memory -- H2D, forward, decode, mask D2H through the
     depth-3 infur_stream ring (two compute lanes when --contexts-per-gpu >= 2), wall-clock frames/s.  Reported next to
     `value` (which is HBM-resident by the bench contract), never as it.
-    zero_copy (ABI 5): infur_stream_acquire / _commit / _collect_view / _release -- the frames are produced IN PLACE in the ring's
-    pinned slots (each slot is filled once here: a decoder's read() into the slot is the producer's own cost either way) and the masks
-    are consumed in place; the copying form adds one pageable -> pinned memcpy per frame and one back per mask."""
+    zero_copy (ABI 5): infur_stream_acquire / _commit / _collect_view / _release -- EVERY frame is produced into its pinned slot (one
+    np.copyto per frame: what a decoder's read() into the slot costs the producer) and the masks are consumed in place; the copying form
+    pays the same production into a pageable frame BEFORE the timed region (the frames exist) plus one pageable -> pinned memcpy per frame
+    and one back per mask.  One mask of the zero-copy run is compared with the copying run's (frame ids and slot contents
+    must belong together)."""
     from infur_amd.app import StreamPath
     from infur_amd.processors import Context, Group, Model, ModelCmd
 
@@ -995,27 +997,31 @@ def pcie_inclusive_rate(a, dev, blob, frames_np, dtype="f32", zero_copy=False, c
             list(sp.run(frames, a.scale))
             dt = time.perf_counter() - t0
         else:
-            seen = set()
+            check = {}
 
-            def pump(items):
+            def pump(items, keep=None):
+                def drain():
+                    fid, rgba, _ = sp.collect_view()
+                    if keep is not None and fid == keep:
+                        check["mask"] = rgba.copy()
+                    sp.release()
+
                 for fid, img in items:
                     if sp.pending() >= depth:
-                        sp.collect_view()
-                        sp.release()
+                        drain()
                     h, w = img.shape[:2]
-                    slot = sp.acquire(w, h, a.scale)
-                    if slot.ctypes.data not in seen:  # a slot is produced into once; afterwards the frame "is already there"
-                        np.copyto(slot, img)
-                        seen.add(slot.ctypes.data)
+                    np.copyto(sp.acquire(w, h, a.scale), img)  # the producer's own cost: every frame goes into its slot
                     sp.commit(w, h, a.scale, fid)
                 while sp.pending():
-                    sp.collect_view()
-                    sp.release()
+                    drain()
 
             pump(frames[:8])
             t0 = time.perf_counter()
-            pump(frames)
+            pump(frames, keep=frames[-1][0])
             dt = time.perf_counter() - t0
+            ref = dict(sp.run(frames[-1:], a.scale))[frames[-1][0]]  # the same frame through the copying calls
+            if "mask" not in check or not (check["mask"] == ref).all():
+                raise RuntimeError("zero-copy mask differs from the copying path's")
         sp.close()
         return n / dt
     finally:

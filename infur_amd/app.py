@@ -336,7 +336,12 @@ class StreamPath:
     # ---- zero-copy ingest / egress (ABI 5): the ring's pinned slots lent to the caller ----
     def acquire(self, w: int, h: int, factor: float) -> np.ndarray:
         """-> the next slot's pinned input buffer as an [h, w, 3] u8 array to fill in place (what the reference's decoder does with its
-        reused BgrImage, ff-video/src/decoder.rs:156-165); then ``commit``."""
+        reused BgrImage, ff-video/src/decoder.rs:156-165); then ``commit``.
+
+        LIFETIME (this array and the views of ``collect_view``): numpy views over pinned memory the LIBRARY owns.  The input view is
+        valid until ``commit`` / ``abandon`` / the next ``acquire``; the output views until ``release`` (or a copying ``collect`` of the same
+        frame).  After that -- and after ``close()``, a re-acquire with another frame size (the slot is re-allocated) or a failed batch call
+        that drops the ring -- they dangle: copy what has to outlive the slot (``run_zero_copy`` yields copies for that reason)."""
         p = C.c_void_p(None)
         self.ctx.check(self.ctx.L.infur_stream_acquire(self.h, w, h, float(np.float32(factor)), C.byref(p)))
         buf = (C.c_uint8 * (w * h * 3)).from_address(p.value)

@@ -1061,13 +1061,6 @@ static bool pool_stream_reserve(const infur_ctx* c, bool on) {
     return true;
 }
 
-// does another live context hold this context's (pool) stream?
-static bool stream_is_shared(const infur_ctx* c) {
-    if (c->pool_slot < 0) return false;  // the caller's own stream, or a private one
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    return g_pool_users[c->device][c->pool_slot] > 1;
-}
-
 int32_t infur_ctx_create(const infur_options* opts, infur_ctx** out) {
     try {
         if (!out) return INFUR_E_INVALID_ARG;
@@ -1733,7 +1726,10 @@ int32_t infur_frame_advance_dev(infur_ctx* c, const void* d_bgr, uint32_t w, uin
             return rc;
         }
         // capture: the same enqueue code, recorded instead of executed -- never on a stream another context enqueues to
-        if (stream_is_shared(c)) return frame_body(c, d_bgr, w, h, factor, mode, d_rgba, d_scaled, *ow, *oh);
+        // (RESERVE the pool slot here, at capture time, not only in infur_ctx_set_graph_replay: a slot that was shared back then and has
+        //  since become this context's alone would otherwise be captured unreserved, and pool_stream() on another thread could hand
+        //  it to a new context in the middle of the capture -- ADVICE r5.  A slot that is shared NOW stays eager.)
+        if (!pool_stream_reserve(c, true)) return frame_body(c, d_bgr, w, h, factor, mode, d_rgba, d_scaled, *ow, *oh);
         const uint64_t gen0 = c->mem_gen;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
@@ -1789,7 +1785,7 @@ int32_t infur_ctx_set_graph_replay(infur_ctx* c, uint32_t enable) {
         // context's thread enqueues between BeginCapture and EndCapture would be recorded into this context's graph, not executed
         // (ThreadLocal capture mode only restricts the capturing thread) -- so the slot is RESERVED instead: while this context is
         // its only user, pool_stream hands it to nobody else.  A slot that is already shared stays shared and simply never captures
-        // (frame_advance_dev runs eagerly: stream_is_shared).
+        // (frame_advance_dev runs eagerly: the reservation at capture time fails).
         (void)pool_stream_reserve(c, true);
     }
     c->graph_streak = 0;
