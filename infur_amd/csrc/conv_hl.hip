@@ -714,13 +714,9 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
 #pragma unroll
                             for (int t = 0; t < 8; t++) x[t] += (float)rh[it][t] + lo[t];
                         }
-                        if (a.relu) {
-#pragma unroll
-                            for (int t = 0; t < 8; t++) x[t] = fmaxf(x[t], 0.f);
-                        }
                         f16x8 hv;
                         u32x2 lv;
-                        hl_split8(x, hv, lv);
+                        hl_split8(x, hv, lv, a.relu ? 0.f : -kHlHiMax);  // (the ReLU is the split's lower clamp)
                         *reinterpret_cast<f16x8*>(out_hi + (size_t)m * a.Cout + n) = hv;
                         *reinterpret_cast<u32x2*>(out_lo + (size_t)m * a.Cout + n) = lv;
                     }

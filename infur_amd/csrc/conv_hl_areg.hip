@@ -319,13 +319,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) conv_hl_areg_kernel(
 #pragma unroll
                     for (int t = 0; t < 8; t++) x[t] += (float)rh[t] + lo[t];
                 }
-                if (a.relu) {
-#pragma unroll
-                    for (int t = 0; t < 8; t++) x[t] = fmaxf(x[t], 0.f);
-                }
                 f16x8 hv;
                 u32x2 lv;
-                hl_split8(x, hv, lv);
+                hl_split8(x, hv, lv, a.relu ? 0.f : -kHlHiMax);  // (the ReLU is the split's lower clamp)
                 *reinterpret_cast<f16x8*>(ph) = hv;
                 *reinterpret_cast<u32x2*>(pl) = lv;
             }

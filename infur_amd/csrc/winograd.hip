@@ -380,13 +380,13 @@ __device__ __forceinline__ f32x8w hl_load8(const _Float16* hi, const unsigned ch
     for (int t = 0; t < 8; t++) v[t] = x[t];
     return v;
 }
-__device__ __forceinline__ void hl_store8(_Float16* hi, unsigned char* lo, size_t e, const f32x8w v) {
+__device__ __forceinline__ void hl_store8(_Float16* hi, unsigned char* lo, size_t e, const f32x8w v, const float lb = -kHlHiMax) {
     float x[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) x[t] = v[t];
     hl_f16x8 hv;
     hl_u32x2 lv;
-    hl_split8(x, hv, lv);
+    hl_split8(x, hv, lv, lb);
     *reinterpret_cast<hl_f16x8*>(hi + e) = hv;
     *reinterpret_cast<hl_u32x2*>(lo + e) = lv;
 }
@@ -493,12 +493,8 @@ __global__ void __launch_bounds__(128)
                 for (int b = 0; b < MT; b++) {
                     const int x = g.d * (MT * tx + b) + rx;
                     if (x >= g.W) continue;
-                    f32x8w v = yv[b] + bv;
-                    if (relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    hl_store8(out_hi, out_lo, ((size_t)y * g.W + x) * Cout + n0, v);
+                    const f32x8w v = yv[b] + bv;
+                    hl_store8(out_hi, out_lo, ((size_t)y * g.W + x) * Cout + n0, v, relu ? 0.f : -kHlHiMax);  // (the ReLU is the split's lower clamp)
                 }
             }
         }
