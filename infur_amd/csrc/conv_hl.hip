@@ -362,7 +362,11 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         };
         // first half of step `img`: slice 1 and the lo planes are read under the slice-0 MFMAs; leaves the step's bf8 operands in a8 / b8
         constexpr int NMF = TM * TN;
-        constexpr int P1 = NPW / 2, P2 = NPW - P1;  // DMA pieces issued in the bf8 half / in the f16 half of an iteration
+        // DMA pieces issued in the bf8 half / in the f16 half of an iteration.  Ring of three: half and half (two steps of cover either way).
+        // Ring of two: ALL of them in the bf8 half, right behind the barrier -- a piece issued in the f16 half would be waited for at the
+        // end of that same half (one step of cover is all this ring has: the trace of a layer4 conv3 tile showed 0.75-1.0 k cycles of
+        // counted-vmcnt wait per step, LAB_NOTES round 6)
+        constexpr int P1 = NIMG == 2 ? NPW : NPW / 2, P2 = NPW - P1;
         // With two waves per SIMD the ORDER still matters: a ds_read_b128 holds its wave ~16 cycles at issue, an LDS-DMA piece 50-60, an MFMA
         // covers 32 (f16) / 64 (bf8): twelve reads in a row in front of the first MFMA of a half leave the pipe to the partner alone --
         // which is in the same place of the same code behind the same barrier.  So every read and every piece sits behind an MFMA of
@@ -386,10 +390,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
             // the second half of the step's DMA pieces goes out between these MFMAs (all of them behind one barrier crowd the CU's
             // one texture path: 48 pieces x >= 16 cycles each inside the ~1 k cycles of the bf8 half)
             auto pieces_behind = [&](const int m2) {
-                if (issue) {
+                if constexpr (P2 > 0) {
+                    if (issue) {
 #pragma unroll
-                    for (int p = P1; p < NPW; p++)
-                        if ((p - P1) * (2 * NMF) / P2 == m2) load_piece(p);
+                        for (int p = P1; p < NPW; p++)
+                            if ((p - P1) * (2 * NMF) / P2 == m2) load_piece(p);
+                    }
                 }
             };
 #pragma unroll
