@@ -40,6 +40,10 @@
 
 namespace infur {
 
+#ifndef HL_TWOBAR
+#define HL_TWOBAR 1
+#endif
+
 // Instrumentation build (make EXTRA="-DHL_TRACE -DHLT_CIN=2048 -DHLT_COUT=512", scripts/hl_trace.py): workgroup HLT_WG of the launches with
 // that shape accumulates, per wave, the shader cycles (s_memtime) of each phase of the pipelined K loop.  Timestamps sit where no LDS
 // read is outstanding (s_memtime shares lgkmcnt with them).  Not compiled into the product library.
@@ -367,6 +371,11 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
         // end of that same half (one step of cover is all this ring has: the trace of a layer4 conv3 tile showed 0.75-1.0 k cycles of
         // counted-vmcnt wait per step, LAB_NOTES round 6)
         constexpr int P1 = NIMG == 2 ? NPW : NPW / 2, P2 = NPW - P1;
+        // Ring of two, TWO barriers per step (round 6, after the trace of a layer4 conv3 tile: 0.75-1.0 k cycles of vmcnt wait per step): the
+        // barrier in front of the bf8 MFMAs only frees the image of step k for the DMA of step k + 2; the wait for step k + 1 and the
+        // barrier that publishes it come BEHIND the bf8 MFMAs -- half a step more cover for every piece -- and the next step's slice 0 is
+        // read there, in front of its MFMAs.
+        constexpr bool TWOBAR = NIMG == 2 && HL_TWOBAR;
         // With two waves per SIMD the ORDER still matters: a ds_read_b128 holds its wave ~16 cycles at issue, an LDS-DMA piece 50-60, an MFMA
         // covers 32 (f16) / 64 (bf8): twelve reads in a row in front of the first MFMA of a half leave the pipe to the partner alone --
         // which is in the same place of the same code behind the same barrier.  So every read and every piece sits behind an MFMA of
@@ -457,7 +466,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
 #pragma unroll
             for (int j = 0; j < TN; j++) f0b[j] = *reinterpret_cast<const uint4*>(smem + b_hi0 + j * 32 * 64);
             first_half(smem, f0a, f0b, false);
-            wait_mid(0);
+            if constexpr (TWOBAR)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else
+                wait_mid(0);
         }
         HLT_T(0);  // prologue + the first step's f16 half
         unsigned cur = 0;
@@ -479,7 +491,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int k = 0; k < TM + TN; k++)
-                        if (k * NMF / (TM + TN) == m) {
+                        if (!TWOBAR && k * NMF / (TM + TN) == m) {
                             if (k < TM) f0a[k] = *reinterpret_cast<const uint4*>(smem + nxt + a_hi0 + k * 32 * 64);
                             else f0b[k - TM] = *reinterpret_cast<const uint4*>(smem + nxt + b_hi0 + (k - TM) * 32 * 64);
                         }
@@ -507,10 +519,27 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) conv_hl_kernel(const ConvArgs 
             }
             if (ks + 1 == ksteps) break;  // (more is false here: nothing is left half-issued)
             HLT_T(2);  // slice-0 reads of the next step, DMA issue, bf8 MFMAs
+            if constexpr (TWOBAR) {
+                // step ks + 1 has landed: in flight behind it only what this iteration issued (the pieces of step ks + 2, or the residual)
+                if (more)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+                else if (CANPF && pf && ks >= pf_mid)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < TM; i++) f0a[i] = *reinterpret_cast<const uint4*>(smem + nxt + a_hi0 + i * 32 * 64);
+#pragma unroll
+                for (int j = 0; j < TN; j++) f0b[j] = *reinterpret_cast<const uint4*>(smem + nxt + b_hi0 + j * 32 * 64);
+            }
             first_half(smem + nxt, f0a, f0b, more && loader);
             if (more) load_next();
             HLT_T(3);  // slice-1 + lo reads, f16 MFMAs
-            wait_mid(ks + 1);
+            if constexpr (TWOBAR)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (every read of image ks + 1 is back: the barrier at the loop's top frees it)
+            else
+                wait_mid(ks + 1);
             HLT_T(4);  // counted vmcnt + lgkmcnt(0)
             cur = nxt;
         }
